@@ -1,0 +1,407 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures in this directory by running the REFERENCE
+(read-only checkout at /root/reference) through tests/golden/ref_harness.py.
+
+Run in the build container only:  python tests/golden/make_golden.py
+The outputs (*.json expected values, *.npz inputs) are committed; the tests
+never need the reference.  Inputs come from the repo's own synthetic generator
+or from hand-written records, never from reference files.
+"""
+import json
+import os
+import sys
+
+_FEATS = "AVX512F AVX512CD AVX512VL AVX512BW AVX512DQ AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR AVX2 FMA3"
+if os.environ.get("NPY_DISABLE_CPU_FEATURES") != _FEATS:
+    # numpy must come up with its SIMD sorts off so np.argsort breaks ties the
+    # way the numpy pinned by the reference does.
+    env = dict(os.environ, NPY_DISABLE_CPU_FEATURES=_FEATS)
+    import subprocess
+    sys.exit(subprocess.call([sys.executable] + sys.argv, env=env))
+
+import random  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_harness as H  # noqa: E402
+from himut_amd.readbatch import ReadBatch, batch_from_records  # noqa: E402
+from himut_amd import synth  # noqa: E402
+
+
+def _canon(v):
+    if isinstance(v, (np.floating, float)):
+        return float(v)
+    if isinstance(v, (np.integer, int)):
+        return int(v)
+    return v
+
+
+def canon_records(recs):
+    return [[_canon(x) for x in r[1:]] for r in recs]  # chrom dropped (constant)
+
+
+def save(case, expected, batch=None, extra_npz=None):
+    with open(os.path.join(HERE, case + ".json"), "w") as o:
+        json.dump(expected, o, indent=0, sort_keys=True)
+    d = {}
+    if batch is not None:
+        d.update(batch.to_npz_dict())
+    if extra_npz:
+        d.update(extra_npz)
+    if d:
+        np.savez_compressed(os.path.join(HERE, case + ".npz"), **d)
+    print("wrote", case, "records" in expected and len(expected["records"]))
+
+
+def thresholds_of(ref, bam, chroms, sizes):
+    return ref.bamlib.get_thresholds(bam, chroms, sizes)
+
+
+def worker_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, phase_block=0, overrides=None,
+                md_threshold=None, qlen_limits=None, mutate=None, create_pon=False):
+    ref = H.load_reference()
+    s = synth.generate(cfg)
+    b = s.batch
+    if mutate is not None:
+        mutate(b)
+    bam = "/fake/{}.bam".format(case)
+    H.register_bam(bam, {b.name: b})
+    sizes = {b.name: b.length}
+    ql, qu, md = thresholds_of(ref, bam, [b.name], sizes)
+    if md_threshold is not None:
+        md = md_threshold
+    if qlen_limits is not None:
+        ql, qu = qlen_limits
+    if chunks is None:
+        _, c2c = ref.util.load_loci(None, None, sizes)
+        chunks = [(s_, e_) for (_, s_, e_) in c2c[b.name]]
+    exp = {"chunks": chunks, "qlen_lower_limit": ql, "qlen_upper_limit": qu, "md_threshold": md,
+           "overrides": overrides or {}, "contig": b.name, "length": b.length}
+    common = pon = None
+    if with_sets:
+        common = os.path.join(tmpdir, case + ".common.vcf")
+        pon = os.path.join(tmpdir, case + ".pon.vcf")
+        # a first pass without sets gives true candidates to seed the side files with
+        recs0, _ = H.run_reference_worker(bam, b.name, chunks, ql, qu, md, **(overrides or {}))
+        passing = [(r[1], r[2], r[3]) for r in recs0 if r[4] in ("PASS", "LowDepth", "HighDepth")]
+        synth.write_common_snps_vcf(common, s, seed=cfg.seed, extra_sites=passing[3::5])
+        synth.write_pon_vcf(pon, s, seed=cfg.seed, extra_sites=passing[::7])
+        exp["common_vcf"] = open(common).read()
+        exp["pon_vcf"] = open(pon).read()
+        exp["common_set"] = sorted([list(t) for t in ref.vcflib.load_common_snp(b.name, common)])
+        exp["pon_set"] = sorted([list(t) for t in ref.vcflib.load_pon(b.name, pon)])
+    phase_sets = None
+    if phase_block:
+        pv = os.path.join(tmpdir, case + ".phased.vcf")
+        synth.write_phased_vcf(pv, s, block=phase_block)
+        hb, hp, hs, c2c = ref.vcflib.load_phased_hetsnps(pv, [b.name], sizes)
+        phase_sets = (dict(hb[b.name]), dict(hp[b.name]), dict(hs[b.name]))
+        chunks = [(s_, e_) for (_, s_, e_) in c2c[b.name]]
+        exp["chunks"] = chunks
+        exp["phased_vcf"] = open(pv).read()
+        exp["phase_sets"] = {"hbit": phase_sets[0], "hpos": phase_sets[1],
+                             "hetsnp": {k: [list(t) for t in v] for k, v in phase_sets[2].items()}}
+    recs, log = H.run_reference_worker(bam, b.name, chunks, ql, qu, md, common_snps=common, panel_of_normals=pon,
+                                       phase=bool(phase_block), phase_sets=phase_sets,
+                                       create_panel_of_normals=create_pon, **(overrides or {}))
+    exp["create_panel_of_normals"] = create_pon
+    exp["records"] = canon_records(recs)
+    exp["log"] = [int(x) for x in log]
+    # formatted VCF body as the reference's own writer prints it
+    out = os.path.join(tmpdir, case + ".out.vcf")
+    cwd = os.getcwd()
+    os.chdir(tmpdir)
+    try:
+        if phase_block:
+            ref.vcflib.dump_phased_sbs(out, "#HEADER", [b.name], {b.name: recs})
+        else:
+            ref.vcflib.dump_sbs(out, "#HEADER", [b.name], {b.name: recs})
+        ref.vcflib.dump_call_log([b.name], {b.name: log})
+        exp["log_text"] = open("himut.log").read()
+    finally:
+        os.chdir(cwd)
+    exp["vcf_text"] = open(out).read()
+    exp["sm_vcf_text"] = open(out.replace(".vcf", ".single_molecule_mutations.vcf")).read()
+    from collections import Counter
+    exp["status_histogram"] = dict(Counter(r[4] for r in recs))
+    print("   ", case, exp["status_histogram"], log)
+    save(case, exp, batch=b)
+    return exp
+
+
+def small_cfg(seed, **kw):
+    d = dict(seed=seed, contig_len=30000, read_len_mean=3000, read_len_sd=500, read_len_min=1200, read_len_max=5000,
+             name="chr7")
+    d.update(kw)
+    return synth.SynthConfig(**d)
+
+
+def leaf_gtlib(n=400):
+    """get_germ_gt / get_germ_gq over random and tie-heavy columns (gtlib.py:122-174)."""
+    ref = H.load_reference()
+    rs = random.Random(5)
+    ref.gtlib.init(1 / (10 ** 3))
+    out = []
+    for k in range(n):
+        depth = rs.choice([1, 2, 3, 5, 8, 13, 30, 60])
+        refb = rs.choice("ATGC")
+        mode = k % 5
+        alleles, bqs = [], []
+        for _ in range(depth):
+            if mode == 0:
+                a = refb if rs.random() < 0.9 else rs.choice("ATGC")
+            elif mode == 1:
+                a = rs.choice([refb, "ATGC"[(("ATGC".index(refb)) + 1) % 4]])
+            elif mode == 2:
+                a = rs.choice("ATGC")
+            elif mode == 3:
+                a = rs.choice([x for x in "ATGC" if x != refb][:2])
+            else:
+                a = rs.choice([x for x in "ATGC" if x != refb][:1])
+            alleles.append(a)
+            bqs.append(93 if (mode in (1, 3) or rs.random() < 0.8) else rs.randint(1, 92))
+        a2b = {0: [], 1: [], 2: [], 3: [], 4: [], 5: []}
+        for a, q in zip(alleles, bqs):
+            a2b[ref.util.base2idx[a]].append(q)
+        gt, gq, state, gt2state = ref.gtlib.get_germ_gt(refb, a2b)
+        alt = rs.choice([x for x in "ATGC" if x != refb])
+        germ_gq = ref.gtlib.get_germ_gq(refb + alt, gt2state, a2b)
+        pls, _ = ref.gtlib.get_germ_gt_pD(refb, a2b)
+        out.append({"ref": refb, "alleles": "".join(alleles), "bqs": bqs, "gt": gt, "gq": int(gq), "state": state,
+                    "germ_gq": int(germ_gq), "pls": [float(x) for x in pls]})
+    tables = {"hom": [ref.gtlib.get_log10_one_minus_epsilon(q) for q in range(1, 94)],
+              "het": [ref.gtlib.get_log10_one_half_minus_epsilon(q) for q in range(1, 94)],
+              "err": [ref.gtlib.get_log10_epsilon(q / 3) for q in range(1, 94)],
+              "prior": {k: ref.gtlib.get_log10_germ_gt_prior(k) for k in ("homref", "het", "hetalt", "homalt")}}
+    save("leaf_gtlib", {"vectors": out, "tables": tables})
+
+
+class _Obj:
+    pass
+
+
+def leaf_cs():
+    """cs2tuple / cs2subindel / identity / window helpers on hand-written tags."""
+    ref = H.load_reference()
+    cases = [
+        (":10*ag:5+tt:3-ac:7", "ACGTACGTACGTACGTAGTTCCCAAAAAAAG", 0, 100),
+        ("=ACGTA*ct=GG+a=T-gg=C", "ACGTATGGATC", 0, 5),
+        (":4*na:4", "NNACGTAACGTT", 2, 50),
+        (":3+acgt:3", "ACGACGTACG", 0, 0),
+        (":2-a:2*ga*ct:1", "ACGTACT", 0, 9),
+    ]
+    out = []
+    for cs, seq, qstart, tstart in cases:
+        o = _Obj()
+        o.qstart = qstart
+        o.qseq = seq
+        o.tstart = tstart
+        o.bq_int_lst = list(range(10, 10 + len(seq)))
+        ref.cslib.cs2tuple(o, cs)
+        ref.cslib.cs2subindel(o)
+        o.qlen = len(seq)
+        ident = ref.bamlib.BAM.get_blast_sequence_identity(o)
+        out.append({"cs": cs, "seq": seq, "qstart": qstart, "tstart": tstart, "bq": o.bq_int_lst,
+                    "tuples": [list(t) for t in o.cstuple_lst], "tsbs": [list(t) for t in o.tsbs_lst],
+                    "qsbs": [list(t) for t in o.qsbs_lst], "mismatch": [list(t) for t in o.mismatch_lst],
+                    "identity": ident})
+    grid = []
+    for qlen in (100, 1000, 15000):
+        for qpos in (0, 5, 19, 20, 21, qlen - 21, qlen - 20, qlen - 19, qlen - 1, qlen // 2):
+            for w in (20, 7):
+                grid.append({"tpos": 1000, "qpos": qpos, "qlen": qlen, "window": w,
+                             "range": list(ref.bamlib.get_mismatch_range(1000, qpos, qlen, w))})
+    trims = []
+    for qlen in (99, 100, 101, 3333, 15000, 15001, 24999):
+        for mt in (0.01, 0.0, 0.05):
+            a, b = ref.bamlib.get_trimmed_range(qlen, mt)
+            trims.append({"qlen": qlen, "min_trim": mt, "start": a, "end": b})
+    chunks = {}
+    for L in (1000, 200000, 200002, 400002, 1000000, 64444167):
+        chunks[str(L)] = [list(t[1:]) for t in ref.util.chunkloci(("c", 0, L))]
+    save("leaf_cs", {"cs": out, "mismatch_range": grid, "trim": trims, "chunkloci": chunks})
+
+
+def boundary_case():
+    """Chunk-boundary candidates at tpos == 200000: column seen
+    with full counts in the earlier chunk, with reads that end at the boundary
+    missing in the later one, and som_seen carried across."""
+    ref = H.load_reference()
+    rs = random.Random(11)
+    L = 400002
+    recs = []
+    genome = {}
+
+    def refbase(p):
+        if p not in genome:
+            genome[p] = rs.choice("ACGT")
+        return genome[p]
+
+    def mk(tstart, tend, subs, name, bq=93):
+        seq = []
+        cs = []
+        run = 0
+        for p in range(tstart, tend):
+            rb = refbase(p)
+            if p in subs:
+                if run:
+                    cs.append(":{}".format(run))
+                    run = 0
+                cs.append("*{}{}".format(rb.lower(), subs[p].lower()))
+                seq.append(subs[p])
+            else:
+                run += 1
+                seq.append(rb)
+        if run:
+            cs.append(":{}".format(run))
+        return dict(tstart=tstart, tend=tend, qstart=0, seq="".join(seq), bq=[bq] * len(seq), cs="".join(cs),
+                    qname=name)
+
+    def other(b, k=1):
+        return "ACGT"[("ACGT".index(b) + k) % 4]
+
+    k = 0
+    # site A: rpos 199999 (tpos 200000). 8 reads span it, 4 of them END at 200000
+    # (tend == 200000): they are fetched by chunk 0 but not by chunk 1.
+    pA = 199999
+    for i in range(4):
+        recs.append(mk(199000 + 10 * i, 200000, {pA: other(refbase(pA))} if i == 0 else {}, "a{}".format(k))); k += 1
+    for i in range(4):
+        recs.append(mk(199500 + 10 * i, 200900, {}, "a{}".format(k))); k += 1
+    # site B: tpos 400000, het-like column in chunk 1 (dropped as germline there),
+    # different column in chunk 2 because three ref reads end at 400000.
+    pB = 399999
+    altB = other(refbase(pB), 2)
+    for i in range(3):
+        recs.append(mk(399000 + 7 * i, 400000, {}, "b{}".format(k))); k += 1
+    for i in range(3):
+        recs.append(mk(399100 + 7 * i, 400001, {pB: altB}, "b{}".format(k))); k += 1
+    for i in range(2):
+        recs.append(mk(399200 + 7 * i, 400002, {}, "b{}".format(k))); k += 1
+    # ordinary candidates inside the chunks
+    recs.append(mk(100000, 101500, {100700: other(refbase(100700))}, "c0"))
+    for i in range(5):
+        recs.append(mk(100100 + i, 101400, {}, "c{}".format(i + 1)))
+    recs.sort(key=lambda r: r["tstart"])
+    b = batch_from_records("chr3", L, recs)
+    bam = "/fake/boundary.bam"
+    H.register_bam(bam, {"chr3": b})
+    _, c2c = ref.util.load_loci(None, None, {"chr3": L})
+    chunks = [(s_, e_) for (_, s_, e_) in c2c["chr3"]]
+    ov = dict(min_trim=0.0, min_ref_count=1)
+    out, log = H.run_reference_worker(bam, "chr3", chunks, 100, 5000, 52, **ov)
+    exp = {"chunks": chunks, "qlen_lower_limit": 100, "qlen_upper_limit": 5000, "md_threshold": 52, "overrides": ov,
+           "records": canon_records(out), "log": [int(x) for x in log], "contig": "chr3", "length": L,
+           "reads": recs}
+    print("    boundary", chunks, [r[:6] for r in out], log)
+    save("worker_boundary", exp, batch=b)
+
+
+def thresholds_case():
+    ref = H.load_reference()
+    out = []
+    for seed, L, depth in ((21, 300000, 8.0), (22, 150000, 16.0)):
+        cfg = synth.SynthConfig(seed=seed, contig_len=L, depth=depth, read_len_mean=4000, read_len_sd=900,
+                                read_len_min=1000, read_len_max=9000, name="chr9")
+        s = synth.generate(cfg)
+        bam = "/fake/thr{}.bam".format(seed)
+        H.register_bam(bam, {"chr9": s.batch})
+        ql, qu, md = ref.bamlib.get_thresholds(bam, ["chr9"], {"chr9": L})
+        random.seed(10)
+        starts = random.sample(range(L), 100)
+        out.append({"cfg": cfg.__dict__, "qlen_lower_limit": ql, "qlen_upper_limit": qu, "md_threshold": md,
+                    "first_starts": starts[:5]})
+    save("thresholds", {"cases": out})
+
+
+def header_case():
+    ref = H.load_reference()
+    b = synth.generate(small_cfg(31)).batch
+    bam = "/fake/header.bam"
+    H.register_bam(bam, {"chr7": b, "chr10": b, "chr2": b})
+    hdr = ref.vcflib.get_himut_vcf_header(
+        bam, None, None, None, None, {"chr7": 30000, "chr10": 5, "chr2": 7}, "c.vcf", "p.vcf", 30, 60, 2000, 4100, 0.99,
+        20, 93, 0.01, 0, 20, 52, 3, 1, 3, 1, 1 / (10 ** 6), 1 / (10 ** 3), 1 / (10 ** 4), False, False, False, False,
+        "1.0.4", "out.vcf")
+    hdr_phase = ref.vcflib.get_himut_vcf_header(
+        bam, None, "ph.vcf", "chr7", None, {"chr7": 30000}, "c.vcf", "p.vcf", 30, 60, 2000, 4100, 0.99,
+        20, 93, 0.01, 0, 20, 52, 3, 1, 3, 4, 1 / (10 ** 6), 1 / (10 ** 3), 1 / (10 ** 4), True, False, False, False,
+        "1.0.4", "out.vcf")
+    save("vcf_header", {"header": hdr, "header_phase": hdr_phase})
+
+
+def main():
+    only = set(sys.argv[1:])
+
+    def want(name):
+        return not only or name in only
+
+    if want("leaf_gtlib"):
+        leaf_gtlib()
+    if want("leaf_cs"):
+        leaf_cs()
+    if want("thresholds"):
+        thresholds_case()
+    if want("vcf_header"):
+        header_case()
+    if want("worker_basic"):
+        worker_case("worker_basic", small_cfg(101), md_threshold=52)
+    if want("worker_sets"):
+        worker_case("worker_sets", small_cfg(102, name="chr12", som_rate=2e-4), with_sets=True, md_threshold=52)
+    if want("worker_dense"):
+        # many coincidences: every filter status shows up
+        worker_case("worker_dense",
+                    small_cfg(103, contig_len=6000, read_len_mean=700, read_len_sd=150, read_len_min=300,
+                              read_len_max=1500, depth=40.0, snp_rate=1.5e-2, sub_rate=4e-3, ins_rate=1e-3,
+                              del_rate=1e-3, som_rate=0.0, frac_noisy=0.0, bq93_prob=0.7, frac_softclip=0.3,
+                              softclip_max=40, hetalt_frac=0.15, het_frac=0.55, name="chrD"),
+                    overrides=dict(min_sequence_identity=0.9, max_mismatch_count=3, min_trim=0.0), md_threshold=45,
+                    qlen_limits=(350, 1300))
+    if want("worker_dense_sets"):
+        worker_case("worker_dense_sets",
+                    small_cfg(104, contig_len=6000, read_len_mean=700, read_len_sd=150, read_len_min=300,
+                              read_len_max=1500, depth=35.0, snp_rate=1.5e-2, sub_rate=4e-3, ins_rate=5e-4,
+                              del_rate=5e-4, som_rate=0.0, frac_noisy=0.0, bq93_prob=0.8, hetalt_frac=0.1, het_frac=0.6,
+                              name="chrE"),
+                    overrides=dict(min_sequence_identity=0.9, max_mismatch_count=2, min_alt_count=2, min_ref_count=5),
+                    md_threshold=44,
+                    qlen_limits=(350, 1300), with_sets=True)
+    if want("worker_longcs"):
+        worker_case("worker_longcs", small_cfg(105, contig_len=12000, cs_long=True, name="chrL"), md_threshold=52)
+    if want("worker_phase"):
+        worker_case("worker_phase", small_cfg(106, contig_len=40000, snp_rate=3e-3, som_rate=3e-4, name="chr5"),
+                    phase_block=25, md_threshold=52)
+    if want("worker_phase_dense"):
+        worker_case("worker_phase_dense",
+                    small_cfg(107, contig_len=8000, read_len_mean=900, read_len_sd=150, read_len_min=400,
+                              read_len_max=1600, depth=40.0, snp_rate=1.2e-2, sub_rate=3e-3, ins_rate=8e-4,
+                              del_rate=8e-4, frac_noisy=0.0, name="chrP"),
+                    overrides=dict(min_sequence_identity=0.9, max_mismatch_count=3, min_hap_count=2),
+                    qlen_limits=(400, 1500), phase_block=12, md_threshold=70)
+    if want("worker_flags"):
+        def mutate(b):
+            rs = np.random.RandomState(7)
+            idx = rs.choice(b.n, 24, replace=False)
+            b.flag[idx[:8]] |= 0x100      # secondary: skipped (bamlib.py:17)
+            b.flag[idx[8:16]] |= 0x800    # supplementary: kept
+            for k in range(16, 24, 2):    # shared query names (supplementary pairs)
+                i, j = sorted((int(idx[k]), int(idx[k + 1])))
+                b.qid[j] = b.qid[i]
+        worker_case("worker_flags", small_cfg(108, contig_len=20000, name="chrF", som_rate=2e-4), md_threshold=52,
+                    mutate=mutate)
+    if want("worker_pon_params"):
+        # the thresholds --create_panel_of_normals switches to (util.py:44-63)
+        worker_case("worker_pon_params", small_cfg(109, contig_len=20000, name="chrN", som_rate=2e-4), md_threshold=52,
+                    overrides=dict(min_bq=20, min_gq=10, min_qv=20, min_trim=0, min_mapq=30, min_hap_count=0,
+                                   min_sequence_identity=0.8), create_pon=True)
+    if want("worker_boundary"):
+        boundary_case()
+
+
+if __name__ == "__main__":
+    main()

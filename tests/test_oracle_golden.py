@@ -1,0 +1,56 @@
+"""The CPU oracle (oracle/himut_oracle.c) against golden vectors captured from
+the reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import util
+from himut_amd.readbatch import batch_from_records
+
+
+@pytest.mark.parametrize("case", util.WORKER_CASES + util.PHASE_CASES)
+def test_worker_matches_reference(case):
+    batch, exp = util.load_case(case)
+    p = util.params_of(exp)
+    pon = O.site_keys([tuple(t) for t in exp["pon_set"]]) if "pon_set" in exp else None
+    com = O.site_keys([tuple(t) for t in exp["common_set"]]) if "common_set" in exp else None
+    recs, log = O.call(batch, util.chunks_of(exp), p, p["germline_snv_prior"], pon, com, util.phase_of(exp))
+    assert log == exp["log"]
+    got = O.records_to_tuples(exp["contig"], recs)
+    want = util.expected_tuples(exp)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w
+
+
+def test_germ_gt_vectors():
+    exp = util.load_json("leaf_gtlib")
+    idx = O.BASE2IDX
+    for v in exp["vectors"]:
+        gt, gq, state, pls = O.germ_gt(v["ref"], [idx[a] for a in v["alleles"]], v["bqs"])
+        assert pls == v["pls"]
+        assert (gt, gq, state) == (v["gt"], v["gq"], v["state"])
+        # the reference hands get_germ_gq the two-letter genotype, so it equals gq
+        assert v["germ_gq"] == v["gq"]
+
+
+def test_lut_tables():
+    exp = util.load_json("leaf_gtlib")["tables"]
+    hom, het, err, logp = O.build_lut(1 / (10 ** 3))
+    assert list(hom[1:94]) == exp["hom"]
+    assert list(het[1:94]) == exp["het"]
+    assert list(err[1:94]) == exp["err"]
+    assert [logp[0], logp[1], logp[2], logp[3]] == [exp["prior"][k] for k in ("homref", "het", "hetalt", "homalt")]
+
+
+def test_cs_tuples():
+    exp = util.load_json("leaf_cs")
+    for c in exp["cs"]:
+        tend = c["tstart"] + sum(t[3] for t in c["tuples"])
+        b = batch_from_records("c", 10 ** 6, [dict(tstart=c["tstart"], tend=tend, qstart=c["qstart"], seq=c["seq"],
+                                                   bq=c["bq"], cs=c["cs"])])
+        ops = O.cs_ops(b, 0)
+        assert [(o[0], o[1], o[2]) for o in ops] == [(t[0], t[3], t[4]) for t in c["tuples"]]
+        for o, t in zip(ops, c["tuples"]):
+            if t[0] == 2:
+                assert (o[3], o[4]) == (t[1], t[2])
