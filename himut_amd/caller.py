@@ -1,0 +1,158 @@
+"""Host mirror of the reference's per-chromosome worker and its driver
+(reference: src/himut/caller.py).
+
+``get_somatic_substitutions`` keeps the reference's 30-argument signature
+(caller.py:208-241) so it can stand in for the starmap target; the body hands
+the contig to the HIP library through the C ABI (include/himut_hip.h) and turns
+the integer records back into the reference's 12-tuples with the reference's
+own divisions (bamlib.py:181-219, caller.py:174-192).  There is no CPU
+implementation of the scan in this package: without the HIP library the call
+raises.
+"""
+import numpy as np
+
+from . import _ffi, gtlib
+from .util import BASE2IDX
+
+STATUS_NAMES = _ffi.STATUS_NAMES
+
+
+def site_keys(sites):
+    """Sorted uint64 keys (pos1 << 4 | ref << 2 | alt) of a set of
+    (pos, ref, alt); entries outside ATGC can never equal a candidate."""
+    ks = {(int(p) << 4) | (BASE2IDX[r] << 2) | BASE2IDX[a] for (p, r, a) in sites if r in BASE2IDX and a in BASE2IDX}
+    return np.array(sorted(ks), dtype=np.uint64)
+
+
+def pack_phase_sets(chunks, ps2hbit, ps2hpos, ps2hetsnp):
+    """Flat per-chunk hetSNP arrays.  The reference keys the phase set of a
+    chunk by str(chunk_start) (caller.py:292-295); a missing key gives empty
+    lists (they are defaultdicts, vcflib.py:627-629)."""
+    off = [0]
+    hpos, href, halt, hbit = [], [], [], []
+    for (s, _e) in chunks:
+        key = str(s)
+        hp = ps2hpos.get(key, [])
+        hs = ps2hetsnp.get(key, [])
+        hb = ps2hbit.get(key, [])
+        for p, (_, r, a), b in zip(hp, hs, hb):
+            hpos.append(int(p))
+            href.append(ord(r) if len(r) == 1 else 0)
+            halt.append(ord(a) if len(a) == 1 else 0)
+            hbit.append(ord(b))
+        off.append(len(hpos))
+    return (np.array(off, np.int64), np.array(hpos, np.int32), np.array(href, np.uint8), np.array(halt, np.uint8),
+            np.array(hbit, np.uint8))
+
+
+def records_to_tuples(chrom, recs):
+    """Integer device records -> the tuples of caller.py:351-620."""
+    out = []
+    for r in recs:
+        c = [int(x) for x in r["counts"]]
+        s = [int(x) for x in r["bqsum"]]
+        read_depth = float(c[0] + c[1] + c[2] + c[3] + c[5])          # bamlib.py:213-219 (np.float64 there)
+        ref = chr(r["ref"])
+        alt = chr(r["alt"])
+        status = STATUS_NAMES[int(r["status"])]
+        ref_count = float(c[BASE2IDX[ref]])
+        if status == "HetAltSite":                                    # caller.py:368-391, 174-192
+            a1, a2 = chr(r["gt0"]), chr(r["gt1"])
+            pidx, qidx = BASE2IDX[a1], BASE2IDX[a2]
+            p_count, q_count = float(c[pidx]), float(c[qidx])
+            pbq = s[pidx] / float(p_count)
+            qbq = s[qidx] / float(q_count)
+            alt_bq = "{:0.1f},{:0.1f}".format(pbq, qbq)
+            alt_count = "{:0.0f},{:0.0f}".format(p_count, q_count)
+            alt_vaf = "{:.2f},{:.2f}".format(p_count / float(read_depth), q_count / float(read_depth))
+            alt = "{},{}".format(a1, a2)
+        else:                                                         # bamlib.py:197-210
+            alt_count = float(c[BASE2IDX[alt]])
+            alt_vaf = alt_count / float(read_depth)
+            alt_bq = s[BASE2IDX[alt]] / float(alt_count) if alt_count != 0 else 0.0
+        ps = str(int(r["phase_set"])) if int(r["phase_set"]) >= 0 else "."
+        out.append((chrom, int(r["tpos"]), ref, alt, status, int(r["gq"]), alt_bq, read_depth, ref_count, alt_count,
+                    alt_vaf, ps))
+    return out
+
+
+class Worker:
+    """A GPU-bound worker: one context, reusable across contigs."""
+
+    def __init__(self, device=0):
+        self.ctx = _ffi.Context(device)
+        self._lut_prior = None
+
+    def close(self):
+        self.ctx.close()
+
+    def configure(self, min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq,
+                  min_trim, max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count,
+                  min_hap_count, germline_snv_prior, phase):
+        self.ctx.set_params(min_qv=int(min_qv), min_mapq=int(min_mapq), qlen_lower_limit=int(qlen_lower_limit),
+                            qlen_upper_limit=int(qlen_upper_limit), min_gq=int(min_gq), min_bq=int(min_bq),
+                            max_mismatch_count=int(max_mismatch_count),
+                            mismatch_window_size=int(mismatch_window_size), md_threshold=int(md_threshold),
+                            min_ref_count=int(min_ref_count), min_alt_count=int(min_alt_count),
+                            min_hap_count=int(min_hap_count), phase=1 if phase else 0,
+                            min_sequence_identity=float(min_sequence_identity), min_trim=float(min_trim))
+        if self._lut_prior != germline_snv_prior:
+            self.ctx.set_gt_lut(*gtlib.build_tables(germline_snv_prior))
+            self._lut_prior = germline_snv_prior
+
+    def call_contig(self, batch, chunks, pon_keys=None, common_keys=None, phase_sets=None):
+        """Runs the scan on one contig; returns (records array, 15 counters)."""
+        ctx = self.ctx
+        ctx.set_chunks(chunks)
+        ctx.set_site_set(0, pon_keys if pon_keys is not None else np.zeros(0, np.uint64))
+        ctx.set_site_set(1, common_keys if common_keys is not None else np.zeros(0, np.uint64))
+        if phase_sets is not None:
+            ctx.set_phase(*pack_phase_sets(chunks, *phase_sets))
+        ctx.push_reads(batch)
+        ctx.run()
+        return ctx.records(), ctx.log()
+
+
+_default_worker = {}
+
+
+def _worker_for(device):
+    w = _default_worker.get(device)
+    if w is None:
+        w = Worker(device)
+        _default_worker[device] = w
+    return w
+
+
+def get_somatic_substitutions(
+    chrom, bam_file, common_snps, panel_of_normals, chunkloci_lst, phase_set2hbit_lst, phase_set2hpos_lst,
+    phase_set2hetsnp_lst, min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq,
+    min_trim, max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
+    somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample, create_panel_of_normals,
+    chrom2tsbs_lst, chrom2tsbs_log, device=0, read_batch=None,
+):
+    """Drop-in for himut.caller.get_somatic_substitutions (caller.py:208).
+
+    ``bam_file`` is read with the package's own BAM reader unless a prebuilt
+    ``read_batch`` is given.  ``somatic_snv_prior`` and ``germline_indel_prior``
+    are accepted and unused, as in the reference.  Assigns
+    chrom2tsbs_lst[chrom] / chrom2tsbs_log[chrom] exactly like caller.py:622-641."""
+    from . import vcflib
+    pon_keys = com_keys = None
+    human = not non_human_sample and not create_panel_of_normals
+    if common_snps is not None and human and common_snps.endswith(".vcf"):          # caller.py:248-254
+        com_keys = site_keys(vcflib.load_common_snp(chrom, common_snps))
+    if panel_of_normals is not None and human and panel_of_normals.endswith(".vcf"):  # caller.py:256-262
+        pon_keys = site_keys(vcflib.load_pon(chrom, panel_of_normals))
+    if read_batch is None:
+        from . import bamio
+        read_batch = bamio.read_contig(bam_file, chrom)
+    w = _worker_for(device)
+    w.configure(min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
+                max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
+                germline_snv_prior, phase)
+    chunks = [(int(s), int(e)) for (_c, s, e) in chunkloci_lst]
+    phase_sets = (phase_set2hbit_lst, phase_set2hpos_lst, phase_set2hetsnp_lst) if phase else None
+    recs, log = w.call_contig(read_batch, chunks, pon_keys, com_keys, phase_sets)
+    chrom2tsbs_lst[chrom] = records_to_tuples(chrom, recs)
+    chrom2tsbs_log[chrom] = log

@@ -1,0 +1,644 @@
+// libhimut_hip.so -- host side of the C ABI declared in include/himut_hip.h.
+// Owns the device buffers of one context, builds the small chunk / window tables,
+// launches the kernels of himut_kernels.h on the context's stream and reads the
+// result back.  No torch types, no C++ exceptions across the boundary.
+#include <hip/hip_runtime.h>
+
+#include <string.h>  // rocprim's texture iterator needs the host memset declared first
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "himut_hip.h"
+#include "himut_kernels.h"
+
+using namespace himut;
+
+namespace {
+
+struct HipFail {
+    hipError_t e;
+    const char* what;
+    int line;
+};
+
+#define HCHECK(expr)                                   \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) throw HipFail{_e, #expr, __LINE__}; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void reserve(size_t bytes) {
+        if (bytes <= cap && p) return;
+        if (p) { HCHECK(hipFree(p)); p = nullptr; cap = 0; }
+        size_t want = std::max<size_t>(bytes, 256);
+        HCHECK(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+template <class T>
+void upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
+    b.reserve(std::max<size_t>(n, 1) * sizeof(T) + 64);
+    if (n) HCHECK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+}
+
+template <class T>
+void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) { upload(b, v.data(), v.size(), st); }
+
+enum { EV_START = 0, EV_BQSUM, EV_PARSE, EV_HAP, EV_EMIT, EV_SWEEP, EV_FINAL, EV_COUNT };
+
+}  // namespace
+
+struct himut_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    std::string err;
+
+    Params params{};
+    bool have_params = false, have_lut = false, have_reads = false;
+
+    // inputs
+    DevBuf d_lut;
+    std::vector<int32_t> cstart, cend;
+    DevBuf d_cstart, d_cend, d_maskoff, d_tileoff, d_sstart, d_sidx, d_spmax, d_rlo, d_rhi, d_pairoff;
+    std::vector<int64_t> maskoff, tileoff;
+    DevBuf d_pon, d_com;
+    int64_t npon = 0, ncom = 0;
+    bool have_phase = false;
+    std::vector<int64_t> h_phoff;
+    DevBuf d_phoff, d_hpos, d_href, d_halt, d_hbit, d_hap;
+
+    // reads
+    int64_t n = 0, cs_bytes = 0, seq_bytes = 0, bq_bytes = 0, read_bases = 0;
+    std::vector<int32_t> h_tstart, h_tend, h_prefmax;
+    bool unique_qnames = true;
+    DevBuf d_tstart, d_tend, d_qstart, d_qlen, d_mapq, d_flag, d_qid, d_qoff, d_csoff, d_seq, d_bq, d_cs, d_prefmax;
+    // derived
+    DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_rflag, d_ccs;
+    // run state
+    DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
+    DevBuf d_dense_counts, d_dense_bqsum;
+    std::vector<himut_record> h_recs;
+    bool h_recs_valid = false;
+    int64_t n_out = 0;
+    int64_t log[15] = {};
+    himut_run_stats stats{};
+};
+
+namespace {
+
+// scalars block in device memory
+struct Scalars {
+    unsigned long long ncand;
+    unsigned long long nrec;
+    unsigned long long row_bases;
+    unsigned long long nccs;
+    unsigned long long log[16];
+    int err;
+    int pad;
+};
+
+const char* err_text(int code) {
+    switch (code) {
+        case HIMUT_ERR_CS: return "cs tag cannot be tokenised, has consecutive insertions, or disagrees with SEQ/CIGAR";
+        case HIMUT_ERR_BASE: return "KeyError: base outside ATGC (util.py:17)";
+        case HIMUT_ERR_BQ0: return "ValueError: math domain error (BQ 0 in a candidate column, gtlib.py:64)";
+        case HIMUT_ERR_COVER: return "KeyError: hetSNP position missing from tpos2qbase (haplib.py:51)";
+        case HIMUT_ERR_BQ_RANGE: return "base quality out of range";
+    }
+    return "device error";
+}
+
+int fail(himut_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+template <class F>
+int guarded(himut_ctx* c, F f) {
+    try {
+        return f();
+    } catch (const HipFail& h) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s (himut_hip.hip:%d)", (int)h.e, hipGetErrorString(h.e), h.what, h.line);
+        return fail(c, HIMUT_ERR_HIP, buf);
+    } catch (const std::bad_alloc&) {
+        return fail(c, HIMUT_ERR_NOMEM, "host allocation failed");
+    } catch (...) {
+        return fail(c, HIMUT_ERR_ARG, "unexpected C++ exception");
+    }
+}
+
+Reads make_reads(himut_ctx* c) {
+    Reads R;
+    R.n = c->n;
+    R.tstart = c->d_tstart.as<int32_t>(); R.tend = c->d_tend.as<int32_t>(); R.qstart = c->d_qstart.as<int32_t>();
+    R.qlen = c->d_qlen.as<int32_t>(); R.mapq = c->d_mapq.as<uint8_t>(); R.flag = c->d_flag.as<uint16_t>();
+    R.qid = c->d_qid.as<int32_t>(); R.qoff = c->d_qoff.as<int64_t>(); R.cs_off = c->d_csoff.as<int64_t>();
+    R.seq = c->d_seq.as<uint8_t>(); R.bq = c->d_bq.as<uint8_t>(); R.cs = c->d_cs.as<uint8_t>();
+    R.prefmax_tend = c->d_prefmax.as<int32_t>();
+    return R;
+}
+
+Derived make_derived(himut_ctx* c) {
+    Derived D;
+    D.bqsum = c->d_bqsum.as<uint32_t>(); D.nseg = c->d_nseg.as<int32_t>(); D.nmis = c->d_nmis.as<int32_t>();
+    D.segs = c->d_segs.as<Seg>(); D.mis = c->d_mis.as<int32_t>(); D.rflag = c->d_rflag.as<uint8_t>();
+    return D;
+}
+
+// Uploads the chunk tables for the given chunk list and the current reads.
+struct ChunkTables {
+    int64_t n = 0, positions = 0, n_tiles = 0, npairs = 0;
+};
+
+ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const std::vector<int32_t>& ce) {
+    ChunkTables T;
+    const int64_t n = (int64_t)cs.size();
+    T.n = n;
+    c->maskoff.assign(n + 1, 0);
+    c->tileoff.assign(n + 1, 0);
+    for (int64_t k = 0; k < n; k++) {
+        int64_t span = (int64_t)ce[k] - cs[k] + 1;
+        c->maskoff[k + 1] = c->maskoff[k] + span;
+        c->tileoff[k + 1] = c->tileoff[k] + (span + TP - 1) / TP;
+    }
+    T.positions = c->maskoff[n];
+    T.n_tiles = c->tileoff[n];
+    std::vector<int32_t> order(n), sstart(n), sidx(n), spmax(n);
+    for (int64_t k = 0; k < n; k++) order[k] = (int32_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cs[a] < cs[b]; });
+    int32_t run = INT32_MIN;
+    for (int64_t k = 0; k < n; k++) {
+        sstart[k] = cs[order[k]];
+        sidx[k] = order[k];
+        run = std::max(run, ce[order[k]]);
+        spmax[k] = run;
+    }
+    // read windows per chunk: [first read whose running max tend > start, first read with tstart >= end)
+    std::vector<int64_t> rlo(n), rhi(n), pairoff(n + 1, 0);
+    for (int64_t k = 0; k < n; k++) {
+        rlo[k] = std::upper_bound(c->h_prefmax.begin(), c->h_prefmax.end(), cs[k]) - c->h_prefmax.begin();
+        rhi[k] = std::lower_bound(c->h_tstart.begin(), c->h_tstart.end(), ce[k]) - c->h_tstart.begin();
+        if (rhi[k] < rlo[k]) rhi[k] = rlo[k];
+        pairoff[k + 1] = pairoff[k] + (rhi[k] - rlo[k]);
+    }
+    T.npairs = pairoff[n];
+    hipStream_t st = c->stream;
+    upload(c->d_cstart, cs, st); upload(c->d_cend, ce, st);
+    upload(c->d_maskoff, c->maskoff, st); upload(c->d_tileoff, c->tileoff, st);
+    upload(c->d_sstart, sstart, st); upload(c->d_sidx, sidx, st); upload(c->d_spmax, spmax, st);
+    upload(c->d_rlo, rlo, st); upload(c->d_rhi, rhi, st); upload(c->d_pairoff, pairoff, st);
+    HCHECK(hipStreamSynchronize(st));  // the host vectors above go out of scope
+    return T;
+}
+
+Chunks make_chunks(himut_ctx* c, int64_t n) {
+    Chunks C;
+    C.n = n;
+    C.start = c->d_cstart.as<int32_t>(); C.end = c->d_cend.as<int32_t>();
+    C.maskoff = c->d_maskoff.as<int64_t>(); C.tileoff = c->d_tileoff.as<int64_t>();
+    C.s_start = c->d_sstart.as<int32_t>(); C.s_idx = c->d_sidx.as<int32_t>(); C.s_pmaxend = c->d_spmax.as<int32_t>();
+    C.rlo = c->d_rlo.as<int64_t>(); C.rhi = c->d_rhi.as<int64_t>(); C.pairoff = c->d_pairoff.as<int64_t>();
+    return C;
+}
+
+Phase make_phase(himut_ctx* c) {
+    Phase H;
+    H.off = c->d_phoff.as<int64_t>(); H.hpos = c->d_hpos.as<int32_t>(); H.href = c->d_href.as<uint8_t>();
+    H.halt = c->d_halt.as<uint8_t>(); H.hbit = c->d_hbit.as<uint8_t>(); H.hap = c->d_hap.as<uint8_t>();
+    return H;
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
+
+int check_device_err(himut_ctx* c, int bits) {
+    if (!bits) return HIMUT_OK;
+    for (int code = 1; code < 31; code++)
+        if (bits & (1 << code)) return fail(c, code, err_text(code));
+    return fail(c, HIMUT_ERR_ARG, "device error");
+}
+
+void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_bqsum, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D);
+    HCHECK(hipEventRecord(c->ev[EV_BQSUM], st));
+    hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, c->params, &sc->err);
+    HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+}
+
+void alloc_derived(himut_ctx* c) {
+    const int64_t n = c->n;
+    const int64_t segcap = (c->cs_bytes >> 1) + n + 2;
+    c->d_bqsum.reserve((size_t)n * 4 + 64);
+    c->d_nseg.reserve((size_t)n * 4 + 64);
+    c->d_nmis.reserve((size_t)n * 4 + 64);
+    c->d_segs.reserve((size_t)segcap * sizeof(Seg));
+    c->d_mis.reserve((size_t)segcap * 4);
+    c->d_rflag.reserve((size_t)n + 64);
+    c->d_ccs.reserve((size_t)n + 64);
+    c->d_scalars.reserve(sizeof(Scalars));
+}
+
+int do_run(himut_ctx* c) {
+    if (!c->have_params) return fail(c, HIMUT_ERR_ARG, "himut_set_params has not been called");
+    if (!c->have_lut) return fail(c, HIMUT_ERR_ARG, "himut_set_gt_lut has not been called");
+    if (!c->have_reads) return fail(c, HIMUT_ERR_ARG, "himut_push_reads has not been called");
+    const bool phase = c->params.p.phase != 0;
+    if (phase && !c->have_phase) return fail(c, HIMUT_ERR_ARG, "phase requested but himut_set_phase has not been called");
+    if (phase && (int64_t)c->h_phoff.size() != (int64_t)c->cstart.size() + 1)
+        return fail(c, HIMUT_ERR_ARG, "himut_set_phase chunk count differs from himut_set_chunks");
+    if (phase && !c->unique_qnames)
+        return fail(c, HIMUT_ERR_ARG, "phase mode needs unique query names (filter the BAM with -F 0x900 as the reference's README asks)");
+    for (size_t k = 0; k < c->cstart.size(); k++)
+        if (c->cstart[k] > c->cend[k]) return fail(c, HIMUT_ERR_CHUNK, "ValueError: invalid coordinates: chunk start > end");
+    HCHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->h_recs_valid = false;
+    c->n_out = 0;
+    memset(c->log, 0, sizeof(c->log));
+    memset(&c->stats, 0, sizeof(c->stats));
+    c->params.unique_qnames = c->unique_qnames ? 1 : 0;
+
+    ChunkTables T = upload_chunks(c, c->cstart, c->cend);
+    alloc_derived(c);
+    const size_t mask_bytes = ((size_t)T.positions * 2 + 7) & ~(size_t)3;
+    c->d_mask.reserve(mask_bytes + 64);
+    if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
+
+    Reads R = make_reads(c);
+    Derived D = make_derived(c);
+    Chunks C = make_chunks(c, T.n);
+    Phase H = make_phase(c);
+    Scalars* sc = c->d_scalars.as<Scalars>();
+
+    HCHECK(hipEventRecord(c->ev[EV_START], st));
+    HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+    HCHECK(hipMemsetAsync(c->d_mask.p, 0, mask_bytes, st));
+    HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
+    if (c->n > 0) run_parse_stage(c, R, D, sc);
+    else { HCHECK(hipEventRecord(c->ev[EV_BQSUM], st)); HCHECK(hipEventRecord(c->ev[EV_PARSE], st)); }
+    if (phase && T.npairs > 0)
+        hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
+    HCHECK(hipEventRecord(c->ev[EV_HAP], st));
+    if (c->n > 0 && T.n > 0)
+        hipLaunchKernelGGL(k_emit_candidates, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, C, H, c->params,
+                           c->d_mask.as<uint16_t>(), c->d_ccs.as<uint8_t>(), &sc->ncand, &sc->err);
+    HCHECK(hipEventRecord(c->ev[EV_EMIT], st));
+
+    // exact number of candidate evaluations -> record capacity
+    Scalars hs;
+    HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+    HCHECK(hipStreamSynchronize(st));
+    if (hs.err) return check_device_err(c, hs.err);
+    const int64_t ncand = (int64_t)hs.ncand;
+    c->d_recs.reserve((size_t)(ncand + 1) * sizeof(himut_record));
+    c->d_recs_out.reserve((size_t)(ncand + 1) * sizeof(himut_record));
+
+    SweepArgs A;
+    A.R = R; A.D = D; A.C = C; A.H = H; A.P = c->params;
+    A.S.pon = c->d_pon.as<uint64_t>(); A.S.npon = c->npon; A.S.com = c->d_com.as<uint64_t>(); A.S.ncom = c->ncom;
+    A.lut = c->d_lut.as<GtLut>();
+    A.mask = c->d_mask.as<uint16_t>();
+    A.recs = c->d_recs.as<himut_record>();
+    A.nrec = &sc->nrec;
+    A.cap = ncand;
+    A.n_tiles = T.n_tiles;
+    A.dense_counts = nullptr; A.dense_bqsum = nullptr;
+    A.row_bases = &sc->row_bases;
+    A.err = &sc->err;
+    if (T.n_tiles > 0 && c->n > 0)
+        hipLaunchKernelGGL(k_pileup_sweep<false>, dim3((unsigned)T.n_tiles), dim3(TP), 0, st, A);
+    HCHECK(hipEventRecord(c->ev[EV_SWEEP], st));
+
+    // ---- finalisation: order, cross-chunk som_seen, counters, compaction
+    int64_t nrec = ncand;  // every set mask bit yields exactly one evaluation
+    if (nrec > 0) {
+        c->d_keys.reserve((size_t)nrec * 8); c->d_keys2.reserve((size_t)nrec * 8);
+        c->d_vals.reserve((size_t)nrec * 4); c->d_vals2.reserve((size_t)nrec * 4);
+        c->d_emit.reserve((size_t)nrec * 4); c->d_pos.reserve((size_t)nrec * 4);
+        const unsigned nb = blocks_for(nrec, 256);
+        hipLaunchKernelGGL(k_record_keys, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), nrec,
+                           c->d_keys.as<uint64_t>(), c->d_vals.as<uint32_t>());
+        size_t tmp_bytes = 0;
+        HCHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
+                                         c->d_vals.as<uint32_t>(), c->d_vals2.as<uint32_t>(), (size_t)nrec, 0, 60, st));
+        size_t tmp2 = 0;
+        HCHECK(rocprim::exclusive_scan(nullptr, tmp2, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u, (size_t)nrec,
+                                       rocprim::plus<uint32_t>(), st));
+        c->d_tmp.reserve(std::max(tmp_bytes, tmp2) + 256);
+        HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, tmp_bytes, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
+                                         c->d_vals.as<uint32_t>(), c->d_vals2.as<uint32_t>(), (size_t)nrec, 0, 60, st));
+        hipLaunchKernelGGL(k_resolve_seen, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
+                           c->d_keys2.as<uint64_t>(), c->d_vals2.as<uint32_t>(), nrec);
+        hipLaunchKernelGGL(k_finalize_flags, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
+                           c->d_keys2.as<uint64_t>(), c->d_vals2.as<uint32_t>(), nrec, c->d_emit.as<uint32_t>(), sc->log);
+        HCHECK(rocprim::exclusive_scan(c->d_tmp.p, tmp2, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
+                                       (size_t)nrec, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), c->d_vals2.as<uint32_t>(),
+                           c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), nrec, c->d_recs_out.as<himut_record>());
+    }
+    if (c->n > 0)
+        hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
+    HCHECK(hipEventRecord(c->ev[EV_FINAL], st));
+
+    uint32_t last_emit = 0, last_pos = 0;
+    HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+    if (nrec > 0) {
+        HCHECK(hipMemcpyAsync(&last_emit, c->d_emit.as<uint32_t>() + (nrec - 1), 4, hipMemcpyDeviceToHost, st));
+        HCHECK(hipMemcpyAsync(&last_pos, c->d_pos.as<uint32_t>() + (nrec - 1), 4, hipMemcpyDeviceToHost, st));
+    }
+    HCHECK(hipStreamSynchronize(st));
+    if (hs.err) return check_device_err(c, hs.err);
+    if ((int64_t)hs.nrec != ncand) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "internal: %lld candidates marked but %lld evaluated", (long long)ncand, (long long)hs.nrec);
+        return fail(c, HIMUT_ERR_ARG, buf);
+    }
+    c->n_out = nrec > 0 ? (int64_t)last_pos + last_emit : 0;
+    for (int k = 0; k < 15; k++) c->log[k] = (int64_t)hs.log[k];
+    c->log[0] = (int64_t)hs.nccs;
+
+    auto ms = [&](int a, int b) { float f = 0; (void)hipEventElapsedTime(&f, c->ev[a], c->ev[b]); return (double)f; };
+    himut_run_stats& S = c->stats;
+    S.ms_total = ms(EV_START, EV_FINAL);
+    S.ms_bqsum = ms(EV_START, EV_BQSUM);
+    S.ms_parse = ms(EV_BQSUM, EV_PARSE);
+    S.ms_hap = ms(EV_PARSE, EV_HAP);
+    S.ms_emit = ms(EV_HAP, EV_EMIT);
+    S.ms_sweep = ms(EV_EMIT, EV_SWEEP);
+    S.ms_finalize = ms(EV_SWEEP, EV_FINAL);
+    S.n_reads = c->n;
+    S.read_bases = c->read_bases;
+    S.positions = T.positions;
+    S.n_tiles = T.n_tiles;
+    S.n_candidates = ncand;
+    S.n_records = c->n_out;
+    S.sweep_row_bases = (int64_t)hs.row_bases;
+    return HIMUT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int himut_abi_version(void) { return HIMUT_ABI_VERSION; }
+
+int himut_create(int device, himut_ctx** out) {
+    if (!out) return HIMUT_ERR_ARG;
+    *out = nullptr;
+    himut_ctx* c = new (std::nothrow) himut_ctx();
+    if (!c) return HIMUT_ERR_NOMEM;
+    c->device = device;
+    int rc = guarded(c, [&]() -> int {
+        int ndev = 0;
+        HCHECK(hipGetDeviceCount(&ndev));
+        if (device < 0 || device >= ndev) return fail(c, HIMUT_ERR_ARG, "no such HIP device");
+        HCHECK(hipSetDevice(device));
+        HCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (auto& e : c->ev) HCHECK(hipEventCreate(&e));
+        return HIMUT_OK;
+    });
+    if (rc) {
+        static thread_local std::string last;
+        last = c->err;
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return HIMUT_OK;
+}
+
+void himut_destroy(himut_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* himut_last_error(const himut_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int himut_set_params(himut_ctx* c, const himut_params* p) {
+    if (!c || !p) return HIMUT_ERR_ARG;
+    c->params.p = *p;
+    c->have_params = true;
+    return HIMUT_OK;
+}
+
+int himut_set_gt_lut(himut_ctx* c, const double* hom, const double* het, const double* err_, int n_bq, const double prior[4]) {
+    if (!c || !hom || !het || !err_ || !prior || n_bq < 1 || n_bq > 256) return fail(c, HIMUT_ERR_ARG, "bad LUT arguments");
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        GtLut L;
+        for (int k = 0; k < 256; k++) {
+            const int s = k < n_bq ? k : n_bq - 1;
+            L.t[0][k] = hom[s]; L.t[1][k] = het[s]; L.t[2][k] = err_[s];
+        }
+        for (int k = 0; k < 4; k++) L.prior[k] = prior[k];
+        c->d_lut.reserve(sizeof(GtLut));
+        HCHECK(hipMemcpyAsync(c->d_lut.p, &L, sizeof(GtLut), hipMemcpyHostToDevice, c->stream));
+        HCHECK(hipStreamSynchronize(c->stream));
+        c->have_lut = true;
+        return HIMUT_OK;
+    });
+}
+
+int himut_set_chunks(himut_ctx* c, const int32_t* start, const int32_t* end, int64_t n) {
+    if (!c || n < 0 || (n > 0 && (!start || !end))) return fail(c, HIMUT_ERR_ARG, "bad chunk arguments");
+    if (n >= (1 << 24)) return fail(c, HIMUT_ERR_ARG, "too many chunks");
+    c->cstart.assign(start, start + n);
+    c->cend.assign(end, end + n);
+    return HIMUT_OK;
+}
+
+int himut_set_site_set(himut_ctx* c, int which, const uint64_t* keys, int64_t n) {
+    if (!c || (which != 0 && which != 1) || n < 0 || (n > 0 && !keys)) return fail(c, HIMUT_ERR_ARG, "bad site-set arguments");
+    for (int64_t k = 1; k < n; k++)
+        if (keys[k - 1] > keys[k]) return fail(c, HIMUT_ERR_ARG, "site-set keys must be sorted ascending");
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        DevBuf& b = which == 0 ? c->d_pon : c->d_com;
+        upload(b, keys, (size_t)n, c->stream);
+        HCHECK(hipStreamSynchronize(c->stream));
+        (which == 0 ? c->npon : c->ncom) = n;
+        return HIMUT_OK;
+    });
+}
+
+int himut_set_phase(himut_ctx* c, const int64_t* off, const int32_t* hpos, const uint8_t* href, const uint8_t* halt,
+                    const uint8_t* hbit, int64_t n_chunks) {
+    if (!c || !off || n_chunks < 0) return fail(c, HIMUT_ERR_ARG, "bad phase arguments");
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        const int64_t m = off[n_chunks];
+        c->h_phoff.assign(off, off + n_chunks + 1);
+        upload(c->d_phoff, off, (size_t)n_chunks + 1, c->stream);
+        upload(c->d_hpos, hpos, (size_t)m, c->stream);
+        upload(c->d_href, href, (size_t)m, c->stream);
+        upload(c->d_halt, halt, (size_t)m, c->stream);
+        upload(c->d_hbit, hbit, (size_t)m, c->stream);
+        HCHECK(hipStreamSynchronize(c->stream));
+        c->have_phase = true;
+        return HIMUT_OK;
+    });
+}
+
+int himut_push_reads(himut_ctx* c, const himut_read_batch* b) {
+    if (!c || !b || b->n_reads < 0) return fail(c, HIMUT_ERR_ARG, "bad read batch");
+    const int64_t n = b->n_reads;
+    if (n > 0 && (!b->tstart || !b->tend || !b->qstart || !b->qlen || !b->mapq || !b->flag || !b->qid || !b->qoff ||
+                  !b->cs_off || !b->seq || !b->bq || !b->cs))
+        return fail(c, HIMUT_ERR_ARG, "read batch has null arrays");
+    // host-side shape checks: everything the kernels index with must be in range
+    int64_t bases = 0;
+    bool unique = true;
+    for (int64_t i = 0; i < n; i++) {
+        if (i > 0 && b->tstart[i] < b->tstart[i - 1]) return fail(c, HIMUT_ERR_ARG, "reads are not coordinate sorted");
+        if (b->qoff[i] < 0 || (b->qoff[i] & 31) || b->qlen[i] < 0 || b->qoff[i] + (((int64_t)b->qlen[i] + 31) & ~(int64_t)31) > b->bq_bytes ||
+            (b->qoff[i] + (((int64_t)b->qlen[i] + 31) & ~(int64_t)31)) / 2 > b->seq_bytes)
+            return fail(c, HIMUT_ERR_ARG, "read offsets exceed the sequence / quality buffers");
+        if (b->cs_off[i] < 0 || b->cs_off[i + 1] < b->cs_off[i] || b->cs_off[i + 1] > b->cs_bytes)
+            return fail(c, HIMUT_ERR_ARG, "cs offsets exceed the cs buffer");
+        if (b->tend[i] < b->tstart[i] || b->qstart[i] < 0 || b->qstart[i] > b->qlen[i])
+            return fail(c, HIMUT_ERR_ARG, "read coordinates are inconsistent");
+        if (b->qid[i] < 0 || b->qid[i] >= n) return fail(c, HIMUT_ERR_ARG, "qid out of range");
+        if (b->qid[i] != i) unique = false;
+        bases += b->qlen[i];
+    }
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        c->n = n; c->cs_bytes = b->cs_bytes; c->seq_bytes = b->seq_bytes; c->bq_bytes = b->bq_bytes; c->read_bases = bases;
+        c->unique_qnames = unique;
+        c->h_tstart.assign(b->tstart, b->tstart + n);
+        c->h_tend.assign(b->tend, b->tend + n);
+        c->h_prefmax.resize((size_t)n);
+        int32_t run = INT32_MIN;
+        for (int64_t i = 0; i < n; i++) { run = std::max(run, b->tend[i]); c->h_prefmax[(size_t)i] = run; }
+        upload(c->d_tstart, b->tstart, (size_t)n, st); upload(c->d_tend, b->tend, (size_t)n, st);
+        upload(c->d_qstart, b->qstart, (size_t)n, st); upload(c->d_qlen, b->qlen, (size_t)n, st);
+        upload(c->d_mapq, b->mapq, (size_t)n, st); upload(c->d_flag, b->flag, (size_t)n, st);
+        upload(c->d_qid, b->qid, (size_t)n, st); upload(c->d_qoff, b->qoff, (size_t)n, st);
+        upload(c->d_csoff, b->cs_off, (size_t)n + 1, st);
+        upload(c->d_seq, b->seq, (size_t)b->seq_bytes, st); upload(c->d_bq, b->bq, (size_t)b->bq_bytes, st);
+        upload(c->d_cs, b->cs, (size_t)b->cs_bytes, st);
+        upload(c->d_prefmax, c->h_prefmax, st);
+        HCHECK(hipStreamSynchronize(st));
+        c->have_reads = true;
+        c->h_recs_valid = false;
+        return HIMUT_OK;
+    });
+}
+
+int himut_run(himut_ctx* c) {
+    if (!c) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int { return do_run(c); });
+}
+
+int himut_get_records(himut_ctx* c, const himut_record** records, int64_t* n) {
+    if (!c || !records || !n) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int {
+        if (!c->h_recs_valid) {
+            HCHECK(hipSetDevice(c->device));
+            c->h_recs.resize((size_t)c->n_out);
+            if (c->n_out)
+                HCHECK(hipMemcpyAsync(c->h_recs.data(), c->d_recs_out.p, (size_t)c->n_out * sizeof(himut_record),
+                                      hipMemcpyDeviceToHost, c->stream));
+            HCHECK(hipStreamSynchronize(c->stream));
+            c->h_recs_valid = true;
+        }
+        *records = c->h_recs.data();
+        *n = c->n_out;
+        return HIMUT_OK;
+    });
+}
+
+int himut_get_log(himut_ctx* c, int64_t out[15]) {
+    if (!c || !out) return HIMUT_ERR_ARG;
+    for (int k = 0; k < 15; k++) out[k] = c->log[k];
+    return HIMUT_OK;
+}
+
+int himut_get_stats(himut_ctx* c, himut_run_stats* out) {
+    if (!c || !out) return HIMUT_ERR_ARG;
+    *out = c->stats;
+    return HIMUT_OK;
+}
+
+int himut_records_device(himut_ctx* c, const void** dev_ptr, int64_t* n) {
+    if (!c || !dev_ptr || !n) return HIMUT_ERR_ARG;
+    *dev_ptr = c->d_recs_out.p;
+    *n = c->n_out;
+    return HIMUT_OK;
+}
+
+int himut_copy_records_to_device(himut_ctx* c, void* dst, int64_t capacity_records) {
+    if (!c || (!dst && c->n_out)) return HIMUT_ERR_ARG;
+    if (capacity_records < c->n_out) return fail(c, HIMUT_ERR_ARG, "destination too small");
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        if (c->n_out)
+            HCHECK(hipMemcpyAsync(dst, c->d_recs_out.p, (size_t)c->n_out * sizeof(himut_record), hipMemcpyDeviceToDevice, c->stream));
+        HCHECK(hipStreamSynchronize(c->stream));
+        return HIMUT_OK;
+    });
+}
+
+int himut_pile_counts(himut_ctx* c, int32_t p0, int32_t p1, uint32_t* counts, uint32_t* bqsum) {
+    if (!c || !counts || !bqsum || p1 <= p0) return fail(c, HIMUT_ERR_ARG, "bad pile range");
+    if (!c->have_reads || !c->have_params || !c->have_lut) return fail(c, HIMUT_ERR_ARG, "context not initialised");
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        // one pseudo chunk (p0, p1): its tiles cover rpos p0-1 .. p1-1, the columns p0 .. p1-1 are complete
+        std::vector<int32_t> cs{p0}, ce{p1};
+        ChunkTables T = upload_chunks(c, cs, ce);
+        alloc_derived(c);
+        Reads R = make_reads(c);
+        Derived D = make_derived(c);
+        Chunks C = make_chunks(c, 1);
+        Scalars* sc = c->d_scalars.as<Scalars>();
+        HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+        if (c->n > 0) run_parse_stage(c, R, D, sc);
+        c->d_dense_counts.reserve((size_t)T.positions * 6 * 4 + 64);
+        c->d_dense_bqsum.reserve((size_t)T.positions * 4 * 4 + 64);
+        HCHECK(hipMemsetAsync(c->d_dense_counts.p, 0, (size_t)T.positions * 24, st));
+        HCHECK(hipMemsetAsync(c->d_dense_bqsum.p, 0, (size_t)T.positions * 16, st));
+        himut_params saved = c->params.p;
+        Params P = c->params;
+        P.p.phase = 0;
+        SweepArgs A;
+        A.R = R; A.D = D; A.C = C; A.H = make_phase(c); A.P = P;
+        A.S.pon = nullptr; A.S.npon = 0; A.S.com = nullptr; A.S.ncom = 0;
+        A.lut = c->d_lut.as<GtLut>();
+        A.mask = nullptr; A.recs = nullptr; A.nrec = &sc->nrec; A.cap = 0; A.n_tiles = T.n_tiles;
+        A.dense_counts = c->d_dense_counts.as<uint32_t>(); A.dense_bqsum = c->d_dense_bqsum.as<uint32_t>();
+        A.row_bases = &sc->row_bases; A.err = &sc->err;
+        if (c->n > 0) hipLaunchKernelGGL(k_pileup_sweep<true>, dim3((unsigned)T.n_tiles), dim3(TP), 0, st, A);
+        (void)saved;
+        const int64_t npos = (int64_t)p1 - p0;
+        HCHECK(hipMemcpyAsync(counts, c->d_dense_counts.as<uint32_t>() + 6, (size_t)npos * 24, hipMemcpyDeviceToHost, st));
+        HCHECK(hipMemcpyAsync(bqsum, c->d_dense_bqsum.as<uint32_t>() + 4, (size_t)npos * 16, hipMemcpyDeviceToHost, st));
+        Scalars hs;
+        HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+        HCHECK(hipStreamSynchronize(st));
+        if (hs.err) return check_device_err(c, hs.err);
+        return HIMUT_OK;
+    });
+}
+
+}  // extern "C"

