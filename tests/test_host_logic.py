@@ -101,3 +101,12 @@ def test_records_to_tuples_roundtrip_on_golden():
         assert caller.records_to_tuples(exp["contig"], recs) == util.expected_tuples(exp)
         if pon is not None:
             assert np.array_equal(caller.site_keys([tuple(t) for t in exp["pon_set"]]), pon)
+
+
+def test_thresholds_match_reference():
+    from himut_amd import bamlib, synth
+    for c in util.load_json("thresholds")["cases"]:
+        cfg = synth.SynthConfig(**c["cfg"])
+        b = synth.generate(cfg).batch
+        got = bamlib.get_thresholds({"chr9": b}, ["chr9"], {"chr9": cfg.contig_len})
+        assert got == (c["qlen_lower_limit"], c["qlen_upper_limit"], c["md_threshold"])
