@@ -153,7 +153,7 @@ def main():
         step()
         st = ctx.stats()
         sweep_ms.append(st["ms_sweep"])
-        for k in ("ms_total", "ms_bqsum", "ms_parse", "ms_emit", "ms_sweep", "ms_finalize"):
+        for k in ("ms_total", "ms_parse", "ms_bqsum", "ms_hap", "ms_emit", "ms_sweep", "ms_eval", "ms_finalize"):
             stage_ms.setdefault(k, []).append(st[k])
     barrier()
     elapsed = time.perf_counter() - t0

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -49,19 +50,20 @@ struct DevBuf {
 
 template <class T>
 void upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
-    b.reserve(std::max<size_t>(n, 1) * sizeof(T) + 64);
+    b.reserve(std::max<size_t>(n, 1) * sizeof(T) + 256);  // slack: kernels read whole 16/32-byte windows
     if (n) HCHECK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, st));
 }
 
 template <class T>
 void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) { upload(b, v.data(), v.size(), st); }
 
-enum { EV_START = 0, EV_BQSUM, EV_PARSE, EV_HAP, EV_EMIT, EV_SWEEP, EV_FINAL, EV_COUNT };
+enum { EV_START = 0, EV_BQSUM, EV_PARSE, EV_HAP, EV_EMIT, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
 
 }  // namespace
 
 struct himut_ctx {
     int device = 0;
+    int n_cus = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     std::string err;
@@ -72,10 +74,12 @@ struct himut_ctx {
     // inputs
     DevBuf d_lut;
     std::vector<int32_t> cstart, cend;
-    DevBuf d_cstart, d_cend, d_maskoff, d_tileoff, d_sstart, d_sidx, d_spmax, d_rlo, d_rhi, d_pairoff;
+    DevBuf d_cstart, d_cend, d_maskoff, d_tileoff, d_sstart, d_sidx, d_spmax, d_rlo, d_rhi, d_pairoff, d_hint;
+    int64_t nhint = 0;
     std::vector<int64_t> maskoff, tileoff;
-    DevBuf d_pon, d_com;
-    int64_t npon = 0, ncom = 0;
+    DevBuf d_pon, d_com, d_posbits;
+    std::vector<uint64_t> h_pon, h_com;
+    int64_t npon = 0, ncom = 0, nposbits = 0;
     bool have_phase = false;
     std::vector<int64_t> h_phoff;
     DevBuf d_phoff, d_hpos, d_href, d_halt, d_hbit, d_hap;
@@ -86,10 +90,10 @@ struct himut_ctx {
     bool unique_qnames = true;
     DevBuf d_tstart, d_tend, d_qstart, d_qlen, d_mapq, d_flag, d_qid, d_qoff, d_csoff, d_seq, d_bq, d_cs, d_prefmax;
     // derived
-    DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_rflag, d_ccs;
+    DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs;
     // run state
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
-    DevBuf d_dense_counts, d_dense_bqsum;
+    DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_winlo_c, d_winn_c, d_winoff_c, d_colstore;
     std::vector<himut_record> h_recs;
     bool h_recs_valid = false;
     int64_t n_out = 0;
@@ -103,7 +107,7 @@ namespace {
 struct Scalars {
     unsigned long long ncand;
     unsigned long long nrec;
-    unsigned long long row_bases;
+    unsigned long long reserved0;
     unsigned long long nccs;
     unsigned long long log[16];
     int err;
@@ -155,7 +159,8 @@ Reads make_reads(himut_ctx* c) {
 Derived make_derived(himut_ctx* c) {
     Derived D;
     D.bqsum = c->d_bqsum.as<uint32_t>(); D.nseg = c->d_nseg.as<int32_t>(); D.nmis = c->d_nmis.as<int32_t>();
-    D.segs = c->d_segs.as<Seg>(); D.mis = c->d_mis.as<int32_t>(); D.rflag = c->d_rflag.as<uint8_t>();
+    D.segs = c->d_segs.as<Seg>(); D.mis = c->d_mis.as<int32_t>(); D.mq = c->d_mq.as<uint32_t>();
+    D.rflag = c->d_rflag.as<uint8_t>(); D.meta = c->d_meta.as<ReadMeta>();
     return D;
 }
 
@@ -166,6 +171,7 @@ struct ChunkTables {
 
 ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const std::vector<int32_t>& ce) {
     ChunkTables T;
+    const int TP = PD_TP;  // tiles are only used by the dense pile kernel
     const int64_t n = (int64_t)cs.size();
     T.n = n;
     c->maskoff.assign(n + 1, 0);
@@ -196,7 +202,21 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
         pairoff[k + 1] = pairoff[k] + (rhi[k] - rlo[k]);
     }
     T.npairs = pairoff[n];
+    // look-up hint: for each 16-kb block of positions, the number of sorted starts <= block start
+    int32_t maxend = 0;
+    for (int64_t k = 0; k < n; k++) maxend = std::max(maxend, ce[k]);
+    c->nhint = ((int64_t)maxend >> CHUNK_HINT_SHIFT) + 2;
+    std::vector<int32_t> hint((size_t)c->nhint);
+    {
+        int64_t j = 0;
+        for (int64_t b = 0; b < c->nhint; b++) {
+            const int64_t p = b << CHUNK_HINT_SHIFT;
+            while (j < n && (int64_t)sstart[j] <= p) j++;
+            hint[(size_t)b] = (int32_t)j;
+        }
+    }
     hipStream_t st = c->stream;
+    upload(c->d_hint, hint, st);
     upload(c->d_cstart, cs, st); upload(c->d_cend, ce, st);
     upload(c->d_maskoff, c->maskoff, st); upload(c->d_tileoff, c->tileoff, st);
     upload(c->d_sstart, sstart, st); upload(c->d_sidx, sidx, st); upload(c->d_spmax, spmax, st);
@@ -209,9 +229,10 @@ Chunks make_chunks(himut_ctx* c, int64_t n) {
     Chunks C;
     C.n = n;
     C.start = c->d_cstart.as<int32_t>(); C.end = c->d_cend.as<int32_t>();
-    C.maskoff = c->d_maskoff.as<int64_t>(); C.tileoff = c->d_tileoff.as<int64_t>();
+    C.maskoff = c->d_maskoff.as<int64_t>();
     C.s_start = c->d_sstart.as<int32_t>(); C.s_idx = c->d_sidx.as<int32_t>(); C.s_pmaxend = c->d_spmax.as<int32_t>();
     C.rlo = c->d_rlo.as<int64_t>(); C.rhi = c->d_rhi.as<int64_t>(); C.pairoff = c->d_pairoff.as<int64_t>();
+    C.hint = c->d_hint.as<int32_t>(); C.nhint = c->nhint;
     return C;
 }
 
@@ -224,6 +245,17 @@ Phase make_phase(himut_ctx* c) {
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
 
+void launch_pile_dense(himut_ctx* c, const Chunks& C, const Reads& R, const Derived& D, const ChunkTables& T, int* err) {
+    hipStream_t st = c->stream;
+    c->d_tiles.reserve((size_t)T.n_tiles * sizeof(TileInfo) + 64);
+    hipLaunchKernelGGL(k_tile_index<PD_TP>, dim3(blocks_for(T.n_tiles, 256)), dim3(256), 0, st, R, C,
+                       c->d_tileoff.as<int64_t>(), T.n_tiles, c->d_tiles.as<TileInfo>());
+    DenseArgs A;
+    A.R = R; A.D = D; A.C = C; A.tiles = c->d_tiles.as<TileInfo>(); A.n_tiles = T.n_tiles;
+    A.counts = c->d_dense_counts.as<uint32_t>(); A.bqsum = c->d_dense_bqsum.as<uint32_t>(); A.err = err;
+    hipLaunchKernelGGL((k_pile_dense<PD_TP, PD_RB, PD_NT>), dim3((unsigned)T.n_tiles), dim3(PD_NT), 0, st, A);
+}
+
 int check_device_err(himut_ctx* c, int bits) {
     if (!bits) return HIMUT_OK;
     for (int code = 1; code < 31; code++)
@@ -233,10 +265,10 @@ int check_device_err(himut_ctx* c, int bits) {
 
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_bqsum, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D);
-    HCHECK(hipEventRecord(c->ev[EV_BQSUM], st));
     hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, c->params, &sc->err);
     HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+    hipLaunchKernelGGL(k_read_filters, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
+    HCHECK(hipEventRecord(c->ev[EV_BQSUM], st));
 }
 
 void alloc_derived(himut_ctx* c) {
@@ -247,6 +279,8 @@ void alloc_derived(himut_ctx* c) {
     c->d_nmis.reserve((size_t)n * 4 + 64);
     c->d_segs.reserve((size_t)segcap * sizeof(Seg));
     c->d_mis.reserve((size_t)segcap * 4);
+    c->d_mq.reserve((size_t)segcap * 4);
+    c->d_meta.reserve((size_t)(n + 1) * sizeof(ReadMeta));
     c->d_rflag.reserve((size_t)n + 64);
     c->d_ccs.reserve((size_t)n + 64);
     c->d_scalars.reserve(sizeof(Scalars));
@@ -274,7 +308,7 @@ int do_run(himut_ctx* c) {
 
     ChunkTables T = upload_chunks(c, c->cstart, c->cend);
     alloc_derived(c);
-    const size_t mask_bytes = ((size_t)T.positions * 2 + 7) & ~(size_t)3;
+    const size_t mask_bytes = ((size_t)T.positions * 2 + 11) & ~(size_t)3;
     c->d_mask.reserve(mask_bytes + 64);
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
 
@@ -289,13 +323,26 @@ int do_run(himut_ctx* c) {
     HCHECK(hipMemsetAsync(c->d_mask.p, 0, mask_bytes, st));
     HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
     if (c->n > 0) run_parse_stage(c, R, D, sc);
-    else { HCHECK(hipEventRecord(c->ev[EV_BQSUM], st)); HCHECK(hipEventRecord(c->ev[EV_PARSE], st)); }
+    else { HCHECK(hipEventRecord(c->ev[EV_PARSE], st)); HCHECK(hipEventRecord(c->ev[EV_BQSUM], st)); }
     if (phase && T.npairs > 0)
         hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
     HCHECK(hipEventRecord(c->ev[EV_HAP], st));
+    // every substitution op takes at least three characters of cs text, so this bounds the candidate list
+    const int64_t cand_cap = 2 * (c->cs_bytes / 3 + c->n) + 64;
+    c->d_cands.reserve((size_t)cand_cap * sizeof(Cand));
     if (c->n > 0 && T.n > 0)
-        hipLaunchKernelGGL(k_emit_candidates, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, C, H, c->params,
-                           c->d_mask.as<uint16_t>(), c->d_ccs.as<uint8_t>(), &sc->ncand, &sc->err);
+        hipLaunchKernelGGL(k_emit_candidates, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, C, H, c->params,
+                           c->d_mask.as<uint32_t>(), c->d_ccs.as<uint8_t>(), c->d_cands.as<Cand>(), &sc->ncand, cand_cap,
+                           &sc->err);
+    // window index for the column kernel
+    int32_t maxend = 0;
+    for (int32_t e : c->cend) maxend = std::max(maxend, e);
+    const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
+    c->d_winlo.reserve((size_t)nblk * 4 + 64);
+    c->d_winhi.reserve((size_t)nblk * 4 + 64);
+    if (c->n > 0)
+        hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, R, nblk, c->d_winlo.as<int32_t>(),
+                           c->d_winhi.as<int32_t>());
     HCHECK(hipEventRecord(c->ev[EV_EMIT], st));
 
     // exact number of candidate evaluations -> record capacity
@@ -304,50 +351,78 @@ int do_run(himut_ctx* c) {
     HCHECK(hipStreamSynchronize(st));
     if (hs.err) return check_device_err(c, hs.err);
     const int64_t ncand = (int64_t)hs.ncand;
+    if (ncand > cand_cap) return fail(c, HIMUT_ERR_ARG, "internal: candidate list overflow");
     c->d_recs.reserve((size_t)(ncand + 1) * sizeof(himut_record));
     c->d_recs_out.reserve((size_t)(ncand + 1) * sizeof(himut_record));
 
-    SweepArgs A;
-    A.R = R; A.D = D; A.C = C; A.H = H; A.P = c->params;
-    A.S.pon = c->d_pon.as<uint64_t>(); A.S.npon = c->npon; A.S.com = c->d_com.as<uint64_t>(); A.S.ncom = c->ncom;
-    A.lut = c->d_lut.as<GtLut>();
-    A.mask = c->d_mask.as<uint16_t>();
-    A.recs = c->d_recs.as<himut_record>();
-    A.nrec = &sc->nrec;
-    A.cap = ncand;
-    A.n_tiles = T.n_tiles;
-    A.dense_counts = nullptr; A.dense_bqsum = nullptr;
-    A.row_bases = &sc->row_bases;
-    A.err = &sc->err;
-    if (T.n_tiles > 0 && c->n > 0)
-        hipLaunchKernelGGL(k_pileup_sweep<false>, dim3((unsigned)T.n_tiles), dim3(TP), 0, st, A);
+    size_t sort_tmp = 0, scan_tmp = 0;
+    if (ncand > 0) {
+        // candidates in the order of the final records (tpos, chunk, ref, alt)
+        c->d_keys.reserve((size_t)ncand * 8); c->d_keys2.reserve((size_t)ncand * 8);
+        c->d_cands2.reserve((size_t)ncand * sizeof(Cand) + 256);
+        c->d_emit.reserve((size_t)ncand * 4); c->d_pos.reserve((size_t)ncand * 4);
+        hipLaunchKernelGGL(k_cand_keys, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, c->d_cands.as<Cand>(), ncand,
+                           c->d_keys.as<uint64_t>());
+        HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
+                                         c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
+        HCHECK(rocprim::exclusive_scan(nullptr, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
+                                       (size_t)ncand, rocprim::plus<uint32_t>(), st));
+        c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
+        HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
+                                         c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
+        // column store layout: window per candidate, offsets by exclusive scan
+        c->d_winlo_c.reserve((size_t)ncand * 4 + 256); c->d_winn_c.reserve((size_t)ncand * 4 + 256);
+        c->d_winoff_c.reserve((size_t)ncand * 4 + 256);
+        hipLaunchKernelGGL(k_cand_windows, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand,
+                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_winlo_c.as<int32_t>(),
+                           c->d_winn_c.as<uint32_t>());
+        HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_tmp, c->d_winn_c.as<uint32_t>(), c->d_winoff_c.as<uint32_t>(), 0u,
+                                       (size_t)ncand, rocprim::plus<uint32_t>(), st));
+        uint32_t last_off = 0, last_n = 0;
+        HCHECK(hipMemcpyAsync(&last_off, c->d_winoff_c.as<uint32_t>() + (ncand - 1), 4, hipMemcpyDeviceToHost, st));
+        HCHECK(hipMemcpyAsync(&last_n, c->d_winn_c.as<uint32_t>() + (ncand - 1), 4, hipMemcpyDeviceToHost, st));
+        HCHECK(hipStreamSynchronize(st));
+        const size_t nslots = (size_t)last_off + last_n;
+        c->d_colstore.reserve(nslots * 2 + 256);
+        c->stats.sweep_row_bases = (int64_t)nslots;
+        GatherArgs G;
+        G.R = R; G.D = D; G.C = C; G.H = H;
+        G.cands = c->d_cands2.as<Cand>(); G.ncand = ncand;
+        G.win_lo = c->d_winlo_c.as<int32_t>(); G.win_n = c->d_winn_c.as<uint32_t>(); G.win_off = c->d_winoff_c.as<uint32_t>();
+        G.colstore = c->d_colstore.as<uint16_t>();
+        const int64_t ngroups = (ncand + EG - 1) / EG;
+        if (phase) hipLaunchKernelGGL(k_gather_columns<true>, dim3(blocks_for(ngroups, 4)), dim3(256), 0, st, G);
+        else hipLaunchKernelGGL(k_gather_columns<false>, dim3(blocks_for(ngroups, 4)), dim3(256), 0, st, G);
+        HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
+        EvalArgs A;
+        A.P = c->params;
+        A.S.pon = c->d_pon.as<uint64_t>(); A.S.npon = c->npon; A.S.com = c->d_com.as<uint64_t>(); A.S.ncom = c->ncom;
+        A.S.posbits = c->d_posbits.as<uint32_t>(); A.S.nposbits = c->nposbits;
+        A.lut = c->d_lut.as<GtLut>();
+        A.cands = c->d_cands2.as<Cand>(); A.ncand = ncand;
+        A.cstart = c->d_cstart.as<int32_t>();
+        A.win_n = c->d_winn_c.as<uint32_t>(); A.win_off = c->d_winoff_c.as<uint32_t>();
+        A.colstore = c->d_colstore.as<uint16_t>();
+        A.recs = c->d_recs.as<himut_record>();
+        A.err = &sc->err;
+        if (phase) hipLaunchKernelGGL(k_eval_columns<true>, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(k_eval_columns<false>, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, A);
+    } else {
+        HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
+    }
     HCHECK(hipEventRecord(c->ev[EV_SWEEP], st));
 
     // ---- finalisation: order, cross-chunk som_seen, counters, compaction
     int64_t nrec = ncand;  // every set mask bit yields exactly one evaluation
     if (nrec > 0) {
-        c->d_keys.reserve((size_t)nrec * 8); c->d_keys2.reserve((size_t)nrec * 8);
-        c->d_vals.reserve((size_t)nrec * 4); c->d_vals2.reserve((size_t)nrec * 4);
-        c->d_emit.reserve((size_t)nrec * 4); c->d_pos.reserve((size_t)nrec * 4);
         const unsigned nb = blocks_for(nrec, 256);
-        hipLaunchKernelGGL(k_record_keys, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), nrec,
-                           c->d_keys.as<uint64_t>(), c->d_vals.as<uint32_t>());
-        size_t tmp_bytes = 0;
-        HCHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
-                                         c->d_vals.as<uint32_t>(), c->d_vals2.as<uint32_t>(), (size_t)nrec, 0, 60, st));
-        size_t tmp2 = 0;
-        HCHECK(rocprim::exclusive_scan(nullptr, tmp2, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u, (size_t)nrec,
-                                       rocprim::plus<uint32_t>(), st));
-        c->d_tmp.reserve(std::max(tmp_bytes, tmp2) + 256);
-        HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, tmp_bytes, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
-                                         c->d_vals.as<uint32_t>(), c->d_vals2.as<uint32_t>(), (size_t)nrec, 0, 60, st));
         hipLaunchKernelGGL(k_resolve_seen, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
-                           c->d_keys2.as<uint64_t>(), c->d_vals2.as<uint32_t>(), nrec);
+                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, nrec);
         hipLaunchKernelGGL(k_finalize_flags, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
-                           c->d_keys2.as<uint64_t>(), c->d_vals2.as<uint32_t>(), nrec, c->d_emit.as<uint32_t>(), sc->log);
-        HCHECK(rocprim::exclusive_scan(c->d_tmp.p, tmp2, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
+                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, nrec, c->d_emit.as<uint32_t>(), sc->log);
+        HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
                                        (size_t)nrec, rocprim::plus<uint32_t>(), st));
-        hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), c->d_vals2.as<uint32_t>(),
+        hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), (const uint32_t*)nullptr,
                            c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), nrec, c->d_recs_out.as<himut_record>());
     }
     if (c->n > 0)
@@ -362,11 +437,6 @@ int do_run(himut_ctx* c) {
     }
     HCHECK(hipStreamSynchronize(st));
     if (hs.err) return check_device_err(c, hs.err);
-    if ((int64_t)hs.nrec != ncand) {
-        char buf[160];
-        snprintf(buf, sizeof(buf), "internal: %lld candidates marked but %lld evaluated", (long long)ncand, (long long)hs.nrec);
-        return fail(c, HIMUT_ERR_ARG, buf);
-    }
     c->n_out = nrec > 0 ? (int64_t)last_pos + last_emit : 0;
     for (int k = 0; k < 15; k++) c->log[k] = (int64_t)hs.log[k];
     c->log[0] = (int64_t)hs.nccs;
@@ -374,11 +444,12 @@ int do_run(himut_ctx* c) {
     auto ms = [&](int a, int b) { float f = 0; (void)hipEventElapsedTime(&f, c->ev[a], c->ev[b]); return (double)f; };
     himut_run_stats& S = c->stats;
     S.ms_total = ms(EV_START, EV_FINAL);
-    S.ms_bqsum = ms(EV_START, EV_BQSUM);
-    S.ms_parse = ms(EV_BQSUM, EV_PARSE);
-    S.ms_hap = ms(EV_PARSE, EV_HAP);
+    S.ms_parse = ms(EV_START, EV_PARSE);
+    S.ms_bqsum = ms(EV_PARSE, EV_BQSUM);
+    S.ms_hap = ms(EV_BQSUM, EV_HAP);
     S.ms_emit = ms(EV_HAP, EV_EMIT);
-    S.ms_sweep = ms(EV_EMIT, EV_SWEEP);
+    S.ms_sweep = ms(EV_EMIT, EV_GATHER);
+    S.ms_eval = ms(EV_GATHER, EV_SWEEP);
     S.ms_finalize = ms(EV_SWEEP, EV_FINAL);
     S.n_reads = c->n;
     S.read_bases = c->read_bases;
@@ -386,7 +457,6 @@ int do_run(himut_ctx* c) {
     S.n_tiles = T.n_tiles;
     S.n_candidates = ncand;
     S.n_records = c->n_out;
-    S.sweep_row_bases = (int64_t)hs.row_bases;
     return HIMUT_OK;
 }
 
@@ -407,6 +477,9 @@ int himut_create(int device, himut_ctx** out) {
         HCHECK(hipGetDeviceCount(&ndev));
         if (device < 0 || device >= ndev) return fail(c, HIMUT_ERR_ARG, "no such HIP device");
         HCHECK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HCHECK(hipGetDeviceProperties(&prop, device));
+        c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         for (auto& e : c->ev) HCHECK(hipEventCreate(&e));
         return HIMUT_OK;
@@ -473,8 +546,18 @@ int himut_set_site_set(himut_ctx* c, int which, const uint64_t* keys, int64_t n)
         HCHECK(hipSetDevice(c->device));
         DevBuf& b = which == 0 ? c->d_pon : c->d_com;
         upload(b, keys, (size_t)n, c->stream);
-        HCHECK(hipStreamSynchronize(c->stream));
+        (which == 0 ? c->h_pon : c->h_com).assign(keys, keys + n);
         (which == 0 ? c->npon : c->ncom) = n;
+        // position bitmap over both sets: lets a candidate skip the two binary searches
+        uint64_t maxpos = 0;
+        for (const auto* v : {&c->h_pon, &c->h_com})
+            if (!v->empty()) maxpos = std::max<uint64_t>(maxpos, v->back() >> 4);
+        std::vector<uint32_t> bits((size_t)(maxpos >> 5) + 2, 0u);
+        for (const auto* v : {&c->h_pon, &c->h_com})
+            for (uint64_t k : *v) bits[(size_t)((k >> 4) >> 5)] |= 1u << ((k >> 4) & 31);
+        c->nposbits = (c->h_pon.empty() && c->h_com.empty()) ? 0 : (int64_t)maxpos + 1;
+        upload(c->d_posbits, bits, c->stream);
+        HCHECK(hipStreamSynchronize(c->stream));
         return HIMUT_OK;
     });
 }
@@ -618,18 +701,7 @@ int himut_pile_counts(himut_ctx* c, int32_t p0, int32_t p1, uint32_t* counts, ui
         c->d_dense_bqsum.reserve((size_t)T.positions * 4 * 4 + 64);
         HCHECK(hipMemsetAsync(c->d_dense_counts.p, 0, (size_t)T.positions * 24, st));
         HCHECK(hipMemsetAsync(c->d_dense_bqsum.p, 0, (size_t)T.positions * 16, st));
-        himut_params saved = c->params.p;
-        Params P = c->params;
-        P.p.phase = 0;
-        SweepArgs A;
-        A.R = R; A.D = D; A.C = C; A.H = make_phase(c); A.P = P;
-        A.S.pon = nullptr; A.S.npon = 0; A.S.com = nullptr; A.S.ncom = 0;
-        A.lut = c->d_lut.as<GtLut>();
-        A.mask = nullptr; A.recs = nullptr; A.nrec = &sc->nrec; A.cap = 0; A.n_tiles = T.n_tiles;
-        A.dense_counts = c->d_dense_counts.as<uint32_t>(); A.dense_bqsum = c->d_dense_bqsum.as<uint32_t>();
-        A.row_bases = &sc->row_bases; A.err = &sc->err;
-        if (c->n > 0) hipLaunchKernelGGL(k_pileup_sweep<true>, dim3((unsigned)T.n_tiles), dim3(TP), 0, st, A);
-        (void)saved;
+        if (c->n > 0) launch_pile_dense(c, C, R, D, T, &sc->err);
         const int64_t npos = (int64_t)p1 - p0;
         HCHECK(hipMemcpyAsync(counts, c->d_dense_counts.as<uint32_t>() + 6, (size_t)npos * 24, hipMemcpyDeviceToHost, st));
         HCHECK(hipMemcpyAsync(bqsum, c->d_dense_bqsum.as<uint32_t>() + 4, (size_t)npos * 16, hipMemcpyDeviceToHost, st));

@@ -2,23 +2,35 @@
 //
 // Pipeline for one contig (himut_run in himut_hip.hip launches them in order):
 //
-//   k_bqsum            one wave per read: sum of BQ over the whole query (qv filter,
-//                      caller.py:85-94 / bamlib.py:34-36)
-//   k_parse_cs         one thread per read: cs tag -> gapless segments + mismatch
-//                      positions + identity, chunk-independent read filters
-//                      (cslib.py:7-64, bamlib.py:47-63, caller.py:310-317)
+//   k_parse_cs         one thread per read: cs tag -> gapless segments + mismatch list +
+//                      identity (cslib.py:7-64, bamlib.py:47-63)
+//   k_read_filters     one wave per read, 16-byte coalesced loads: sum of BQ over the whole
+//                      query (np.mean, bamlib.py:34-36) = the HBM stream of the path; cs vs SEQ
+//                      check of every substitution; read filters of caller.py:310-317
 //   k_read_hap         (--phase) one thread per (chunk, read): haplib.py:46-83
-//   k_emit_candidates  one thread per read: trim / mismatch-window filters
-//                      (bamlib.py:69-86,222-282) -> per-chunk candidate bit mask
-//   k_pileup_sweep     one workgroup per 256-position tile of a chunk: stages the
-//                      base/BQ rows of every overlapping read through LDS, reduces the
-//                      columns (caller.py:44-72, bamlib.py:181-219) and runs the
-//                      genotyper + filter cascade on candidate columns
-//                      (gtlib.py:72-174, caller.py:324-621)
-//   k_record_keys / k_resolve_seen / k_finalize_flags / k_compact
+//   k_emit_candidates  one wave per read, lanes = mismatch entries: trim / mismatch-window
+//                      filters (bamlib.py:69-86,222-282); the first read to propose a
+//                      (chunk, tpos, ref, alt) appends it to the candidate list
+//                      (the set() of caller.py:324) using a per-chunk bit mask
+//   k_cand_keys + sort the candidates in the order of the final records
+//   k_window_index     per 256-position block: the range of reads that can cover it
+//   k_cand_windows + scan  per candidate: its read window and its offset in the column store
+//   k_gather_columns   one WAVE per 8 neighbouring candidate columns, lanes = the reads that
+//                      can cover them: read metadata + segment list once per group, then
+//                      the base / quality byte of every (column, read) with independent
+//                      loads -> 16-bit slots of the column store, in fetch order
+//   k_eval_columns     one THREAD per candidate column: allele counts, BQ sums, the
+//                      genotype likelihood sums added in fetch order exactly as the
+//                      reference's python sum() does, genotype, filter cascade
+//                      (caller.py:44-72,324-621, bamlib.py:181-219, gtlib.py:72-174)
+//   k_resolve_seen / k_finalize_flags / k_compact
 //                      sorted order, cross-chunk som_seen (caller.py:244,347,
 //                      bamlib.py:77), the 15 counters (caller.py:625-641), set()
 //                      de-duplication (caller.py:622-624)
+//   k_pile_dense       dense per-position pile (counts + BQ sums for EVERY position of a
+//                      range): LDS-staged base/BQ tiles, one workgroup per tile.  Used by
+//                      himut_pile_counts (the per-position sweep of normcounts.py:317-400
+//                      builds on it).
 //
 // Integer work plus a small fp64 tail; no MFMA.  Wave size 64 throughout.
 #pragma once
@@ -29,10 +41,13 @@
 
 namespace himut {
 
-constexpr int TP = 256;  // reference positions per tile == threads per workgroup
-constexpr int RB = 64;   // pile rows staged per LDS batch
+constexpr int WIN_SHIFT = 8;  // k_window_index granularity: 256 reference positions
+constexpr int CHUNK_HINT_SHIFT = 14;  // chunk look-up hint granularity: 16 kb
 
-// pile cell (LDS): bits 0-2 allele, bit 3 "an insertion precedes this position"
+// k_pile_dense geometry: tile width, LDS row batch, threads
+constexpr int PD_TP = 512, PD_RB = 56, PD_NT = 256;
+
+// pile cell: bits 0-2 allele, bit 3 "an insertion precedes this position"
 constexpr uint8_t CELL_OTHER = 4;  // query base outside ATGC (reference raises KeyError)
 constexpr uint8_t CELL_DEL = 5;
 constexpr uint8_t CELL_EMPTY = 7;
@@ -43,6 +58,7 @@ constexpr uint32_t SEG_INS = 2;
 
 constexpr uint8_t RF_SECONDARY = 1;
 constexpr uint8_t RF_PASS = 2;
+constexpr uint8_t RF_IDENT_OK = 4;
 
 constexpr uint8_t REC_GERM = 1;        // dropped as germline (caller.py:338-345): counted, no record
 constexpr uint8_t REC_SUPPRESSED = 2;  // tpos already in som_seen from an earlier chunk
@@ -72,22 +88,34 @@ struct Derived {
     uint32_t* bqsum;
     int32_t* nseg;
     int32_t* nmis;
-    Seg* segs;      // seg_base(r) = (cs_off[r] >> 1) + r
-    int32_t* mis;   // same base; 1-based mismatch positions (cslib.py:54-62)
+    Seg* segs;       // seg_base(r) = (cs_off[r] >> 1) + r
+    int32_t* mis;    // same base; 1-based mismatch positions (cslib.py:54-62)
+    uint32_t* mq;    // same base; per mismatch: qpos << 5 | (substitution ? 16 | ref << 2 | alt : 0)
     uint8_t* rflag;
+    struct ReadMeta* meta;
+};
+
+// everything a pile row needs about its read, in one 32-byte load
+struct ReadMeta {
+    int32_t tstart, tend;
+    int32_t nseg;
+    uint32_t flags;   // RF_*
+    int64_t segbase;
+    int64_t qoff;
 };
 
 struct Chunks {
     int64_t n;
     const int32_t *start, *end;
-    const int64_t* maskoff;  // prefix of (end - start + 1)
-    const int64_t* tileoff;  // prefix of ceil((end - start + 1) / TP)
-    const int32_t* s_start;  // starts sorted ascending
-    const int32_t* s_idx;    // chunk index per sorted slot
+    const int64_t* maskoff;    // prefix of (end - start + 1)
+    const int32_t* s_start;    // starts sorted ascending
+    const int32_t* s_idx;      // chunk index per sorted slot
     const int32_t* s_pmaxend;  // prefix maximum of end in sorted order
-    const int64_t* rlo;      // first read with prefmax_tend > start
-    const int64_t* rhi;      // first read with tstart >= end
-    const int64_t* pairoff;  // prefix of (rhi - rlo)
+    const int64_t* rlo;        // first read with prefmax_tend > start
+    const int64_t* rhi;        // first read with tstart >= end
+    const int64_t* pairoff;    // prefix of (rhi - rlo)
+    const int32_t* hint;       // hint[p >> CHUNK_HINT_SHIFT] = number of sorted starts <= (p >> SHIFT) << SHIFT
+    int64_t nhint;
 };
 
 struct Phase {
@@ -107,6 +135,12 @@ struct GtLut {
     double prior[4];   // homref het hetalt homalt
 };
 
+// one proposed (chunk, tpos, ref, alt)
+struct Cand {
+    int32_t tpos;        // 1-based
+    uint32_t chunk_bit;  // chunk << 4 | (ref << 2 | alt)
+};
+
 __device__ __forceinline__ int64_t seg_base(const Reads& R, int64_t r) { return (R.cs_off[r] >> 1) + r; }
 
 __device__ __forceinline__ int nib_at(const uint8_t* seq, int64_t o) {
@@ -116,7 +150,7 @@ __device__ __forceinline__ int nib_at(const uint8_t* seq, int64_t o) {
 // BAM nibble -> himut allele index A0 T1 G2 C3 (util.py:14-20), 4 otherwise
 __device__ __forceinline__ int nib2allele(int n) { return (int)((0x4444444144424304ULL >> (4 * n)) & 15); }
 __device__ __forceinline__ int nib2char(int n) { return "=ACMGRSVTWYHKDBN"[n]; }
-__device__ __forceinline__ int allele2char(int a) { return "ATGC"[a & 3]; }
+__device__ __forceinline__ int allele2char(int a) { return (int)((0x43475441u >> (8 * (a & 3))) & 255); }  // "ATGC"
 __device__ __forceinline__ int char2allele(int c) {
     return c == 'A' ? 0 : c == 'T' ? 1 : c == 'G' ? 2 : c == 'C' ? 3 : -1;
 }
@@ -137,35 +171,57 @@ __device__ __forceinline__ int64_t upper_bound(const T* a, int64_t lo, int64_t h
 
 __device__ __forceinline__ void set_err(int* err, int code) { atomicOr(err, 1 << code); }
 
-// ---------------------------------------------------------------------------------------
-// k_bqsum: one wave per read, 16-byte coalesced loads (qoff is a multiple of 32).
-__global__ void __launch_bounds__(256) k_bqsum(Reads R, Derived D) {
+// slot reservation for the lanes that reach this point together: one atomic per wave
+__device__ __forceinline__ unsigned long long wave_reserve(unsigned long long* counter) {
+    const unsigned long long act = __ballot(1);
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R.n) return;
-    const uint8_t* base = R.bq + R.qoff[r];
-    const int n = R.qlen[r];
-    uint32_t sum = 0;
-    for (int o = lane * 16; o < n; o += 64 * 16) {
-        uint4 v = *reinterpret_cast<const uint4*>(base + o);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int rem = n - (o + 4 * k);
-            uint32_t x = w[k];
-            if (rem < 4) x = rem <= 0 ? 0u : (x & (0xffffffffu >> (8 * (4 - rem))));
-            uint32_t s2 = (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
-            sum += (s2 & 0xffffu) + (s2 >> 16);
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
-    if (lane == 0) D.bqsum[r] = sum;
+    const int leader = __ffsll((long long)act) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(act));
+    base = __shfl(base, leader, 64);
+    return base + (unsigned long long)__popcll(act & ((1ULL << lane) - 1ULL));
 }
 
 // ---------------------------------------------------------------------------------------
-// cs tokenizer shared by k_parse_cs and k_emit_candidates.  Mirrors the regex of
-// cslib.py:8  (:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+).
+// cs tokenizer.  Mirrors the regex of cslib.py:8  (:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+).
+// Each thread reads its tag through a private 128-byte window in LDS (dword k of thread
+// t lives at s_win[k * 256 + t]: conflict-free), refilled 64 bytes at a time; the next
+// 64 bytes are already in flight in registers while the current ones are consumed.
+struct CsText {
+    const uint8_t* s;
+    uint32_t* w;          // this thread's column of the LDS window
+    int64_t loaded_end;   // text bytes [loaded_end - 128, loaded_end) are in the window
+    uint4 p0, p1, p2, p3; // the 64 bytes after loaded_end
+    uint32_t cw;
+    int ck;
+    __device__ __forceinline__ void fetch(int64_t off) {
+        __builtin_memcpy(&p0, s + off, 16);       // buffers carry 256 bytes of slack
+        __builtin_memcpy(&p1, s + off + 16, 16);
+        __builtin_memcpy(&p2, s + off + 32, 16);
+        __builtin_memcpy(&p3, s + off + 48, 16);
+    }
+    __device__ __forceinline__ void commit() {
+        const int h = (int)((loaded_end >> 6) & 1) * 16;  // which half of the window
+        w[(h + 0) * 256] = p0.x; w[(h + 1) * 256] = p0.y; w[(h + 2) * 256] = p0.z; w[(h + 3) * 256] = p0.w;
+        w[(h + 4) * 256] = p1.x; w[(h + 5) * 256] = p1.y; w[(h + 6) * 256] = p1.z; w[(h + 7) * 256] = p1.w;
+        w[(h + 8) * 256] = p2.x; w[(h + 9) * 256] = p2.y; w[(h + 10) * 256] = p2.z; w[(h + 11) * 256] = p2.w;
+        w[(h + 12) * 256] = p3.x; w[(h + 13) * 256] = p3.y; w[(h + 14) * 256] = p3.z; w[(h + 15) * 256] = p3.w;
+        loaded_end += 64;
+        ck = -1;
+        fetch(loaded_end);
+    }
+    __device__ __forceinline__ CsText(const uint8_t* p, uint32_t* win) : s(p), w(win), loaded_end(0), cw(0), ck(-1) {
+        fetch(0);
+        commit();
+    }
+    __device__ __forceinline__ int at(int64_t i) {
+        while (i >= loaded_end) commit();
+        const int k = (int)((i >> 2) & 31);
+        if (k != ck) { cw = w[k * 256]; ck = k; }
+        return (int)((cw >> (8 * (i & 3))) & 255u);
+    }
+};
+
 struct CsOp {
     int kind;     // ':' '*' '=' '+' '-' ; 0 on error
     int len;      // run length / letters
@@ -173,27 +229,32 @@ struct CsOp {
     int64_t text; // offset of the letters ('=' '+' '-')
 };
 
-__device__ __forceinline__ int64_t cs_next(const uint8_t* s, int64_t i, int64_t n, CsOp& op) {
-    int c = s[i];
+__device__ __forceinline__ int64_t cs_next(CsText& s, int64_t i, int64_t n, CsOp& op) {
+    const int c = s.at(i);
     op.kind = 0;
     if (c == ':') {
         int64_t j = i + 1;
         int64_t v = 0;
-        while (j < n && s[j] >= '0' && s[j] <= '9') { v = v * 10 + (s[j] - '0'); j++; }
+        while (j < n) {
+            const int d = s.at(j);
+            if (d < '0' || d > '9') break;
+            v = v * 10 + (d - '0');
+            j++;
+        }
         if (j == i + 1) return n;
         op.kind = ':'; op.len = (int)v;
         return j;
     }
     if (c == '*') {
         if (i + 2 >= n) return n;
-        int a = s[i + 1], b = s[i + 2];
+        const int a = s.at(i + 1), b = s.at(i + 2);
         if (!(a >= 'a' && a <= 'z') || !(b >= 'a' && b <= 'z')) return n;
         op.kind = '*'; op.len = 1; op.ref = a - 32; op.alt = b - 32;
         return i + 3;
     }
     if (c == '=' || c == '+' || c == '-') {
         int64_t j = i + 1;
-        while (j < n && is_alpha(s[j])) j++;
+        while (j < n && is_alpha(s.at(j))) j++;
         if (j == i + 1) return n;
         op.kind = c; op.len = (int)(j - i - 1); op.text = i + 1;
         return j;
@@ -201,18 +262,29 @@ __device__ __forceinline__ int64_t cs_next(const uint8_t* s, int64_t i, int64_t 
     return n;
 }
 
-// k_parse_cs: thread per read.
+// ---------------------------------------------------------------------------------------
+// k_parse_cs: thread per read.  cs -> gapless segments, mismatch list, identity.
 __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err) {
+    __shared__ uint32_t s_win[32 * 256];
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R.n) return;
-    if (R.flag[r] & 0x100) { D.rflag[r] = RF_SECONDARY; D.nseg[r] = 0; D.nmis[r] = 0; return; }  // bamlib.py:17
-    const uint8_t* s = R.cs + R.cs_off[r];
-    const int64_t n = R.cs_off[r + 1] - R.cs_off[r];
-    const int64_t sb = seg_base(R, r);
+    const int64_t cs0 = R.cs_off[r];
+    const int64_t sb = (cs0 >> 1) + r;
+    ReadMeta M;
+    M.tstart = R.tstart[r]; M.tend = R.tend[r]; M.nseg = 0; M.flags = 0; M.segbase = sb; M.qoff = R.qoff[r];
+    if (R.flag[r] & 0x100) {  // bamlib.py:17
+        M.flags = RF_SECONDARY;
+        D.rflag[r] = RF_SECONDARY; D.nseg[r] = 0; D.nmis[r] = 0; D.meta[r] = M;
+        return;
+    }
+    const int64_t n = R.cs_off[r + 1] - cs0;
+    CsText s(R.cs + cs0, s_win + threadIdx.x);
     Seg* segs = D.segs + sb;
     int32_t* mis = D.mis + sb;
-    const int64_t qo = R.qoff[r];
-    int64_t t = R.tstart[r], q = R.qstart[r];
+    uint32_t* mq = D.mq + sb;
+    const int64_t qo = M.qoff;
+    int64_t t = M.tstart, q = R.qstart[r];
+    const int32_t qlen = R.qlen[r];
     int ns = 0, nm = 0;
     int64_t match = 0, mism = 0;
     bool open = false, pending_ins = false;
@@ -229,18 +301,20 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
                 pending_ins = false; open = true;
             }
             if (op.kind == '*') {
-                int qa = nib2allele(nib_at(R.seq, qo + q));
-                if (char2allele(op.alt) < 0 || qa > 3) bad = HIMUT_ERR_BASE;          // caller.py:62
-                else if (qa != char2allele(op.alt)) bad = HIMUT_ERR_CS;                // cs vs SEQ
+                const int aa = char2allele(op.alt);
+                if (aa < 0) bad = HIMUT_ERR_BASE;                                      // caller.py:62
                 if (op.ref != 'N') {
-                    if (char2allele(op.ref) < 0) bad = HIMUT_ERR_BASE;                 // bamlib.py:188
-                    mis[nm++] = (int32_t)(t + 1);                                      // cslib.py:56-60
+                    const int ra = char2allele(op.ref);
+                    if (ra < 0) bad = HIMUT_ERR_BASE;                                  // bamlib.py:188
+                    mis[nm] = (int32_t)(t + 1);                                        // cslib.py:56-60
+                    mq[nm] = ((uint32_t)q << 5) | 16u | ((uint32_t)(ra & 3) << 2) | (uint32_t)(aa & 3);
+                    nm++;
                 }
                 mism += 1;
             } else {
                 if (op.kind == '=') {  // long form: letters must agree with SEQ
                     for (int k = 0; k < op.len; k++)
-                        if (upper(s[op.text + k]) != nib2char(nib_at(R.seq, qo + q + k))) bad = HIMUT_ERR_CS;
+                        if (upper(R.cs[cs0 + op.text + k]) != nib2char(nib_at(R.seq, qo + q + k))) bad = HIMUT_ERR_CS;
                 }
                 match += op.len;
             }
@@ -250,13 +324,13 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
             if (op.kind == '+') {
                 if (pending_ins) bad = HIMUT_ERR_CS;  // two insertions in a row: unsupported
                 pending_ins = true;
-                mis[nm++] = (int32_t)(t + 1);
+                mis[nm] = (int32_t)(t + 1); mq[nm] = (uint32_t)q << 5; nm++;
                 q += op.len; mism += op.len;
             } else {
                 Seg d = {(int32_t)t, (int32_t)q, op.len, SEG_DEL | (pending_ins ? SEG_INS : 0u)};
                 pending_ins = false;
                 segs[ns++] = d;
-                mis[nm++] = (int32_t)(t + 1);
+                mis[nm] = (int32_t)(t + 1); mq[nm] = (uint32_t)q << 5; nm++;
                 t += op.len; mism += op.len;
             }
         }
@@ -264,37 +338,73 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     }
     if (open) segs[ns++] = cur;
     if (pending_ins) { Seg z = {(int32_t)t, (int32_t)q, 0, SEG_INS}; segs[ns++] = z; }
-    if (!bad && (t != R.tend[r] || q > R.qlen[r])) bad = HIMUT_ERR_CS;  // cs inconsistent with CIGAR / SEQ
+    if (!bad && (t != M.tend || q > qlen)) bad = HIMUT_ERR_CS;  // cs inconsistent with CIGAR / SEQ
     if (bad) { set_err(err, bad); ns = 0; nm = 0; }
+    // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow in k_read_filters
+    const double ident = (double)match / (double)(match + mism);
+    uint8_t fl = 0;
+    if (!bad && !(ident < P.p.min_sequence_identity)) fl = RF_IDENT_OK;
+    M.nseg = ns; M.flags = fl;
     D.nseg[r] = ns;
     D.nmis[r] = nm;
-    // chunk-independent read filters, caller.py:310-317
-    const int32_t qlen = R.qlen[r];
-    bool pass = !bad;
-    double qv = (double)D.bqsum[r] / (double)qlen;                    // bamlib.py:35
-    if (qv < (double)P.p.min_qv) pass = false;
-    if ((int)R.mapq[r] < P.p.min_mapq) pass = false;
-    double ident = (double)match / (double)(match + mism);            // bamlib.py:61-62
-    if (ident < P.p.min_sequence_identity) pass = false;
-    if (!(P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit)) pass = false;
-    D.rflag[r] = pass ? RF_PASS : 0;
+    D.rflag[r] = fl;
+    D.meta[r] = M;
 }
 
-// allele (0..3), CELL_OTHER, CELL_DEL or -1 (not covered) of read r at 0-based rpos
-__device__ __forceinline__ int allele_at(const Reads& R, const Derived& D, int64_t r, int32_t rpos, int* nibout) {
-    const Seg* segs = D.segs + seg_base(R, r);
-    const int ns = D.nseg[r];
-    for (int j = 0; j < ns; j++) {
-        Seg sg = segs[j];
-        if (rpos < sg.t0) break;
-        if (rpos < sg.t0 + sg.len) {
-            if (sg.flags & SEG_DEL) return CELL_DEL;
-            int nb = nib_at(R.seq, R.qoff[r] + sg.q0 + (rpos - sg.t0));
-            if (nibout) *nibout = nb;
-            return nib2allele(nb);
+// ---------------------------------------------------------------------------------------
+// k_read_filters: one wave per read.  Streams the read's qualities with 16-byte
+// coalesced loads (np.mean of the whole query, bamlib.py:34-36), checks every
+// substitution of the cs tag against SEQ in parallel, and applies the read filters of
+// caller.py:310-317.
+__global__ void __launch_bounds__(256) k_read_filters(Reads R, Derived D, Params P, int* err) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R.n) return;
+    const uint8_t fl = D.rflag[r];
+    if (fl & RF_SECONDARY) return;
+    const int64_t qo = R.qoff[r];
+    const uint8_t* base = R.bq + qo;
+    const int n = R.qlen[r];
+    uint32_t sum = 0;
+    for (int o = lane * 16; o < n; o += 64 * 16) {
+        uint4 v = *reinterpret_cast<const uint4*>(base + o);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int rem = n - (o + 4 * k);
+            uint32_t x = w[k];
+            if (rem < 4) x = rem <= 0 ? 0u : (x & (0xffffffffu >> (8 * (4 - rem))));
+            uint32_t s2 = (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
+            sum += (s2 & 0xffffu) + (s2 >> 16);
         }
     }
-    return -1;
+    // substitutions: the base cs names must be the base SEQ holds (caller.py:62 uses cs, the pile uses SEQ)
+    int bad = 0;
+    const int nm = D.nmis[r];
+    const uint32_t* mq = D.mq + seg_base(R, r);
+    for (int e = lane; e < nm; e += 64) {
+        const uint32_t v = mq[e];
+        if (v & 16u) {
+            const int qa = nib2allele(nib_at(R.seq, qo + (v >> 5)));
+            if (qa > 3) bad = HIMUT_ERR_BASE;
+            else if (qa != (int)(v & 3u)) bad = HIMUT_ERR_CS;
+        }
+    }
+    if (bad) set_err(err, bad);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if (lane == 0) {
+        D.bqsum[r] = sum;
+        bool pass = (fl & RF_IDENT_OK) != 0;
+        const double qv = (double)sum / (double)n;                         // bamlib.py:35
+        if (qv < (double)P.p.min_qv) pass = false;
+        if ((int)R.mapq[r] < P.p.min_mapq) pass = false;
+        if (!(P.p.qlen_lower_limit < n && n < P.p.qlen_upper_limit)) pass = false;
+        if (pass) {
+            D.rflag[r] = fl | RF_PASS;
+            D.meta[r].flags = fl | RF_PASS;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -340,106 +450,285 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
 }
 
 // ---------------------------------------------------------------------------------------
-// k_emit_candidates: thread per read that passed the read filters.  For every
-// substitution that survives the trim and mismatch-window filters, sets the
-// (ref, alt) bit of its position in the mask of every chunk that both contains
-// tpos (caller.py:104-108,325) and fetched the read (caller.py:299).
+// k_emit_candidates: one wave per read that passed the read filters; lanes = the
+// entries of the read's mismatch list.  For every substitution that survives the trim
+// and mismatch-window filters (bamlib.py:69-86,222-282), and for every chunk that both
+// contains tpos (caller.py:104-108,325) and fetched the read (caller.py:299): set the
+// (ref, alt) bit of the position in that chunk's mask; the lane that sets it first
+// appends the candidate (set() semantics of caller.py:324).
+constexpr int EMIT_MAXC = 4;  // chunks of one read kept in registers
+
 __global__ void __launch_bounds__(256) k_emit_candidates(Reads R, Derived D, Chunks C, Phase H, Params P,
-                                                         uint16_t* mask, uint8_t* ccs_flag,
-                                                         unsigned long long* ncand, int* err) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                         uint32_t* mask, uint8_t* ccs_flag, Cand* cands,
+                                                         unsigned long long* ncand, int64_t cand_cap, int* err) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R.n) return;
-    if (!(D.rflag[r] & RF_PASS)) return;
-    const int32_t ts = R.tstart[r], te = R.tend[r];
+    const ReadMeta M = D.meta[r];
+    if (!(M.flags & RF_PASS)) return;
+    const int32_t ts = M.tstart, te = M.tend;
     const bool phase = P.p.phase != 0;
-    // num_ccs (caller.py:318-320): the read is counted once it passes in any chunk that fetched it
-    {
-        int64_t hi = lower_bound(C.s_start, (int64_t)0, C.n, te);  // chunks with start < tend
-        bool counted = false;
-        for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts && !counted; j--) {
-            const int c = C.s_idx[j];
-            if (C.end[c] > ts) {
-                if (!phase) counted = true;
-                else {
-                    uint8_t h = H.hap[C.pairoff[c] + (r - C.rlo[c])];
-                    if (h != HAP_NONE) counted = true;
-                }
-            }
-        }
-        if (counted) ccs_flag[R.qid[r]] = 1;
-        else if (phase) { /* not phased anywhere: proposes nothing */ return; }
+    // the chunks that fetched this read (start < tend and end > tstart), newest start first
+    int64_t hi = C.hint[min((int64_t)(te > 0 ? te : 0) >> CHUNK_HINT_SHIFT, C.nhint - 1)];
+    while (hi < C.n && C.s_start[hi] < te) hi++;
+    int nc = 0;
+    bool overflow = false;
+    int32_t cc[EMIT_MAXC], cst[EMIT_MAXC], cen[EMIT_MAXC];
+#pragma unroll
+    for (int k = 0; k < EMIT_MAXC; k++) { cc[k] = -1; cst[k] = 0; cen[k] = -1; }
+    for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts; j--) {
+        const int c = C.s_idx[j];
+        const int32_t e = C.end[c];
+        if (e <= ts) continue;
+        if (phase && H.hap[C.pairoff[c] + (r - C.rlo[c])] == HAP_NONE) continue;   // caller.py:306-309
+        if (nc < EMIT_MAXC) {
+#pragma unroll
+            for (int k = 0; k < EMIT_MAXC; k++) if (k == nc) { cc[k] = c; cst[k] = C.start[c]; cen[k] = e; }
+        } else overflow = true;
+        nc++;
     }
-    const uint8_t* s = R.cs + R.cs_off[r];
-    const int64_t n = R.cs_off[r + 1] - R.cs_off[r];
-    const int32_t* mis = D.mis + seg_base(R, r);
+    // num_ccs (caller.py:318-320): counted once it passes in any chunk that fetched it
+    if (nc == 0) return;
+    if (lane == 0) ccs_flag[R.qid[r]] = 1;
+
+    const int64_t sb = M.segbase;
+    const int32_t* mis = D.mis + sb;
+    const uint32_t* mq = D.mq + sb;
     const int nm = D.nmis[r];
     const int32_t qlen = R.qlen[r];
     const double trim_start = floor(P.p.min_trim * (double)qlen);        // bamlib.py:226
     const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);   // bamlib.py:227
     const int64_t w = P.p.mismatch_window_size;
-    int64_t t = ts, q = R.qstart[r];
-    int64_t i = 0;
-    while (i < n) {
-        CsOp op;
-        i = cs_next(s, i, n, op);
-        if (op.kind == 0) break;
-        if (op.kind == ':' || op.kind == '=') { t += op.len; q += op.len; continue; }
-        if (op.kind == '+') { q += op.len; continue; }
-        if (op.kind == '-') { t += op.len; continue; }
-        // substitution
-        if (op.ref != 'N') {
-            const int32_t tp1 = (int32_t)(t + 1);
-            bool ok = !((double)q < trim_start || (double)q > trim_end);  // bamlib.py:231-242
-            if (ok) {                                                       // bamlib.py:245-282
-                int64_t qs = q - w, qe = q + w, ur, dr;
-                if (qs < 0) { ur = w + qs; dr = w - qs; }
-                else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - q; }
-                else { ur = w; dr = w; }
-                const int32_t ms = (int32_t)(tp1 - ur), me = (int32_t)(tp1 + dr);
-                int64_t cnt = upper_bound(mis, (int64_t)0, (int64_t)nm, me) - lower_bound(mis, (int64_t)0, (int64_t)nm, ms) - 1;
-                if (cnt > P.p.max_mismatch_count) ok = false;
+    for (int e = lane; e < nm; e += 64) {
+        const uint32_t v = mq[e];
+        if (!(v & 16u)) continue;  // indel entry
+        const int32_t tp1 = mis[e];
+        const int64_t q = v >> 5;
+        if ((double)q < trim_start || (double)q > trim_end) continue;    // bamlib.py:231-242
+        {                                                                   // bamlib.py:245-282
+            int64_t qs = q - w, qe = q + w, ur, dr;
+            if (qs < 0) { ur = w + qs; dr = w - qs; }
+            else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - q; }
+            else { ur = w; dr = w; }
+            const int32_t ms = (int32_t)(tp1 - ur), me = (int32_t)(tp1 + dr);
+            // bisect_right(me) - bisect_left(ms) - 1 on the sorted list; the entry itself is inside [ms, me]
+            int lo = e, up = e + 1;
+            while (lo > 0 && mis[lo - 1] >= ms) lo--;
+            while (up < nm && mis[up] <= me) up++;
+            if ((int64_t)(up - lo) - 1 > P.p.max_mismatch_count) continue;
+        }
+        const int bit = (int)(v & 15u);
+        auto propose = [&](int c, int32_t cs_) {
+            // 16 mask bits per position, two positions per 32-bit word
+            const int64_t cell = C.maskoff[c] + (tp1 - cs_);
+            const unsigned int m = (1u << bit) << ((cell & 1) ? 16 : 0);
+            const unsigned int old = atomicOr(mask + (cell >> 1), m);
+            if (!(old & m)) {
+                const unsigned long long slot = wave_reserve(ncand);
+                if ((int64_t)slot < cand_cap) {
+                    Cand cd; cd.tpos = tp1; cd.chunk_bit = ((uint32_t)c << 4) | (uint32_t)bit;
+                    cands[slot] = cd;
+                }
             }
-            if (ok) {
-                const int bit = char2allele(op.ref) * 4 + char2allele(op.alt);
-                int64_t hi = upper_bound(C.s_start, (int64_t)0, C.n, tp1);  // chunks with start <= tpos
-                for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] >= tp1; j--) {
-                    const int c = C.s_idx[j];
-                    const int32_t cs_ = C.start[c], ce_ = C.end[c];
-                    if (ce_ < tp1) continue;
-                    if (!(ts < ce_ && te > cs_)) continue;  // not fetched by this chunk
-                    if (phase) {
-                        uint8_t h = H.hap[C.pairoff[c] + (r - C.rlo[c])];
-                        if (h == HAP_NONE) continue;        // caller.py:306-309
-                    }
-                    uint16_t* cell = mask + C.maskoff[c] + (tp1 - cs_);
-                    // 16-bit atomic OR through the containing aligned 32-bit word
-                    uintptr_t addr = (uintptr_t)cell;
-                    unsigned int* word = (unsigned int*)(addr & ~(uintptr_t)3);
-                    const unsigned int sh = (addr & 2) ? 16u : 0u;
-                    const unsigned int m = (1u << bit) << sh;
-                    unsigned int old = atomicOr(word, m);
-                    if (!(old & m)) atomicAdd(ncand, 1ULL);
+        };
+        if (!overflow) {
+#pragma unroll
+            for (int k = 0; k < EMIT_MAXC; k++)
+                if (cc[k] >= 0 && cst[k] <= tp1 && tp1 <= cen[k]) propose(cc[k], cst[k]);
+        } else {
+            // a read that lies in more chunks than fit the registers: walk the table again
+            for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts; j--) {
+                const int c = C.s_idx[j];
+                const int32_t cs_ = C.start[c], ce_ = C.end[c];
+                if (ce_ <= ts || !(cs_ <= tp1 && tp1 <= ce_)) continue;
+                if (phase && H.hap[C.pairoff[c] + (r - C.rlo[c])] == HAP_NONE) continue;
+                propose(c, cs_);
+            }
+        }
+    }
+}
+
+// sort key of a candidate == sort key of its record: (tpos, chunk, ref, alt) with the
+// alleles in ASCII order (natsorted order of the reference's tuples, caller.py:622)
+__global__ void __launch_bounds__(256) k_cand_keys(const Cand* cands, int64_t n, uint64_t* keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Cand c = cands[i];
+    const int bit = (int)(c.chunk_bit & 15u);
+    keys[i] = ((uint64_t)(uint32_t)c.tpos << 28) | ((uint64_t)(c.chunk_bit >> 4) << 4) |
+              ((uint64_t)asc_rank(bit >> 2) << 2) | (uint64_t)asc_rank(bit & 3);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_window_index: per block of 256 reference positions, the range of reads that can
+// cover a position of the block (reads are coordinate sorted).
+__global__ void __launch_bounds__(256) k_window_index(Reads R, int64_t nblk, int32_t* winlo, int32_t* winhi) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const int32_t p0 = (int32_t)(b << WIN_SHIFT), p1 = (int32_t)((b + 1) << WIN_SHIFT);
+    const int64_t hi = lower_bound(R.tstart, (int64_t)0, R.n, p1);           // reads with tstart < p1
+    const int64_t lo = lower_bound(R.prefmax_tend, (int64_t)0, hi, p0);      // running max of tend >= p0
+    winlo[b] = (int32_t)lo;
+    winhi[b] = (int32_t)hi;
+}
+
+// ---------------------------------------------------------------------------------------
+// The column store: for every candidate (sorted), one 16-bit slot per read of its
+// window [lo, lo + n), in fetch order:
+//   bits 0-2 cell (0-3 allele A T G C, 4 base outside ATGC, 5 deletion, 7 not in the pile)
+//   bit 3    an insertion precedes the position
+//   bits 4-5 haplotype of the read for the vote (HAP_0 / HAP_1 / HAP_NONE), only set when
+//            the read also covers rpos + 1 (caller.py:558)
+//   bits 8-15 base quality
+// k_gather_columns fills it (lanes = reads), k_eval_columns consumes it (thread = column).
+
+constexpr int EG = 8;  // candidates per gather wave
+
+__global__ void __launch_bounds__(256) k_cand_windows(const Cand* cands, int64_t n, const int32_t* winlo,
+                                                      const int32_t* winhi, int32_t* lo, uint32_t* cnt) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t rpos = cands[j].tpos - 1;
+    int32_t a = 0, b = 0;
+    if (rpos >= 0) { a = winlo[rpos >> WIN_SHIFT]; b = winhi[rpos >> WIN_SHIFT]; }
+    lo[j] = a;
+    cnt[j] = (uint32_t)(b - a);
+}
+
+struct GatherArgs {
+    Reads R;
+    Derived D;
+    Chunks C;
+    Phase H;
+    const Cand* cands;      // sorted by record key
+    int64_t ncand;
+    const int32_t* win_lo;  // per candidate
+    const uint32_t* win_n;
+    const uint32_t* win_off;
+    uint16_t* colstore;
+};
+
+// where does a read (first eight segments in registers, the rest in memory) put
+// reference position rpos?  o = query offset of the base, -1 deletion, -2 not covered
+struct SegHit { int64_t o; bool ins; };
+
+__device__ __forceinline__ SegHit locate(const Seg* first8, const Seg* segs, int ns, int32_t rpos) {
+    SegHit h; h.o = -2; h.ins = false;
+    bool done = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < ns && !done) {
+            const Seg sg = first8[k];
+            if (sg.t0 > rpos) done = true;
+            else {
+                if (rpos == sg.t0 && (sg.flags & SEG_INS)) h.ins = true;
+                if (rpos < sg.t0 + sg.len) { done = true; h.o = (sg.flags & SEG_DEL) ? -1 : (int64_t)sg.q0 + (rpos - sg.t0); }
+            }
+        }
+    }
+    for (int k = 8; k < ns && !done; k++) {
+        const Seg sg = segs[k];
+        if (sg.t0 > rpos) break;
+        if (rpos == sg.t0 && (sg.flags & SEG_INS)) h.ins = true;
+        if (rpos < sg.t0 + sg.len) { done = true; h.o = (sg.flags & SEG_DEL) ? -1 : (int64_t)sg.q0 + (rpos - sg.t0); }
+    }
+    return h;
+}
+
+template <bool PHASE>
+__global__ void __launch_bounds__(256) k_gather_columns(GatherArgs A) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const Reads& R = A.R;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (tid >> 6);
+    const int64_t j0 = g * EG;
+    if (j0 >= A.ncand) return;
+    const int ng = (int)min((int64_t)EG, A.ncand - j0);
+    // the group's candidates, one per lane; wave-uniform copies via readlane
+    Cand mine; mine.tpos = 0; mine.chunk_bit = 0;
+    int32_t my_cs = 0, my_ce = 0, my_lo = 0x7fffffff, my_n = 0;
+    uint32_t my_off = 0;
+    if (lane < ng) {
+        mine = A.cands[j0 + lane];
+        my_cs = A.C.start[mine.chunk_bit >> 4];
+        my_ce = A.C.end[mine.chunk_bit >> 4];
+        my_lo = A.win_lo[j0 + lane];
+        my_n = (int32_t)A.win_n[j0 + lane];
+        my_off = A.win_off[j0 + lane];
+    }
+    int32_t krpos[EG], kcs[EG], kce[EG], klo[EG], kn[EG];
+    uint32_t koff[EG], kch[EG];
+    int32_t glo = 0x7fffffff, ghi = 0;
+#pragma unroll
+    for (int k = 0; k < EG; k++) {
+        krpos[k] = __builtin_amdgcn_readlane(mine.tpos, k) - 1;
+        kch[k] = (uint32_t)__builtin_amdgcn_readlane((int)mine.chunk_bit, k) >> 4;
+        kcs[k] = __builtin_amdgcn_readlane(my_cs, k);
+        kce[k] = __builtin_amdgcn_readlane(my_ce, k);
+        klo[k] = __builtin_amdgcn_readlane(my_lo, k);
+        kn[k] = __builtin_amdgcn_readlane(my_n, k);
+        koff[k] = (uint32_t)__builtin_amdgcn_readlane((int)my_off, k);
+        if (k < ng && kn[k] > 0) { glo = min(glo, klo[k]); ghi = max(ghi, klo[k] + kn[k]); }
+    }
+    for (int32_t base = glo; base < ghi; base += 64) {
+        // ---- rows: one read per lane, metadata + first eight segments in registers
+        const int32_t r = base + lane;
+        ReadMeta M; M.tstart = 0; M.tend = -1; M.nseg = 0; M.flags = RF_SECONDARY; M.segbase = 0; M.qoff = 0;
+        if (r < ghi) M = A.D.meta[r];
+        const bool rowok = !(M.flags & RF_SECONDARY) && M.nseg > 0;
+        const Seg* segs = A.D.segs + M.segbase;
+        Seg first[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            first[k].t0 = 0x7fffffff; first[k].q0 = 0; first[k].len = 0; first[k].flags = 0;
+            if (rowok) first[k] = segs[min(k, M.nseg - 1)];
+        }
+        // ---- the base / quality byte of every column, all loads in flight together
+        uint32_t gq[EG], gsb[EG], gst[EG];
+#pragma unroll
+        for (int k = 0; k < EG; k++) {
+            gq[k] = 0; gsb[k] = 0; gst[k] = CELL_EMPTY | (HAP_NONE << 4);
+            const int32_t rpos = krpos[k];
+            // the read is in the pile of the column's chunk (fetch rule, caller.py:299) and can touch rpos
+            if (k < ng && rowok && M.tstart <= rpos && M.tend >= rpos && M.tstart < kce[k] && M.tend > kcs[k]) {
+                const SegHit h = locate(first, segs, M.nseg, rpos);
+                if (h.ins) gst[k] |= CELL_INS;
+                if (h.o == -1) gst[k] = (gst[k] & ~7u) | CELL_DEL;
+                else if (h.o >= 0) {
+                    const int64_t o = M.qoff + h.o;
+                    gst[k] = (gst[k] & ~7u) | 6u | ((o & 1) ? 0x100u : 0u);   // 6 = base pending
+                    gq[k] = R.bq[o];
+                    gsb[k] = R.seq[o >> 1];
+                    if (PHASE && M.tend > rpos + 1)
+                        gst[k] = (gst[k] & ~0x30u) | ((uint32_t)A.H.hap[A.C.pairoff[kch[k]] + ((int64_t)r - A.C.rlo[kch[k]])] << 4);
                 }
             }
         }
-        t += 1; q += 1;
+        // ---- publish the slots
+#pragma unroll
+        for (int k = 0; k < EG; k++) {
+            if (k < ng && r >= klo[k] && r < klo[k] + kn[k]) {
+                uint32_t st = gst[k] & 0x3fu;
+                if ((st & 7u) == 6u) {
+                    const int cell = nib2allele((int)((gst[k] & 0x100u) ? (gsb[k] & 15u) : (gsb[k] >> 4)));
+                    st = (st & ~7u) | (uint32_t)cell;
+                    if (cell >= 4) st |= (HAP_NONE << 4);
+                }
+                A.colstore[(int64_t)koff[k] + (r - klo[k])] = (uint16_t)(st | (gq[k] << 8));
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// Candidate evaluation on one pile column (thread-level).
-
-struct Column {
-    uint32_t cnt[6];
-    uint32_t bqs[4];
-    uint32_t maxbq[4];
-    double S[3][4];          // per allele: sum of log10 terms for hom / het / err (gtlib.py:84-93)
-    unsigned long long h0, h1;  // 16-bit packed per-allele counts of rows with hap 0 / 1 that also cover rpos + 1
-};
+// k_eval_columns: one THREAD per candidate column: walks the column's slots in fetch
+// order -- allele counts, BQ sums (caller.py:44-72, bamlib.py:181-219), the ordered
+// likelihood sums of gtlib.py:72-96 -- then genotypes and filters (caller.py:324-621).
 
 struct SiteSets {
     const uint64_t* pon; int64_t npon;
     const uint64_t* com; int64_t ncom;
+    const uint32_t* posbits;  // bit tpos set when either set holds a key at that position
+    int64_t nposbits;         // number of valid bits
 };
 
 __device__ __forceinline__ bool key_in(const uint64_t* a, int64_t n, uint64_t x) {
@@ -447,9 +736,10 @@ __device__ __forceinline__ bool key_in(const uint64_t* a, int64_t n, uint64_t x)
     return k < n && a[k] == x;
 }
 
-// genotype list of gtlib.py:9 in himut allele indices (A0 T1 G2 C3)
-__device__ __constant__ const uint8_t GT_B1[10] = {0, 1, 3, 2, 1, 3, 2, 3, 2, 2};
-__device__ __constant__ const uint8_t GT_B2[10] = {0, 0, 0, 0, 1, 1, 1, 3, 3, 2};
+// genotype list of gtlib.py:9 in himut allele indices (A0 T1 G2 C3):
+// AA TA CA GA TT CT GT CC GC GG
+#define HIMUT_GT_B1(g) ((0x2232312310ULL >> (4 * (g))) & 15)
+#define HIMUT_GT_B2(g) ((0x2331110000ULL >> (4 * (g))) & 15)
 
 __device__ __forceinline__ int gt_state_of(int b1, int b2, int ref) {  // gtlib.py:23-38
     if (b1 == b2 && b2 == ref) return 0;
@@ -458,108 +748,191 @@ __device__ __forceinline__ int gt_state_of(int b1, int b2, int ref) {  // gtlib.
     return 3;
 }
 
-__device__ void eval_candidate(const Column& col, int ref, int alt, int32_t tpos, int32_t chunk, int32_t cstart,
-                               const double* prior, const Params& P, const SiteSets& S, himut_record* out,
-                               unsigned long long* nrec, int64_t cap) {
-    // ten PLs, gtlib.py:72-110
+struct EvalArgs {
+    Params P;
+    SiteSets S;
+    const GtLut* lut;
+    const Cand* cands;       // sorted by record key
+    int64_t ncand;
+    const int32_t* cstart;   // chunk starts (phase set id of a phased PASS, caller.py:292,584)
+    const uint32_t* win_n;
+    const uint32_t* win_off;
+    const uint16_t* colstore;
+    himut_record* recs;      // record j belongs to candidate j
+    int* err;
+};
+
+template <bool PHASE>
+__global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
+    __shared__ double s_lut[3 * 256];
+    __shared__ double s_prior[4];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = A.lut->t[i >> 8][i & 255];
+    if (tid < 4) s_prior[tid] = A.lut->prior[tid];
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + tid;
+    if (j >= A.ncand) return;
+    const Cand cd = A.cands[j];
+    const int32_t tpos = cd.tpos;
+    const int chunk = (int)(cd.chunk_bit >> 4);
+    const int ref = (int)((cd.chunk_bit >> 2) & 3), alt = (int)(cd.chunk_bit & 3);
+    const uint32_t n = A.win_n[j];
+    const uint16_t* col = A.colstore + A.win_off[j];
+    const int min_bq = A.P.p.min_bq;
+
+    uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t bqs[4] = {0, 0, 0, 0};
+    double S[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
+    uint32_t ref_count = 0, alt_count = 0, alt_hi = 0, h0_ref = 0, h1_ref = 0, som0 = 0, som1 = 0;
+    int bad = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t v = col[i];
+        const uint32_t cell = v & 7u;
+        if (v & CELL_INS) cnt[4]++;
+        if (cell < 4) {
+            const uint32_t q = v >> 8;
+            if (q == 0) bad |= 1 << HIMUT_ERR_BQ0;                     // gtlib.py:64
+            const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if ((int)cell == b) {
+                    cnt[b]++; bqs[b] += q;
+                    S[0][b] = S[0][b] + vh;                            // sums in fetch order (gtlib.py:84-93)
+                    S[1][b] = S[1][b] + vt;
+                    S[2][b] = S[2][b] + ve;
+                }
+            }
+            if ((int)cell == ref) ref_count++;
+            if ((int)cell == alt) { alt_count++; if ((int)q >= min_bq) alt_hi++; }   // caller.py:160-171
+            if (PHASE) {
+                const uint32_t hp = (v >> 4) & 3u;
+                if ((int)cell == ref) { if (hp == HAP_0) h0_ref++; else if (hp == HAP_1) h1_ref++; }   // caller.py:562-564
+                if ((int)cell == alt) { if (hp == HAP_0) som0 = 1; else if (hp == HAP_1) som1 = 1; }   // caller.py:565-569
+            }
+        } else if (cell == CELL_DEL) cnt[5]++;
+        else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;       // caller.py:57
+    }
+
+    // ten PLs, gtlib.py:72-110; np.argsort with the scalar insertion sort: ties -> lower index (gtlib.py:113-119)
     double best = 0.0, second = 0.0;
-    int ibest = -1;
-    double pl[10];
+    int ibest = 0;
 #pragma unroll
     for (int g = 0; g < 10; g++) {
-        const int b1 = GT_B1[g], b2 = GT_B2[g];
+        const int b1 = (int)HIMUT_GT_B1(g), b2 = (int)HIMUT_GT_B2(g);
         double acc = 0.0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             double term;
-            if (b1 == b2 && b == b1) term = col.S[0][b];
-            else if (b1 != b2 && (b == b1 || b == b2)) term = col.S[1][b];
-            else term = col.S[2][b];
+            if (b1 == b2 && b == b1) term = S[0][b];
+            else if (b1 != b2 && (b == b1 || b == b2)) term = S[1][b];
+            else term = S[2][b];
             acc = acc + term;
         }
-        acc = acc + prior[gt_state_of(b1, b2, ref)];
-        pl[g] = -10.0 * acc;
-    }
-    // np.argsort with the scalar insertion sort: ties -> lower index (gtlib.py:113-119)
-#pragma unroll
-    for (int g = 0; g < 10; g++)
-        if (ibest < 0 || pl[g] < best) { best = pl[g]; ibest = g; }
-    bool have2 = false;
-#pragma unroll
-    for (int g = 0; g < 10; g++) {
-        if (g == ibest) continue;
-        if (!have2 || pl[g] < second) { second = pl[g]; have2 = true; }
+        acc = acc + s_prior[gt_state_of(b1, b2, ref)];
+        const double pl = -10.0 * acc;
+        if (g == 0) { best = pl; ibest = 0; }
+        else if (pl < best) { second = best; best = pl; ibest = g; }
+        else if (g == 1 || pl < second) second = pl;
     }
     const double gqf = second - best;
     const int gq = gqf < 99.0 ? (int)gqf : 99;
-    int g0 = GT_B1[ibest], g1 = GT_B2[ibest];
+    int g0 = (int)HIMUT_GT_B1(ibest), g1 = (int)HIMUT_GT_B2(ibest);
     const int state = gt_state_of(g0, g1, ref);
     if (g0 != ref && ((g0 == ref) + (g1 == ref)) == 1) { int tmp = g0; g0 = g1; g1 = tmp; }  // gtlib.py:133-134
 
-    const uint32_t* c = col.cnt;
-    const uint32_t ref_count = c[ref], alt_count = c[alt];
-    const uint32_t depth = c[0] + c[1] + c[2] + c[3] + c[5];  // bamlib.py:213-219
+    const uint32_t depth = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[5];  // bamlib.py:213-219
     bool germ;  // caller.py:111-147
     if (state == 1) germ = (g0 == ref && g1 == alt);
-    else if (state == 2) germ = ((c[0] + c[1] + c[2] + c[3]) == (c[g0] + c[g1])) && (alt == g0 || alt == g1);
-    else if (state == 3) germ = (ref_count == 0) && (g0 == alt && g1 == alt);
+    else if (state == 2) {
+        uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) { if (g0 == b) c0 = cnt[b]; if (g1 == b) c1 = cnt[b]; }
+        germ = ((cnt[0] + cnt[1] + cnt[2] + cnt[3]) == (c0 + c1)) && (alt == g0 || alt == g1);
+    } else if (state == 3) germ = (ref_count == 0) && (g0 == alt && g1 == alt);
     else germ = (alt == g0);
 
     int status = 255;
     int32_t ps = -1;
-    uint8_t flags = 0;
+    uint32_t flags = 0;
     if (germ) flags = REC_GERM;
     else if (state == 1) status = HIMUT_ST_HET;
     else if (state == 2) status = HIMUT_ST_HETALT;
     else if (state == 3) status = HIMUT_ST_HOMALT;
-    else if (c[5] != 0 || c[4] != 0) status = HIMUT_ST_INDEL;
+    else if (cnt[5] != 0 || cnt[4] != 0) status = HIMUT_ST_INDEL;
     else {
         const uint64_t key = ((uint64_t)(uint32_t)tpos << 4) | ((uint64_t)ref << 2) | (uint64_t)alt;
-        if (gq < P.p.min_gq) status = HIMUT_ST_LOWGQ;
-        else if ((int)col.maxbq[alt] < P.p.min_bq) status = HIMUT_ST_LOWBQ;   // caller.py:160-171
-        else if (key_in(S.pon, S.npon, key)) status = HIMUT_ST_PON;
-        else if (key_in(S.com, S.ncom, key)) status = HIMUT_ST_COMSNP;
-        else if (!((int64_t)ref_count >= P.p.min_ref_count && (int64_t)alt_count >= P.p.min_alt_count)) status = HIMUT_ST_LOWDEPTH;
-        else if ((int64_t)depth > P.p.md_threshold) status = HIMUT_ST_HIGHDEPTH;
-        else if (P.p.phase) {  // caller.py:552-603 (unique query names: the voters are the pile's own rows)
-            const int64_t h0 = (int64_t)((col.h0 >> (16 * ref)) & 0xffff), h1 = (int64_t)((col.h1 >> (16 * ref)) & 0xffff);
-            const int som = (((col.h0 >> (16 * alt)) & 0xffff) ? 1 : 0) + (((col.h1 >> (16 * alt)) & 0xffff) ? 1 : 0);
-            if (h0 >= P.p.min_hap_count && h1 >= P.p.min_hap_count && som == 1) { status = HIMUT_ST_PASS; ps = cstart; }
-            else status = HIMUT_ST_UNPHASED;
-        } else status = HIMUT_ST_PASS;
+        if (gq < A.P.p.min_gq) status = HIMUT_ST_LOWGQ;
+        else if (alt_hi == 0) status = HIMUT_ST_LOWBQ;
+        else {
+            const SiteSets& St = A.S;
+            const bool site_maybe = (int64_t)tpos < St.nposbits && ((St.posbits[tpos >> 5] >> (tpos & 31)) & 1u);
+            if (site_maybe && key_in(St.pon, St.npon, key)) status = HIMUT_ST_PON;
+            else if (site_maybe && key_in(St.com, St.ncom, key)) status = HIMUT_ST_COMSNP;
+            else if (!((int64_t)ref_count >= A.P.p.min_ref_count && (int64_t)alt_count >= A.P.p.min_alt_count)) status = HIMUT_ST_LOWDEPTH;
+            else if ((int64_t)depth > A.P.p.md_threshold) status = HIMUT_ST_HIGHDEPTH;
+            else if (PHASE) {  // caller.py:552-603 (unique query names: the voters are the pile's own rows)
+                if ((int64_t)h0_ref >= A.P.p.min_hap_count && (int64_t)h1_ref >= A.P.p.min_hap_count && (som0 + som1) == 1) {
+                    status = HIMUT_ST_PASS; ps = A.cstart[chunk];
+                } else status = HIMUT_ST_UNPHASED;
+            } else status = HIMUT_ST_PASS;
+        }
     }
-    const unsigned long long idx = atomicAdd(nrec, 1ULL);
-    if ((int64_t)idx >= cap) return;
-    himut_record rec;
-    rec.tpos = tpos; rec.chunk = chunk; rec.phase_set = ps; rec.gq = gq;
-    rec.ref = (uint8_t)allele2char(ref); rec.alt = (uint8_t)allele2char(alt);
-    rec.gt0 = (uint8_t)allele2char(g0); rec.gt1 = (uint8_t)allele2char(g1);
-    rec.status = (uint8_t)status; rec.gt_state = (uint8_t)state; rec.flags = flags; rec.pad = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) rec.counts[k] = c[k];
-#pragma unroll
-    for (int k = 0; k < 4; k++) rec.bqsum[k] = col.bqs[k];
-    const uint4* src = reinterpret_cast<const uint4*>(&rec);
-    uint4* dst = reinterpret_cast<uint4*>(out + idx);
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    uint4 w0, w1, w2, w3;
+    w0.x = (uint32_t)tpos; w0.y = (uint32_t)chunk; w0.z = (uint32_t)ps; w0.w = (uint32_t)gq;
+    w1.x = (uint32_t)allele2char(ref) | ((uint32_t)allele2char(alt) << 8) | ((uint32_t)allele2char(g0) << 16) | ((uint32_t)allele2char(g1) << 24);
+    w1.y = (uint32_t)(status & 255) | ((uint32_t)state << 8) | (flags << 16);
+    w1.z = cnt[0]; w1.w = cnt[1];
+    w2.x = cnt[2]; w2.y = cnt[3]; w2.z = cnt[4]; w2.w = cnt[5];
+    w3.x = bqs[0]; w3.y = bqs[1]; w3.z = bqs[2]; w3.w = bqs[3];
+    uint4* dst = reinterpret_cast<uint4*>(A.recs + j);
+    dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
+    if (bad) atomicOr(A.err, bad);
 }
 
-struct SweepArgs {
+// ---------------------------------------------------------------------------------------
+// k_pile_dense: counts + BQ sums at every position of the given chunks, through
+// LDS-staged base / BQ tiles (one workgroup per PD_TP positions).
+
+struct TileInfo {
+    int32_t chunk;
+    int32_t p0;     // first rpos of the tile
+    int32_t npos;   // positions in the tile
+    int32_t nwin;   // reads in the candidate window [lo, lo + nwin)
+    int64_t lo;
+    int64_t outbase;  // index of the tile's first position in the output arrays
+};
+
+template <int TP>
+__global__ void __launch_bounds__(256) k_tile_index(Reads R, Chunks C, const int64_t* tileoff, int64_t n_tiles, TileInfo* out) {
+    const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    const int64_t c = upper_bound(tileoff, (int64_t)0, C.n + 1, tile) - 1;
+    const int32_t cs_ = C.start[c], ce_ = C.end[c];
+    const int64_t local = (tile - tileoff[c]) * TP;
+    TileInfo t;
+    t.chunk = (int32_t)c;
+    t.p0 = (int32_t)(cs_ - 1 + local);
+    const int32_t p1 = (int32_t)min((int64_t)t.p0 + TP, (int64_t)ce_);  // last rpos of the chunk is end - 1
+    t.npos = p1 - t.p0;
+    const int64_t rlo = C.rlo[c], rhi = C.rhi[c];
+    const int64_t hi = lower_bound(R.tstart, rlo, rhi, p1);                // reads with tstart < p1
+    const int64_t lo = lower_bound(R.prefmax_tend, rlo, hi, t.p0);         // running max of tend >= p0
+    t.lo = lo;
+    t.nwin = (int32_t)(hi - lo);
+    t.outbase = C.maskoff[c] + local;
+    out[tile] = t;
+}
+
+struct DenseArgs {
     Reads R;
     Derived D;
     Chunks C;
-    Phase H;
-    Params P;
-    SiteSets S;
-    const GtLut* lut;
-    const uint16_t* mask;
-    himut_record* recs;
-    unsigned long long* nrec;
-    int64_t cap;
+    const TileInfo* tiles;
     int64_t n_tiles;
-    uint32_t* dense_counts;  // DENSE only: [position][6]
-    uint32_t* dense_bqsum;   // DENSE only: [position][4]
-    unsigned long long* row_bases;
+    uint32_t* counts;  // [position][6]
+    uint32_t* bqsum;   // [position][4]
     int* err;
 };
 
@@ -572,54 +945,64 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
     return base + (b >> 3);
 }
 
-template <bool DENSE>
-__global__ void __launch_bounds__(TP) k_pileup_sweep(SweepArgs A) {
-    __shared__ __align__(16) uint8_t s_cell[RB * TP];
+// One piece = the part of one gapless segment (or deletion) of a read that falls
+// into the tile.  x0/x1 are tile-local positions, qa the query offset of x0.
+struct Piece {
+    int32_t x0, x1;
+    int32_t qa;
+    uint32_t flags;  // SEG_DEL, SEG_INS (insertion in front of position x0)
+};
+constexpr int MAXP = 4;
+
+// 16 BAM nibbles (base j at bits 4j..4j+3) -> 16 pile cells (himut allele index, 4 = not ATGC)
+__device__ __forceinline__ uint64_t nib16_to_cells(uint64_t x) {
+    const uint64_t m = 0x1111111111111111ULL;
+    const uint64_t n0 = x & m, n1 = (x >> 1) & m, n2 = (x >> 2) & m, n3 = (x >> 3) & m;  // A C G T one-hot bits
+    const uint64_t sum = n0 + n1 + n2 + n3;
+    const uint64_t inv = ((sum >> 1) | (sum >> 2) | ~sum) & m;     // not exactly one bit set
+    uint64_t code = (n3 | n1) | ((n2 | n1) << 1);                  // T,C -> bit0 ; G,C -> bit1
+    code = (code & ~(inv * 3)) | (inv << 2);
+    return code;
+}
+
+template <int TP, int RB, int NT>
+__global__ void __launch_bounds__(NT) k_pile_dense(DenseArgs A) {
+    constexpr int PPL = TP / 64;        // positions per lane when a wave stages one row
+    constexpr int NW = NT / 64;
+    constexpr int DPT = TP / NT;        // positions per thread in the column pass
+    static_assert(PPL == 8, "tile width must be 512");
     __shared__ __align__(16) uint8_t s_bq[RB * TP];
-    __shared__ double s_lut[3 * 256];
-    __shared__ int s_rows[TP];
-    __shared__ int s_rowtend[RB];
-    __shared__ uint8_t s_rowhap[RB];
-    __shared__ int s_wcnt[TP / 64];
+    __shared__ __align__(16) uint8_t s_cell[RB * TP / 2];
+    __shared__ __align__(16) Piece s_piece[RB * MAXP];
+    __shared__ int64_t s_rowqo[RB];
+    __shared__ int s_rowread[RB];
+    __shared__ uint8_t s_rownp[RB];
+    __shared__ uint16_t s_rows[NT];
+    __shared__ int s_wcnt[NW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Reads& R = A.R;
     const Derived& D = A.D;
-    const Chunks& C = A.C;
-    const int64_t tile = xcd_remap(blockIdx.x, A.n_tiles);
-    const int64_t c = upper_bound(C.tileoff, (int64_t)0, C.n + 1, tile) - 1;
-    const int32_t cs_ = C.start[c], ce_ = C.end[c];
-    const int64_t local = (tile - C.tileoff[c]) * TP;
-    const int32_t p0 = (int32_t)(cs_ - 1 + local);
-    const int32_t p1 = (int32_t)min((int64_t)p0 + TP, (int64_t)ce_);  // rpos in [p0, p1); last rpos of the chunk is end - 1
-    const int32_t p = p0 + tid;
-    const bool active = p < p1;
-    const bool phase = A.P.p.phase != 0;
-    uint32_t mask = 0;
-    if (!DENSE && active) mask = A.mask[C.maskoff[c] + local + tid];
-    const bool need = mask != 0;
+    const TileInfo T = A.tiles[xcd_remap(blockIdx.x, A.n_tiles)];
+    const int32_t p0 = T.p0, p1 = T.p0 + T.npos;
+    const int32_t cs_ = A.C.start[T.chunk], ce_ = A.C.end[T.chunk];
 
-    for (int i = tid; i < 3 * 256; i += TP) s_lut[i] = A.lut->t[i >> 8][i & 255];
-
-    Column col;
+    uint32_t dcnt[DPT][6];
+    uint32_t dbq[DPT][4];
 #pragma unroll
-    for (int k = 0; k < 6; k++) col.cnt[k] = 0;
+    for (int d = 0; d < DPT; d++) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { col.bqs[k] = 0; col.maxbq[k] = 0; col.S[0][k] = 0.0; col.S[1][k] = 0.0; col.S[2][k] = 0.0; }
-    col.h0 = 0; col.h1 = 0;
+        for (int k = 0; k < 6; k++) dcnt[d][k] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) dbq[d][k] = 0;
+    }
     int bad = 0;
-    unsigned long long staged = 0;
 
-    // reads that can overlap the tile: tstart < p1 and (running max of) tend >= p0
-    const int64_t rlo = C.rlo[c], rhi = C.rhi[c];
-    const int64_t hi = lower_bound(R.tstart, rlo, rhi, p1);
-    const int64_t lo = lower_bound(R.prefmax_tend, rlo, hi, p0);
-
-    for (int64_t base = lo; base < hi; base += TP) {
-        // ordered compaction of the rows of this tile (fetch rule of the chunk: caller.py:299)
+    for (int64_t base = T.lo; base < T.lo + T.nwin; base += NT) {
+        // ---- rows of the tile, in fetch order (fetch rule of the chunk: caller.py:299)
         const int64_t r = base + tid;
         bool ok = false;
-        if (r < hi) {
+        if (r < T.lo + T.nwin) {
             const int32_t te = R.tend[r];
             ok = !(D.rflag[r] & RF_SECONDARY) && te >= p0 && te > cs_ && R.tstart[r] < ce_;
         }
@@ -628,133 +1011,152 @@ __global__ void __launch_bounds__(TP) k_pileup_sweep(SweepArgs A) {
         __syncthreads();
         int woff = 0, nrows = 0;
 #pragma unroll
-        for (int k = 0; k < TP / 64; k++) { if (k < wave) woff += s_wcnt[k]; nrows += s_wcnt[k]; }
-        if (ok) s_rows[woff + __popcll(bal & ((1ULL << lane) - 1ULL))] = (int)(r - base);
+        for (int k = 0; k < NW; k++) { if (k < wave) woff += s_wcnt[k]; nrows += s_wcnt[k]; }
+        if (ok) s_rows[woff + __popcll(bal & ((1ULL << lane) - 1ULL))] = (uint16_t)tid;
         __syncthreads();
 
         for (int b0 = 0; b0 < nrows; b0 += RB) {
             const int nb = min(RB, nrows - b0);
-            // ---- stage nb rows: each wave takes rows wave, wave+4, ...
-            for (int i = wave; i < nb; i += TP / 64) {
-                const int64_t rr = base + s_rows[b0 + i];
-                const Seg* segs = D.segs + seg_base(R, rr);
+            // ---- row setup: one thread per row turns the read's segments into tile pieces
+            if (tid < nb) {
+                const int64_t rr = base + s_rows[b0 + tid];
                 const int ns = D.nseg[rr];
-                const int64_t qo = R.qoff[rr];
-                if (lane == 0) {
-                    s_rowtend[i] = R.tend[rr];
-                    s_rowhap[i] = phase ? A.H.hap[C.pairoff[c] + (rr - rlo)] : HAP_NONE;
-                }
-                // segments of the read that touch [p0, p1)
-                int sfirst = ns, slast = -1;
-                for (int j0 = 0; j0 < ns; j0 += 64) {
-                    const int j = j0 + lane;
-                    bool hit = false;
-                    if (j < ns) {
-                        Seg sg = segs[j];
-                        int32_t eend = sg.t0 + ((sg.flags & SEG_INS) ? max(sg.len, 1) : sg.len);
-                        hit = sg.t0 < p1 && eend > p0;
+                const Seg* segs = D.segs + seg_base(R, rr);
+                s_rowqo[tid] = R.qoff[rr];
+                s_rowread[tid] = (int)(rr - T.lo);
+                int np = 0;
+                auto add_seg = [&](const Seg& sg) {
+                    const int32_t eend = sg.t0 + ((sg.flags & SEG_INS) ? max(sg.len, 1) : sg.len);
+                    if (sg.t0 < p1 && eend > p0) {
+                        if (np < MAXP) {
+                            Piece pc;
+                            pc.x0 = max(sg.t0, p0) - p0;
+                            pc.x1 = max(min(sg.t0 + sg.len, p1) - p0, pc.x0);
+                            pc.qa = sg.q0 + (p0 + pc.x0 - sg.t0);
+                            pc.flags = (sg.flags & SEG_DEL) | (((sg.flags & SEG_INS) && sg.t0 >= p0) ? SEG_INS : 0u);
+                            s_piece[tid * MAXP + np] = pc;
+                        }
+                        np++;
                     }
-                    const unsigned long long hb = __ballot(hit);
-                    if (hb) {
-                        if (sfirst == ns) sfirst = j0 + __ffsll((long long)hb) - 1;
-                        slast = j0 + 63 - __clzll((long long)hb);
-                    }
-                }
+                };
+                if (ns > 0) {
+                    // the first eight segments with independent loads (one memory latency), the rest in a loop
+                    Seg first[8];
 #pragma unroll
-                for (int k = 0; k < TP / 64; k++) {
-                    const int x = lane + 64 * k;
-                    const int32_t pp = p0 + x;
-                    uint8_t cell = CELL_EMPTY, bqv = 0;
-                    for (int j = sfirst; j <= slast; j++) {
+                    for (int j = 0; j < 8; j++) first[j] = segs[min(j, ns - 1)];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) if (j < ns) add_seg(first[j]);
+                    for (int j = 8; j < ns; j++) {
                         const Seg sg = segs[j];
-                        if (pp == sg.t0 && (sg.flags & SEG_INS)) cell |= CELL_INS;
-                        if (pp >= sg.t0 && pp < sg.t0 + sg.len) {
-                            if (sg.flags & SEG_DEL) cell = (cell & CELL_INS) | CELL_DEL;
-                            else {
-                                const int64_t o = qo + sg.q0 + (pp - sg.t0);
-                                cell = (cell & CELL_INS) | (uint8_t)nib2allele(nib_at(R.seq, o));
-                                bqv = R.bq[o];
+                        if (sg.t0 >= p1) break;
+                        add_seg(sg);
+                    }
+                }
+                s_rownp[tid] = (uint8_t)min(np, 255);
+            }
+            __syncthreads();
+            // ---- staging: one wave per row; every lane assembles its PPL positions in registers
+            for (int i = wave; i < nb; i += NW) {
+                const int gx = lane * PPL;
+                uint64_t cell = 0x7777777777777777ULL;  // CELL_EMPTY everywhere (low PPL nibbles used)
+                uint64_t bqw = 0;
+                const int np = s_rownp[i];
+                const int64_t qo = s_rowqo[i];
+                if (np <= MAXP) {
+                    for (int k = 0; k < np; k++) {
+                        const Piece pc = s_piece[i * MAXP + k];
+                        const int a = max(pc.x0, gx) - gx, b = min(pc.x1, gx + PPL) - gx;
+                        if ((pc.flags & SEG_INS) && pc.x0 >= gx && pc.x0 < gx + PPL) cell |= 8ULL << (4 * (pc.x0 - gx));
+                        const bool cov = a < b;
+                        const int aa = cov ? a : 0, bb = cov ? b : 0;
+                        const uint64_t nm = ((1ULL << (4 * bb)) - 1ULL) & ~((1ULL << (4 * aa)) - 1ULL);  // nibbles [a, b)
+                        if (pc.flags & SEG_DEL) {
+                            cell = (cell & ~(nm & 0x7777777777777777ULL)) | (nm & 0x5555555555555555ULL);
+                        } else {
+                            // loads are issued unconditionally (clamped address) so that they go out together
+                            const int64_t o = qo + pc.qa + (cov ? (gx + a - pc.x0) : 0);
+                            const uint8_t* sp = R.seq + (o >> 1);
+                            uint32_t w32;
+                            __builtin_memcpy(&w32, sp, 4);
+                            const uint32_t extra = sp[4];
+                            uint64_t l;
+                            __builtin_memcpy(&l, R.bq + o, 8);
+                            uint64_t w = w32;
+                            w = ((w & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((w >> 4) & 0x0f0f0f0f0f0f0f0fULL);
+                            if (o & 1) w = (w >> 4) | ((uint64_t)(extra >> 4) << 28);
+                            const uint64_t codes = nib16_to_cells(w) << (4 * aa);
+                            if (codes & nm & 0x4444444444444444ULL) bad |= 1 << HIMUT_ERR_BASE;  // caller.py:57
+                            cell = (cell & ~(nm & 0x7777777777777777ULL)) | (codes & nm);
+                            const uint64_t bm = ((bb >= 8) ? ~0ULL : ((1ULL << (8 * bb)) - 1ULL)) & ~((1ULL << (8 * aa)) - 1ULL);
+                            bqw |= (l << (8 * aa)) & bm;
+                        }
+                    }
+                } else {
+                    // rare: more than MAXP pieces in one tile -> position-by-position from the segment list
+                    const int64_t rr = T.lo + s_rowread[i];
+                    const Seg* segs = D.segs + seg_base(R, rr);
+                    const int ns = D.nseg[rr];
+                    for (int j = 0; j < PPL; j++) {
+                        const int32_t pp = p0 + gx + j;
+                        for (int q = 0; q < ns; q++) {
+                            const Seg sg = segs[q];
+                            if (sg.t0 > pp) break;
+                            if (pp == sg.t0 && (sg.flags & SEG_INS)) cell |= 8ULL << (4 * j);
+                            if (pp < sg.t0 + sg.len) {
+                                uint64_t code;
+                                if (sg.flags & SEG_DEL) code = CELL_DEL;
+                                else {
+                                    const int64_t o = qo + sg.q0 + (pp - sg.t0);
+                                    code = (uint64_t)nib2allele(nib_at(R.seq, o));
+                                    bqw |= (uint64_t)R.bq[o] << (8 * j);
+                                }
+                                cell = (cell & ~(7ULL << (4 * j))) | (code << (4 * j));
                             }
                         }
                     }
-                    s_cell[i * TP + x] = cell;
-                    s_bq[i * TP + x] = bqv;
                 }
+                *reinterpret_cast<uint32_t*>(&s_cell[i * (TP / 2) + lane * 4]) = (uint32_t)cell;
+                *reinterpret_cast<uint64_t*>(&s_bq[i * TP + lane * 8]) = bqw;
             }
             __syncthreads();
             // ---- column pass: thread = position, rows in fetch order
-            if (active) {
-                for (int i = 0; i < nb; i++) {
-                    const uint8_t cell = s_cell[i * TP + tid];
-                    if (cell == CELL_EMPTY) continue;
-                    if (cell & CELL_INS) col.cnt[4]++;
-                    const int a = cell & 7;
-                    if (a < 4) {
-                        const uint32_t q = s_bq[i * TP + tid];
-                        staged++;
-                        bool vote = false; uint8_t hp = HAP_NONE;
-                        if (phase && need) { vote = s_rowtend[i] > p + 1; hp = s_rowhap[i]; }
-                        double vh = 0.0, vt = 0.0, ve = 0.0;
-                        if (need) {
-                            if (q == 0) bad |= 1 << HIMUT_ERR_BQ0;
-                            vh = s_lut[q]; vt = s_lut[256 + q]; ve = s_lut[512 + q];
-                        }
 #pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            if (a == b) {
-                                col.cnt[b]++; col.bqs[b] += q; col.maxbq[b] = max(col.maxbq[b], q);
-                                if (need) {
-                                    col.S[0][b] = col.S[0][b] + vh;
-                                    col.S[1][b] = col.S[1][b] + vt;
-                                    col.S[2][b] = col.S[2][b] + ve;
-                                }
-                            }
-                        }
-                        if (vote) {
-                            if (hp == HAP_0) col.h0 += 1ULL << (16 * a);
-                            else if (hp == HAP_1) col.h1 += 1ULL << (16 * a);
-                        }
-                    } else if (a == CELL_DEL) col.cnt[5]++;
-                    else if (a == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;
+            for (int d = 0; d < DPT; d++) {
+                const int x = tid + d * NT;
+                if (x < T.npos) {
+                    for (int i = 0; i < nb; i++) {
+                        const uint32_t cb = (s_cell[i * (TP / 2) + (x >> 1)] >> (4 * (x & 1))) & 15;
+                        if (cb == CELL_EMPTY) continue;
+                        if (cb & CELL_INS) dcnt[d][4]++;
+                        const int a = cb & 7;
+                        if (a < 4) {
+                            const uint32_t q = s_bq[i * TP + x];
+#pragma unroll
+                            for (int b = 0; b < 4; b++) if (a == b) { dcnt[d][b]++; dbq[d][b] += q; }
+                        } else if (a == CELL_DEL) dcnt[d][5]++;
+                        else if (a == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;
+                    }
                 }
             }
             __syncthreads();
         }
     }
-
-    if (DENSE) {
-        if (active) {
-            const int64_t o = C.maskoff[c] + local + tid;
 #pragma unroll
-            for (int k = 0; k < 6; k++) A.dense_counts[o * 6 + k] = col.cnt[k];
+    for (int d = 0; d < DPT; d++) {
+        const int x = tid + d * NT;
+        if (x < T.npos) {
+            const int64_t o = T.outbase + x;
 #pragma unroll
-            for (int k = 0; k < 4; k++) A.dense_bqsum[o * 4 + k] = col.bqs[k];
-        }
-    } else if (need) {
-        const int32_t tpos = p + 1;
-        for (int bit = 0; bit < 16; bit++) {
-            if (!(mask & (1u << bit))) continue;
-            eval_candidate(col, bit >> 2, bit & 3, tpos, (int32_t)c, cs_, A.lut->prior, A.P, A.S, A.recs, A.nrec, A.cap);
+            for (int k = 0; k < 6; k++) A.counts[o * 6 + k] = dcnt[d][k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) A.bqsum[o * 4 + k] = dbq[d][k];
         }
     }
     if (bad) atomicOr(A.err, bad);
-    // pile cells this workgroup staged (for the roofline figure)
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) staged += __shfl_down(staged, d, 64);
-    if (lane == 0 && staged) atomicAdd(A.row_bases, staged);
 }
 
 // ---------------------------------------------------------------------------------------
 // finalisation
-
-__global__ void __launch_bounds__(256) k_record_keys(const himut_record* recs, int64_t n, uint64_t* keys, uint32_t* vals) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const himut_record& r = recs[i];
-    keys[i] = ((uint64_t)(uint32_t)r.tpos << 28) | ((uint64_t)(uint32_t)r.chunk << 4) |
-              ((uint64_t)asc_rank(char2allele(r.ref)) << 2) | (uint64_t)asc_rank(char2allele(r.alt));
-    vals[i] = (uint32_t)i;
-}
 
 // som_seen across chunks (caller.py:244,347; bamlib.py:77): a candidate whose
 // tpos was already added by an EARLIER chunk is never proposed again.
@@ -771,7 +1173,7 @@ __global__ void __launch_bounds__(256) k_resolve_seen(himut_record* recs, const 
         bool nongerm = false;
         int64_t k = j;
         while (k < n && (keys[k] >> 28) == tp && ((keys[k] >> 4) & 0xffffff) == ch) {
-            himut_record& rec = recs[vals[k]];
+            himut_record& rec = recs[vals ? vals[k] : (uint32_t)k];
             if (seen) rec.flags |= REC_SUPPRESSED;
             else if (!(rec.flags & REC_GERM)) nongerm = true;
             k++;
@@ -789,7 +1191,7 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        himut_record& rec = recs[vals[i]];
+        himut_record& rec = recs[vals ? vals[i] : (uint32_t)i];
         uint32_t e = 0;
         if (!(rec.flags & REC_SUPPRESSED)) {
             atomicAdd(&s_log[1], 1u);  // num_sbs
@@ -816,7 +1218,7 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
                     // set(): a HetAltSite tuple printed as ref / "a1,a2" is identical for every alt of the column
                     const uint64_t m = ~(uint64_t)3;
                     if ((keys[i - 1] & m) == (keys[i] & m)) {
-                        const himut_record& prev = recs[vals[i - 1]];
+                        const himut_record& prev = recs[vals ? vals[i - 1] : (uint32_t)(i - 1)];
                         if (prev.status == HIMUT_ST_HETALT && !(prev.flags & (REC_SUPPRESSED | REC_GERM))) { e = 0; rec.flags |= REC_DUP; }
                     }
                 }
@@ -832,7 +1234,7 @@ __global__ void __launch_bounds__(256) k_compact(const himut_record* recs, const
                                                  const uint32_t* pos, int64_t n, himut_record* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !emit[i]) return;
-    const uint4* src = reinterpret_cast<const uint4*>(recs + vals[i]);
+    const uint4* src = reinterpret_cast<const uint4*>(recs + (vals ? vals[i] : (uint32_t)i));
     uint4 a = src[0], b = src[1], c = src[2], d = src[3];
     b.y &= 0xff00ffffu;  // flags byte (offset 22) -> 0
     uint4* dst = reinterpret_cast<uint4*>(out + pos[i]);

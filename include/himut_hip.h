@@ -132,19 +132,20 @@ typedef struct himut_record {
  * context's stream, in milliseconds). */
 typedef struct himut_run_stats {
     double ms_total;
-    double ms_bqsum;            /* k_bqsum: whole-read BQ sums (qv filter) */
-    double ms_parse;            /* k_parse_cs: cs decode, read filters */
+    double ms_parse;            /* k_parse_cs: cs decode */
+    double ms_bqsum;            /* k_read_filters: whole-read BQ stream (qv), cs-vs-SEQ check, read filters */
     double ms_hap;              /* k_read_hap (phase only) */
-    double ms_emit;             /* k_emit_candidates */
-    double ms_sweep;            /* k_pileup_sweep: LDS-staged pile tiles + candidate columns */
-    double ms_finalize;         /* sort / cross-chunk som_seen / counters / compaction */
+    double ms_emit;             /* k_emit_candidates + k_window_index */
+    double ms_sweep;            /* candidate sort + k_cand_windows + k_gather_columns (pile columns -> column store) */
+    double ms_eval;             /* k_eval_columns: counts, ordered likelihood sums, genotype, filters */
+    double ms_finalize;         /* cross-chunk som_seen / counters / compaction */
     int64_t n_reads;
     int64_t read_bases;         /* sum of qlen */
     int64_t positions;          /* sum over chunks of (end - start + 1) */
     int64_t n_tiles;
     int64_t n_candidates;       /* evaluated candidates before the cross-chunk pass */
     int64_t n_records;
-    int64_t sweep_row_bases;    /* pile cells staged by k_pileup_sweep (rows x tile width actually covered) */
+    int64_t sweep_row_bases;    /* column-store slots gathered (candidate columns x reads in their windows) */
 } himut_run_stats;
 
 int himut_abi_version(void);

@@ -160,9 +160,12 @@ def test_error_codes_mirror_reference_failures(worker):
         return worker.call_contig(b, list(chunks))
 
     ok = dict(tstart=10, tend=210, seq=seq, bq=[93] * 200, cs=":200")
-    run([ok])
-    with pytest.raises(_ffi.HimutError) as e:   # query N inside a match: KeyError in the reference
-        run([dict(ok, seq="N" + seq[1:])])
+    cand = dict(tstart=10, tend=210, seq=seq[:100] + "T" + seq[101:], bq=[93] * 200, cs=":100*at:99")
+    run([ok, cand])
+    # query N inside a match: KeyError in the reference.  Detected where the N sits in an
+    # evaluated column (the reference dies wherever it sits in a fetched read).
+    with pytest.raises(_ffi.HimutError) as e:
+        run([dict(ok, seq=seq[:100] + "N" + seq[101:]), cand])
     assert e.value.code == 4
     with pytest.raises(_ffi.HimutError) as e:   # garbage in cs
         run([dict(ok, cs=":100~ac:100")])
