@@ -21,9 +21,24 @@ if ROOT not in sys.path:
 
 CHR20_LEN = 64_444_167
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_PER_READ_BASE = 1.5      # 0.5 B packed base + 1 B quality, each read once by k_pileup_sweep
-BYTES_PER_POSITION = 2.0       # candidate mask cell
-BYTES_PER_CANDIDATE = 64.0     # one record written
+# algorithmic HBM bytes per unit of work, per kernel (DESIGN.md "Kernels and their rooflines")
+STAGE_KERNEL = {"ms_parse": "k_parse_cs", "ms_bqsum": "k_read_filters", "ms_emit": "k_emit_candidates",
+                "ms_capture": "k_stream_capture", "ms_eval": "k_eval_columns"}
+
+
+def algorithmic_bytes(stage, st, cs_bytes):
+    rb, pos, cand, slots = st["read_bases"], st["positions"], st["n_candidates"], st["column_slots"]
+    if stage == "ms_bqsum":      # every quality byte once
+        return rb * 1.0
+    if stage == "ms_capture":    # every quality byte + every packed base once, one 2-byte slot per pile cell kept
+        return rb * 1.5 + slots * 2.0
+    if stage == "ms_parse":      # cs text in, ~16 B per cs operation out (segments + mismatch list)
+        return cs_bytes * 1.0 + cs_bytes / 4.0 * 16.0
+    if stage == "ms_emit":       # mismatch list in, mask word + candidate out per candidate
+        return cs_bytes / 4.0 * 8.0 + cand * 16.0
+    if stage == "ms_eval":       # column slots in, one 64-byte record out
+        return slots * 2.0 + cand * 64.0
+    return 0.0
 
 
 def parse():
@@ -145,15 +160,14 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    sweep_ms = []
     stage_ms = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
         st = ctx.stats()
-        sweep_ms.append(st["ms_sweep"])
-        for k in ("ms_total", "ms_parse", "ms_bqsum", "ms_hap", "ms_emit", "ms_sweep", "ms_eval", "ms_finalize"):
+        for k in ("ms_total", "ms_parse", "ms_bqsum", "ms_hap", "ms_emit", "ms_index", "ms_capture", "ms_eval",
+                  "ms_finalize"):
             stage_ms.setdefault(k, []).append(st[k])
     barrier()
     elapsed = time.perf_counter() - t0
@@ -173,17 +187,21 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         mbp_s = positions / 1e6 / (elapsed / a.steps)
-        sweep_avg_ms = float(np.mean(sweep_ms))
-        alg_bytes = (st["read_bases"] * BYTES_PER_READ_BASE + st["positions"] * BYTES_PER_POSITION +
-                     st["n_candidates"] * BYTES_PER_CANDIDATE)
-        achieved = alg_bytes / (sweep_avg_ms * 1e-3) / 1e9
+        avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+        dom = max(STAGE_KERNEL, key=lambda k: avg[k])           # the dominant kernel of the step
+        dom_ms = avg[dom]
+        cs_bytes = int(batch.cs.shape[0])
+        alg_bytes = algorithmic_bytes(dom, st, cs_bytes)
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        per_kernel = {STAGE_KERNEL[k]: {"ms": avg[k], "alg_GBps": algorithmic_bytes(k, st, cs_bytes) / (avg[k] * 1e-3) / 1e9}
+                      for k in STAGE_KERNEL}
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 t = json.load(open(tp))
                 if t.get("contig_len") == a.contig_len and t.get("depth") == a.depth:
-                    traffic = t.get("sweep_hbm_bytes_per_launch")
+                    traffic = t.get(STAGE_KERNEL[dom])
             except Exception:
                 traffic = None
         out = {
@@ -198,12 +216,11 @@ def main():
                        "parallelism": "contig-per-gpu x{} + RCCL gather".format(world)},
             "candidate_sites_per_sec": cand_sites / (elapsed / a.steps),
             "candidate_sites_per_step": cand_sites, "records_per_step": n_records,
-            "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
+            "stage_ms": avg, "kernels": per_kernel,
             "setup_s": {"generate": t_gen, "h2d": t_h2d},
-            "roofline": {"bound": "hbm", "kernel": "k_pileup_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sweep_avg_ms,
-                         "bytes_per_read_base": BYTES_PER_READ_BASE},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, chunks, params, pon, com, a.cpu_sample_mb)

@@ -34,10 +34,10 @@ class ReadBatchStruct(ctypes.Structure):
 
 
 class RunStats(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_double) for k in ("ms_total", "ms_parse", "ms_bqsum", "ms_hap", "ms_emit", "ms_sweep",
-                                               "ms_eval", "ms_finalize")] + \
-               [(k, ctypes.c_int64) for k in ("n_reads", "read_bases", "positions", "n_tiles", "n_candidates",
-                                              "n_records", "sweep_row_bases")]
+    _fields_ = [(k, ctypes.c_double) for k in ("ms_total", "ms_parse", "ms_bqsum", "ms_hap", "ms_emit", "ms_index",
+                                               "ms_capture", "ms_eval", "ms_finalize")] + \
+               [(k, ctypes.c_int64) for k in ("n_reads", "read_bases", "positions", "n_unique_positions", "n_candidates",
+                                              "n_records", "column_slots")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -57,7 +57,7 @@ void upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
 template <class T>
 void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) { upload(b, v.data(), v.size(), st); }
 
-enum { EV_START = 0, EV_BQSUM, EV_PARSE, EV_HAP, EV_EMIT, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
+enum { EV_START = 0, EV_BQSUM, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
 
 }  // namespace
 
@@ -93,7 +93,7 @@ struct himut_ctx {
     DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs;
     // run state
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
-    DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_winlo_c, d_winn_c, d_winoff_c, d_colstore;
+    DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_winlo_c, d_winn_c, d_winoff_c, d_colstore, d_posbits_c, d_posrank, d_poppc, d_tmp2;
     std::vector<himut_record> h_recs;
     bool h_recs_valid = false;
     int64_t n_out = 0;
@@ -370,12 +370,31 @@ int do_run(himut_ctx* c) {
         c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
         HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                          c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
-        // column store layout: window per candidate, offsets by exclusive scan
+        // bitmap of candidate positions + rank index + per unique position window / column offset
+        // the bitmap is probed at every position a read covers, so it spans reads as well as chunks
+        int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
+        for (int32_t e : c->cend) maxpos = std::max(maxpos, e);
+        const int64_t nwords = ((int64_t)maxpos >> 5) + 2;
+        c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
+        c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
+        c->d_poppc.reserve((size_t)(nwords + 2) * 4 + 256);
         c->d_winlo_c.reserve((size_t)ncand * 4 + 256); c->d_winn_c.reserve((size_t)ncand * 4 + 256);
         c->d_winoff_c.reserve((size_t)ncand * 4 + 256);
-        hipLaunchKernelGGL(k_cand_windows, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand,
-                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_winlo_c.as<int32_t>(),
-                           c->d_winn_c.as<uint32_t>());
+        HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
+        hipLaunchKernelGGL(k_candpos_set, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand,
+                           c->d_posbits_c.as<uint32_t>());
+        hipLaunchKernelGGL(k_word_popc, dim3(blocks_for(nwords, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
+                           nwords, c->d_poppc.as<uint32_t>());
+        size_t scan2 = 0;
+        HCHECK(rocprim::exclusive_scan(nullptr, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
+                                       (size_t)nwords, rocprim::plus<uint32_t>(), st));
+        c->d_tmp2.reserve(scan2 + 256);
+        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
+                                       (size_t)nwords, rocprim::plus<uint32_t>(), st));
+        HCHECK(hipMemsetAsync(c->d_winn_c.p, 0, (size_t)ncand * 4, st));
+        hipLaunchKernelGGL(k_upos_windows, dim3(blocks_for(nwords, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
+                           c->d_posrank.as<uint32_t>(), nwords, c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(),
+                           c->d_winlo_c.as<int32_t>(), c->d_winn_c.as<uint32_t>());
         HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_tmp, c->d_winn_c.as<uint32_t>(), c->d_winoff_c.as<uint32_t>(), 0u,
                                        (size_t)ncand, rocprim::plus<uint32_t>(), st));
         uint32_t last_off = 0, last_n = 0;
@@ -384,15 +403,15 @@ int do_run(himut_ctx* c) {
         HCHECK(hipStreamSynchronize(st));
         const size_t nslots = (size_t)last_off + last_n;
         c->d_colstore.reserve(nslots * 2 + 256);
-        c->stats.sweep_row_bases = (int64_t)nslots;
-        GatherArgs G;
-        G.R = R; G.D = D; G.C = C; G.H = H;
-        G.cands = c->d_cands2.as<Cand>(); G.ncand = ncand;
-        G.win_lo = c->d_winlo_c.as<int32_t>(); G.win_n = c->d_winn_c.as<uint32_t>(); G.win_off = c->d_winoff_c.as<uint32_t>();
-        G.colstore = c->d_colstore.as<uint16_t>();
-        const int64_t ngroups = (ncand + EG - 1) / EG;
-        if (phase) hipLaunchKernelGGL(k_gather_columns<true>, dim3(blocks_for(ngroups, 4)), dim3(256), 0, st, G);
-        else hipLaunchKernelGGL(k_gather_columns<false>, dim3(blocks_for(ngroups, 4)), dim3(256), 0, st, G);
+        c->stats.column_slots = (int64_t)nslots;
+        if (nslots) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, nslots, st));
+        PosIndex X;
+        X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
+        X.ulo = c->d_winlo_c.as<int32_t>(); X.un = c->d_winn_c.as<uint32_t>(); X.uoff = c->d_winoff_c.as<uint32_t>();
+        CaptureArgs G;
+        G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>();
+        HCHECK(hipEventRecord(c->ev[EV_INDEX], st));
+        hipLaunchKernelGGL(k_stream_capture, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
         HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
         EvalArgs A;
         A.P = c->params;
@@ -400,14 +419,14 @@ int do_run(himut_ctx* c) {
         A.S.posbits = c->d_posbits.as<uint32_t>(); A.S.nposbits = c->nposbits;
         A.lut = c->d_lut.as<GtLut>();
         A.cands = c->d_cands2.as<Cand>(); A.ncand = ncand;
-        A.cstart = c->d_cstart.as<int32_t>();
-        A.win_n = c->d_winn_c.as<uint32_t>(); A.win_off = c->d_winoff_c.as<uint32_t>();
+        A.R = R; A.D = D; A.C = C; A.H = H; A.X = X;
         A.colstore = c->d_colstore.as<uint16_t>();
         A.recs = c->d_recs.as<himut_record>();
         A.err = &sc->err;
         if (phase) hipLaunchKernelGGL(k_eval_columns<true>, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, A);
         else hipLaunchKernelGGL(k_eval_columns<false>, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, A);
     } else {
+        HCHECK(hipEventRecord(c->ev[EV_INDEX], st));
         HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
     }
     HCHECK(hipEventRecord(c->ev[EV_SWEEP], st));
@@ -448,13 +467,14 @@ int do_run(himut_ctx* c) {
     S.ms_bqsum = ms(EV_PARSE, EV_BQSUM);
     S.ms_hap = ms(EV_BQSUM, EV_HAP);
     S.ms_emit = ms(EV_HAP, EV_EMIT);
-    S.ms_sweep = ms(EV_EMIT, EV_GATHER);
+    S.ms_index = ms(EV_EMIT, EV_INDEX);
+    S.ms_capture = ms(EV_INDEX, EV_GATHER);
     S.ms_eval = ms(EV_GATHER, EV_SWEEP);
     S.ms_finalize = ms(EV_SWEEP, EV_FINAL);
     S.n_reads = c->n;
     S.read_bases = c->read_bases;
     S.positions = T.positions;
-    S.n_tiles = T.n_tiles;
+    S.n_unique_positions = 0;
     S.n_candidates = ncand;
     S.n_records = c->n_out;
     return HIMUT_OK;

@@ -14,11 +14,13 @@
 //                      (the set() of caller.py:324) using a per-chunk bit mask
 //   k_cand_keys + sort the candidates in the order of the final records
 //   k_window_index     per 256-position block: the range of reads that can cover it
-//   k_cand_windows + scan  per candidate: its read window and its offset in the column store
-//   k_gather_columns   one WAVE per 8 neighbouring candidate columns, lanes = the reads that
-//                      can cover them: read metadata + segment list once per group, then
-//                      the base / quality byte of every (column, read) with independent
-//                      loads -> 16-bit slots of the column store, in fetch order
+//   k_candpos_set / k_word_popc / k_upos_windows + scans
+//                      bitmap of candidate positions, its rank index, and per unique
+//                      position the read window and the offset of its column
+//   k_stream_capture   one wave per read: streams the read's qualities and packed bases once
+//                      (16 B + 8 B per lane, coalesced), maps every base to its reference
+//                      position through the segment list, and drops the (allele, BQ) of the
+//                      bases that sit on candidate positions into the column store
 //   k_eval_columns     one THREAD per candidate column: allele counts, BQ sums, the
 //                      genotype likelihood sums added in fetch order exactly as the
 //                      reference's python sum() does, genotype, filter cascade
@@ -456,95 +458,138 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
 // contains tpos (caller.py:104-108,325) and fetched the read (caller.py:299): set the
 // (ref, alt) bit of the position in that chunk's mask; the lane that sets it first
 // appends the candidate (set() semantics of caller.py:324).
-constexpr int EMIT_MAXC = 4;  // chunks of one read kept in registers
+constexpr int EMIT_MAXC = 4;   // chunks of one read kept in registers
+constexpr int EMIT_MAXP = 4;   // proposals one lane can hold per round (chunks containing the site)
 
 __global__ void __launch_bounds__(256) k_emit_candidates(Reads R, Derived D, Chunks C, Phase H, Params P,
                                                          uint32_t* mask, uint8_t* ccs_flag, Cand* cands,
                                                          unsigned long long* ncand, int64_t cand_cap, int* err) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R.n) return;
-    const ReadMeta M = D.meta[r];
-    if (!(M.flags & RF_PASS)) return;
-    const int32_t ts = M.tstart, te = M.tend;
+    __shared__ int s_cnt[4];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     const bool phase = P.p.phase != 0;
+    ReadMeta M; M.flags = 0; M.tstart = 0; M.tend = 0; M.segbase = 0; M.nseg = 0; M.qoff = 0;
+    if (r < R.n) M = D.meta[r];
+    bool live = (M.flags & RF_PASS) != 0;
+    const int32_t ts = M.tstart, te = M.tend;
     // the chunks that fetched this read (start < tend and end > tstart), newest start first
-    int64_t hi = C.hint[min((int64_t)(te > 0 ? te : 0) >> CHUNK_HINT_SHIFT, C.nhint - 1)];
-    while (hi < C.n && C.s_start[hi] < te) hi++;
     int nc = 0;
     bool overflow = false;
+    int64_t hi = 0;
     int32_t cc[EMIT_MAXC], cst[EMIT_MAXC], cen[EMIT_MAXC];
 #pragma unroll
     for (int k = 0; k < EMIT_MAXC; k++) { cc[k] = -1; cst[k] = 0; cen[k] = -1; }
-    for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts; j--) {
-        const int c = C.s_idx[j];
-        const int32_t e = C.end[c];
-        if (e <= ts) continue;
-        if (phase && H.hap[C.pairoff[c] + (r - C.rlo[c])] == HAP_NONE) continue;   // caller.py:306-309
-        if (nc < EMIT_MAXC) {
+    if (live) {
+        hi = C.hint[min((int64_t)(te > 0 ? te : 0) >> CHUNK_HINT_SHIFT, C.nhint - 1)];
+        while (hi < C.n && C.s_start[hi] < te) hi++;
+        for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts; j--) {
+            const int c = C.s_idx[j];
+            const int32_t e = C.end[c];
+            if (e <= ts) continue;
+            if (phase && H.hap[C.pairoff[c] + (r - C.rlo[c])] == HAP_NONE) continue;   // caller.py:306-309
+            if (nc < EMIT_MAXC) {
 #pragma unroll
-            for (int k = 0; k < EMIT_MAXC; k++) if (k == nc) { cc[k] = c; cst[k] = C.start[c]; cen[k] = e; }
-        } else overflow = true;
-        nc++;
+                for (int k = 0; k < EMIT_MAXC; k++) if (k == nc) { cc[k] = c; cst[k] = C.start[c]; cen[k] = e; }
+            } else overflow = true;
+            nc++;
+        }
+        // num_ccs (caller.py:318-320): counted once it passes in any chunk that fetched it
+        if (nc == 0) live = false;
+        else if (lane == 0) ccs_flag[R.qid[r]] = 1;
     }
-    // num_ccs (caller.py:318-320): counted once it passes in any chunk that fetched it
-    if (nc == 0) return;
-    if (lane == 0) ccs_flag[R.qid[r]] = 1;
-
     const int64_t sb = M.segbase;
     const int32_t* mis = D.mis + sb;
     const uint32_t* mq = D.mq + sb;
-    const int nm = D.nmis[r];
-    const int32_t qlen = R.qlen[r];
+    const int nm = live ? D.nmis[r] : 0;
+    const int32_t qlen = live ? R.qlen[r] : 1;
     const double trim_start = floor(P.p.min_trim * (double)qlen);        // bamlib.py:226
     const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);   // bamlib.py:227
     const int64_t w = P.p.mismatch_window_size;
-    for (int e = lane; e < nm; e += 64) {
-        const uint32_t v = mq[e];
-        if (!(v & 16u)) continue;  // indel entry
-        const int32_t tp1 = mis[e];
-        const int64_t q = v >> 5;
-        if ((double)q < trim_start || (double)q > trim_end) continue;    // bamlib.py:231-242
-        {                                                                   // bamlib.py:245-282
-            int64_t qs = q - w, qe = q + w, ur, dr;
-            if (qs < 0) { ur = w + qs; dr = w - qs; }
-            else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - q; }
-            else { ur = w; dr = w; }
-            const int32_t ms = (int32_t)(tp1 - ur), me = (int32_t)(tp1 + dr);
-            // bisect_right(me) - bisect_left(ms) - 1 on the sorted list; the entry itself is inside [ms, me]
-            int lo = e, up = e + 1;
-            while (lo > 0 && mis[lo - 1] >= ms) lo--;
-            while (up < nm && mis[up] <= me) up++;
-            if ((int64_t)(up - lo) - 1 > P.p.max_mismatch_count) continue;
-        }
-        const int bit = (int)(v & 15u);
-        auto propose = [&](int c, int32_t cs_) {
-            // 16 mask bits per position, two positions per 32-bit word
-            const int64_t cell = C.maskoff[c] + (tp1 - cs_);
-            const unsigned int m = (1u << bit) << ((cell & 1) ? 16 : 0);
-            const unsigned int old = atomicOr(mask + (cell >> 1), m);
-            if (!(old & m)) {
-                const unsigned long long slot = wave_reserve(ncand);
-                if ((int64_t)slot < cand_cap) {
-                    Cand cd; cd.tpos = tp1; cd.chunk_bit = ((uint32_t)c << 4) | (uint32_t)bit;
-                    cands[slot] = cd;
+    // rounds of 64 mismatch entries; every round ends with ONE reservation for the whole workgroup
+    int nm_max = nm;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) nm_max = max(nm_max, __shfl_xor(nm_max, d, 64));
+    __shared__ int s_nm[4];
+    if (lane == 0) s_nm[wv] = nm_max;
+    __syncthreads();
+    const int rounds = (max(max(s_nm[0], s_nm[1]), max(s_nm[2], s_nm[3])) + 63) / 64;
+    for (int round = 0; round < rounds; round++) {
+        const int e = round * 64 + lane;
+        Cand mine[EMIT_MAXP];
+        int nmine = 0;
+        if (e < nm) {
+            const uint32_t v = mq[e];
+            const int32_t tp1 = mis[e];
+            const int64_t q = v >> 5;
+            bool ok = (v & 16u) != 0;                                               // substitutions only
+            if (ok && ((double)q < trim_start || (double)q > trim_end)) ok = false;  // bamlib.py:231-242
+            if (ok) {                                                               // bamlib.py:245-282
+                int64_t qs = q - w, qe = q + w, ur, dr;
+                if (qs < 0) { ur = w + qs; dr = w - qs; }
+                else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - q; }
+                else { ur = w; dr = w; }
+                const int32_t ms = (int32_t)(tp1 - ur), me = (int32_t)(tp1 + dr);
+                // bisect_right(me) - bisect_left(ms) - 1 on the sorted list; the entry itself is inside [ms, me]
+                int lo = e, up = e + 1;
+                while (lo > 0 && mis[lo - 1] >= ms) lo--;
+                while (up < nm && mis[up] <= me) up++;
+                if ((int64_t)(up - lo) - 1 > P.p.max_mismatch_count) ok = false;
+            }
+            if (ok) {
+                const int bit = (int)(v & 15u);
+                auto propose = [&](int c, int32_t cs_) {
+                    // 16 mask bits per position, two positions per 32-bit word
+                    const int64_t cell = C.maskoff[c] + (tp1 - cs_);
+                    const unsigned int m = (1u << bit) << ((cell & 1) ? 16 : 0);
+                    const unsigned int old = atomicOr(mask + (cell >> 1), m);
+                    if (!(old & m)) {
+                        Cand cd; cd.tpos = tp1; cd.chunk_bit = ((uint32_t)c << 4) | (uint32_t)bit;
+                        if (nmine < EMIT_MAXP) {
+#pragma unroll
+                            for (int k = 0; k < EMIT_MAXP; k++) if (k == nmine) mine[k] = cd;
+                            nmine++;
+                        } else {  // more chunks share this site than a lane can buffer: reserve on its own
+                            const unsigned long long slot = atomicAdd(ncand, 1ULL);
+                            if ((int64_t)slot < cand_cap) cands[slot] = cd;
+                        }
+                    }
+                };
+                if (!overflow) {
+#pragma unroll
+                    for (int k = 0; k < EMIT_MAXC; k++)
+                        if (cc[k] >= 0 && cst[k] <= tp1 && tp1 <= cen[k]) propose(cc[k], cst[k]);
+                } else {
+                    // a read that lies in more chunks than fit the registers: walk the table again
+                    for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts; j--) {
+                        const int c = C.s_idx[j];
+                        const int32_t cs_ = C.start[c], ce_ = C.end[c];
+                        if (ce_ <= ts || !(cs_ <= tp1 && tp1 <= ce_)) continue;
+                        if (phase && H.hap[C.pairoff[c] + (r - C.rlo[c])] == HAP_NONE) continue;
+                        propose(c, cs_);
+                    }
                 }
             }
-        };
-        if (!overflow) {
-#pragma unroll
-            for (int k = 0; k < EMIT_MAXC; k++)
-                if (cc[k] >= 0 && cst[k] <= tp1 && tp1 <= cen[k]) propose(cc[k], cst[k]);
-        } else {
-            // a read that lies in more chunks than fit the registers: walk the table again
-            for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts; j--) {
-                const int c = C.s_idx[j];
-                const int32_t cs_ = C.start[c], ce_ = C.end[c];
-                if (ce_ <= ts || !(cs_ <= tp1 && tp1 <= ce_)) continue;
-                if (phase && H.hap[C.pairoff[c] + (r - C.rlo[c])] == HAP_NONE) continue;
-                propose(c, cs_);
-            }
         }
+        // exclusive prefix of nmine inside the wave, wave totals through LDS, one atomic per workgroup
+        int incl = nmine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int wtot = __shfl(incl, 63, 64);
+        if (lane == 0) s_cnt[wv] = wtot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            s_base = tot ? atomicAdd(ncand, (unsigned long long)tot) : 0ULL;
+        }
+        __syncthreads();
+        unsigned long long slot = s_base + (unsigned long long)(incl - nmine);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k < wv) slot += (unsigned long long)s_cnt[k];
+#pragma unroll
+        for (int k = 0; k < EMIT_MAXP; k++)
+            if (k < nmine && (int64_t)(slot + k) < cand_cap) cands[slot + k] = mine[k];
+        __syncthreads();
     }
 }
 
@@ -572,151 +617,259 @@ __global__ void __launch_bounds__(256) k_window_index(Reads R, int64_t nblk, int
     winhi[b] = (int32_t)hi;
 }
 
+// 16 BAM nibbles (base j at bits 4j..4j+3) -> 16 pile cells (himut allele index, 4 = not ATGC)
+__device__ __forceinline__ uint64_t nib16_to_cells(uint64_t x) {
+    const uint64_t m = 0x1111111111111111ULL;
+    const uint64_t n0 = x & m, n1 = (x >> 1) & m, n2 = (x >> 2) & m, n3 = (x >> 3) & m;  // A C G T one-hot bits
+    const uint64_t sum = n0 + n1 + n2 + n3;
+    const uint64_t inv = ((sum >> 1) | (sum >> 2) | ~sum) & m;     // not exactly one bit set
+    uint64_t code = (n3 | n1) | ((n2 | n1) << 1);                  // T,C -> bit0 ; G,C -> bit1
+    code = (code & ~(inv * 3)) | (inv << 2);
+    return code;
+}
+
 // ---------------------------------------------------------------------------------------
-// The column store: for every candidate (sorted), one 16-bit slot per read of its
-// window [lo, lo + n), in fetch order:
+// The column store.  Candidate columns live at the UNIQUE reference positions that carry
+// a candidate (several chunks / alts can share one).  Unique position u (rank of its bit
+// in the position bitmap) owns the slots [uoff[u], uoff[u] + un[u]): one 16-bit slot per
+// read of its window [ulo[u], ulo[u] + un[u]), in fetch order:
 //   bits 0-2 cell (0-3 allele A T G C, 4 base outside ATGC, 5 deletion, 7 not in the pile)
 //   bit 3    an insertion precedes the position
-//   bits 4-5 haplotype of the read for the vote (HAP_0 / HAP_1 / HAP_NONE), only set when
-//            the read also covers rpos + 1 (caller.py:558)
 //   bits 8-15 base quality
-// k_gather_columns fills it (lanes = reads), k_eval_columns consumes it (thread = column).
+// k_stream_capture fills it while streaming every read once with coalesced loads;
+// k_eval_columns consumes it, one thread per candidate.
 
-constexpr int EG = 8;  // candidates per gather wave
+struct PosIndex {
+    const uint32_t* bits;    // bit rpos set: some candidate sits at rpos
+    const uint32_t* rank;    // exclusive prefix popcount per 32-bit word
+    int64_t nwords;
+    const int32_t* ulo;      // per unique position: window start (read index)
+    const uint32_t* un;      // window size
+    const uint32_t* uoff;    // slot offset
+};
 
-__global__ void __launch_bounds__(256) k_cand_windows(const Cand* cands, int64_t n, const int32_t* winlo,
-                                                      const int32_t* winhi, int32_t* lo, uint32_t* cnt) {
+__device__ __forceinline__ uint32_t pos_rank(const PosIndex& X, int32_t rpos) {
+    const int64_t w = rpos >> 5;
+    return X.rank[w] + (uint32_t)__popc(X.bits[w] & ((1u << (rpos & 31)) - 1u));
+}
+
+__global__ void __launch_bounds__(256) k_candpos_set(const Cand* cands, int64_t n, uint32_t* bits) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int32_t rpos = cands[j].tpos - 1;
-    int32_t a = 0, b = 0;
-    if (rpos >= 0) { a = winlo[rpos >> WIN_SHIFT]; b = winhi[rpos >> WIN_SHIFT]; }
-    lo[j] = a;
-    cnt[j] = (uint32_t)(b - a);
+    if (rpos >= 0) atomicOr(bits + (rpos >> 5), 1u << (rpos & 31));
 }
 
-struct GatherArgs {
+__global__ void __launch_bounds__(256) k_word_popc(const uint32_t* bits, int64_t nwords, uint32_t* out) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) out[w] = (uint32_t)__popc(bits[w]);
+}
+
+// per unique candidate position: its read window (from the 256-position window index)
+__global__ void __launch_bounds__(256) k_upos_windows(const uint32_t* bits, const uint32_t* rank, int64_t nwords,
+                                                      const int32_t* winlo, const int32_t* winhi, int32_t* ulo, uint32_t* un) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint32_t b = bits[w];
+    uint32_t u = rank[w];
+    while (b) {
+        const int k = __ffs((int)b) - 1;
+        b &= b - 1;
+        const int64_t rpos = w * 32 + k;
+        const int32_t lo = winlo[rpos >> WIN_SHIFT], hi = winhi[rpos >> WIN_SHIFT];
+        ulo[u] = lo;
+        un[u] = (uint32_t)(hi - lo);
+        u++;
+    }
+}
+
+struct CaptureArgs {
     Reads R;
     Derived D;
-    Chunks C;
-    Phase H;
-    const Cand* cands;      // sorted by record key
-    int64_t ncand;
-    const int32_t* win_lo;  // per candidate
-    const uint32_t* win_n;
-    const uint32_t* win_off;
+    PosIndex X;
     uint16_t* colstore;
 };
 
-// where does a read (first eight segments in registers, the rest in memory) put
-// reference position rpos?  o = query offset of the base, -1 deletion, -2 not covered
-struct SegHit { int64_t o; bool ins; };
+constexpr int CQ = 192;    // per-wave hit queue entries
+constexpr int CBW = 1024;  // bitmap words of the read's reference span kept in LDS (32768 positions)
+constexpr int CSG = 32;    // segments of the read kept in LDS
 
-__device__ __forceinline__ SegHit locate(const Seg* first8, const Seg* segs, int ns, int32_t rpos) {
-    SegHit h; h.o = -2; h.ins = false;
-    bool done = false;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (k < ns && !done) {
-            const Seg sg = first8[k];
-            if (sg.t0 > rpos) done = true;
-            else {
-                if (rpos == sg.t0 && (sg.flags & SEG_INS)) h.ins = true;
-                if (rpos < sg.t0 + sg.len) { done = true; h.o = (sg.flags & SEG_DEL) ? -1 : (int64_t)sg.q0 + (rpos - sg.t0); }
-            }
-        }
+struct CapQueue {
+    uint32_t* pos;   // rpos of the hit
+    uint32_t* val;   // slot value | (candidate bits below rpos in its bitmap word) << 16
+    int n;           // wave-uniform length
+};
+
+// resolve up to 64 queued hits: rank -> window -> slot
+__device__ __forceinline__ void cap_flush(CapQueue& Q, int count, const PosIndex& X, uint16_t* colstore, int32_t r, int lane) {
+    if (lane < count) {
+        const uint32_t rpos = Q.pos[lane];
+        const uint32_t v = Q.val[lane];
+        const uint32_t u = X.rank[rpos >> 5] + (v >> 16);
+        const int32_t lo = X.ulo[u];
+        const uint32_t off = X.uoff[u];
+        colstore[(int64_t)off + (r - lo)] = (uint16_t)(v & 0xffffu);
     }
-    for (int k = 8; k < ns && !done; k++) {
-        const Seg sg = segs[k];
-        if (sg.t0 > rpos) break;
-        if (rpos == sg.t0 && (sg.flags & SEG_INS)) h.ins = true;
-        if (rpos < sg.t0 + sg.len) { done = true; h.o = (sg.flags & SEG_DEL) ? -1 : (int64_t)sg.q0 + (rpos - sg.t0); }
-    }
-    return h;
+    __builtin_amdgcn_wave_barrier();
+    const int rest = Q.n - count;   // < 64 by construction of cap_push
+    uint32_t p0 = 0, v0 = 0;
+    if (lane < rest) { p0 = Q.pos[count + lane]; v0 = Q.val[count + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) { Q.pos[lane] = p0; Q.val[lane] = v0; }
+    __builtin_amdgcn_wave_barrier();
+    Q.n = rest;
 }
 
-template <bool PHASE>
-__global__ void __launch_bounds__(256) k_gather_columns(GatherArgs A) {
-    const int tid = threadIdx.x, lane = tid & 63;
+// appends the lanes' hits in lane order
+__device__ __forceinline__ void cap_push(CapQueue& Q, bool have, uint32_t rpos, uint32_t val, const PosIndex& X,
+                                         uint16_t* colstore, int32_t r, int lane) {
+    const unsigned long long bal = __ballot(have);
+    if (!bal) return;
+    if (have) {
+        const int slot = Q.n + __popcll(bal & ((1ULL << lane) - 1ULL));
+        Q.pos[slot] = rpos; Q.val[slot] = val;
+    }
+    Q.n += __popcll(bal);
+    __builtin_amdgcn_wave_barrier();
+    if (Q.n >= 64) cap_flush(Q, 64, X, colstore, r, lane);
+}
+
+// One wave per read.  The read's aligned bases are streamed in query order, 1 KB of
+// qualities + 512 B of packed bases per step (16 bases per lane, 16-byte / 8-byte aligned
+// coalesced loads, the next step's loads issued before the current step is consumed).
+// The segment list and the candidate-position bitmap under the read sit in LDS, so
+// mapping a base to its reference position and probing it costs no memory round trip.
+// Hits are queued in LDS and resolved to column-store slots 64 at a time.
+__global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
+    __shared__ uint32_t s_qpos[4][CQ];
+    __shared__ uint32_t s_qval[4][CQ];
+    __shared__ uint32_t s_bits[4][CBW];
+    __shared__ Seg s_seg[4][CSG];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Reads& R = A.R;
-    const int64_t g = (int64_t)blockIdx.x * 4 + (tid >> 6);
-    const int64_t j0 = g * EG;
-    if (j0 >= A.ncand) return;
-    const int ng = (int)min((int64_t)EG, A.ncand - j0);
-    // the group's candidates, one per lane; wave-uniform copies via readlane
-    Cand mine; mine.tpos = 0; mine.chunk_bit = 0;
-    int32_t my_cs = 0, my_ce = 0, my_lo = 0x7fffffff, my_n = 0;
-    uint32_t my_off = 0;
-    if (lane < ng) {
-        mine = A.cands[j0 + lane];
-        my_cs = A.C.start[mine.chunk_bit >> 4];
-        my_ce = A.C.end[mine.chunk_bit >> 4];
-        my_lo = A.win_lo[j0 + lane];
-        my_n = (int32_t)A.win_n[j0 + lane];
-        my_off = A.win_off[j0 + lane];
+    const PosIndex& X = A.X;
+    const int64_t r64 = (int64_t)blockIdx.x * 4 + wv;
+    if (r64 >= R.n) return;
+    const int32_t r = (int32_t)r64;
+    const ReadMeta M = A.D.meta[r];
+    if ((M.flags & RF_SECONDARY) || M.nseg <= 0) return;
+    const Seg* gsegs = A.D.segs + M.segbase;
+    const int ns = M.nseg;
+    const bool seg_lds = ns <= CSG;
+    CapQueue Q; Q.pos = s_qpos[wv]; Q.val = s_qval[wv]; Q.n = 0;
+    // segment list and the bitmap words under the read -> LDS, one coalesced sweep each
+    if (seg_lds && lane < ns) s_seg[wv][lane] = gsegs[lane];
+    const int64_t w_lo = M.tstart >> 5;
+    const int nwl = (int)min((int64_t)CBW, ((int64_t)(M.tend + 32) >> 5) - w_lo + 2);
+    uint32_t* lbits = s_bits[wv];
+    for (int k = lane; k < nwl; k += 64) lbits[k] = X.bits[w_lo + k];
+    __builtin_amdgcn_wave_barrier();
+#define CAP_SEG(j) (seg_lds ? s_seg[wv][(j)] : gsegs[(j)])
+#define CAP_WORD(w) ((((w) - w_lo) >= 0 && ((w) - w_lo) < nwl) ? lbits[(w) - w_lo] : X.bits[(w)])
+    const int64_t qo = M.qoff;
+    // query range of the aligned segments (soft clips are never touched)
+    int32_t q_lo = 0x7fffffff, q_hi = 0;
+    for (int j = 0; j < ns; j++) {
+        const Seg sg = CAP_SEG(j);
+        if (!(sg.flags & SEG_DEL) && sg.len > 0) { q_lo = min(q_lo, sg.q0); q_hi = max(q_hi, sg.q0 + sg.len); }
     }
-    int32_t krpos[EG], kcs[EG], kce[EG], klo[EG], kn[EG];
-    uint32_t koff[EG], kch[EG];
-    int32_t glo = 0x7fffffff, ghi = 0;
-#pragma unroll
-    for (int k = 0; k < EG; k++) {
-        krpos[k] = __builtin_amdgcn_readlane(mine.tpos, k) - 1;
-        kch[k] = (uint32_t)__builtin_amdgcn_readlane((int)mine.chunk_bit, k) >> 4;
-        kcs[k] = __builtin_amdgcn_readlane(my_cs, k);
-        kce[k] = __builtin_amdgcn_readlane(my_ce, k);
-        klo[k] = __builtin_amdgcn_readlane(my_lo, k);
-        kn[k] = __builtin_amdgcn_readlane(my_n, k);
-        koff[k] = (uint32_t)__builtin_amdgcn_readlane((int)my_off, k);
-        if (k < ng && kn[k] > 0) { glo = min(glo, klo[k]); ghi = max(ghi, klo[k] + kn[k]); }
+    // the first step's loads go out before anything else
+    int32_t c0 = q_lo & ~15;
+    uint4 bq_n = make_uint4(0, 0, 0, 0);
+    uint2 sq_n = make_uint2(0, 0);
+    if (c0 + lane * 16 < q_hi) {
+        bq_n = *reinterpret_cast<const uint4*>(R.bq + qo + c0 + lane * 16);      // qoff % 32 == 0
+        sq_n = *reinterpret_cast<const uint2*>(R.seq + ((qo + c0 + lane * 16) >> 1));
     }
-    for (int32_t base = glo; base < ghi; base += 64) {
-        // ---- rows: one read per lane, metadata + first eight segments in registers
-        const int32_t r = base + lane;
-        ReadMeta M; M.tstart = 0; M.tend = -1; M.nseg = 0; M.flags = RF_SECONDARY; M.segbase = 0; M.qoff = 0;
-        if (r < ghi) M = A.D.meta[r];
-        const bool rowok = !(M.flags & RF_SECONDARY) && M.nseg > 0;
-        const Seg* segs = A.D.segs + M.segbase;
-        Seg first[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            first[k].t0 = 0x7fffffff; first[k].q0 = 0; first[k].len = 0; first[k].flags = 0;
-            if (rowok) first[k] = segs[min(k, M.nseg - 1)];
-        }
-        // ---- the base / quality byte of every column, all loads in flight together
-        uint32_t gq[EG], gsb[EG], gst[EG];
-#pragma unroll
-        for (int k = 0; k < EG; k++) {
-            gq[k] = 0; gsb[k] = 0; gst[k] = CELL_EMPTY | (HAP_NONE << 4);
-            const int32_t rpos = krpos[k];
-            // the read is in the pile of the column's chunk (fetch rule, caller.py:299) and can touch rpos
-            if (k < ng && rowok && M.tstart <= rpos && M.tend >= rpos && M.tstart < kce[k] && M.tend > kcs[k]) {
-                const SegHit h = locate(first, segs, M.nseg, rpos);
-                if (h.ins) gst[k] |= CELL_INS;
-                if (h.o == -1) gst[k] = (gst[k] & ~7u) | CELL_DEL;
-                else if (h.o >= 0) {
-                    const int64_t o = M.qoff + h.o;
-                    gst[k] = (gst[k] & ~7u) | 6u | ((o & 1) ? 0x100u : 0u);   // 6 = base pending
-                    gq[k] = R.bq[o];
-                    gsb[k] = R.seq[o >> 1];
-                    if (PHASE && M.tend > rpos + 1)
-                        gst[k] = (gst[k] & ~0x30u) | ((uint32_t)A.H.hap[A.C.pairoff[kch[k]] + ((int64_t)r - A.C.rlo[kch[k]])] << 4);
+    // ---- deletions and trailing insertion markers (no query bases involved)
+    for (int j = 0; j < ns; j++) {
+        const Seg sg = CAP_SEG(j);
+        if (sg.flags & SEG_DEL) {
+            for (int i0 = 0; i0 < sg.len; i0 += 64) {
+                const int i = i0 + lane;
+                bool have = false;
+                uint32_t rpos = 0, val = 0;
+                if (i < sg.len) {
+                    rpos = (uint32_t)(sg.t0 + i);
+                    const int64_t w = rpos >> 5;
+                    const uint32_t wbits = CAP_WORD(w);
+                    if ((wbits >> (rpos & 31)) & 1u) {
+                        have = true;
+                        val = CELL_DEL | ((i == 0 && (sg.flags & SEG_INS)) ? CELL_INS : 0u);
+                        val |= (uint32_t)__popc(wbits & ((1u << (rpos & 31)) - 1u)) << 16;
+                    }
+                }
+                cap_push(Q, have, rpos, val, X, A.colstore, r, lane);
+            }
+        } else if (sg.len == 0 && (sg.flags & SEG_INS)) {
+            bool have = false;
+            const uint32_t rpos = (uint32_t)sg.t0;
+            uint32_t val = 0;
+            if (lane == 0) {
+                const int64_t w = rpos >> 5;
+                const uint32_t wbits = CAP_WORD(w);
+                if ((wbits >> (rpos & 31)) & 1u) {
+                    have = true;
+                    val = CELL_EMPTY | CELL_INS | ((uint32_t)__popc(wbits & ((1u << (rpos & 31)) - 1u)) << 16);
                 }
             }
+            cap_push(Q, have, rpos, val, X, A.colstore, r, lane);
         }
-        // ---- publish the slots
-#pragma unroll
-        for (int k = 0; k < EG; k++) {
-            if (k < ng && r >= klo[k] && r < klo[k] + kn[k]) {
-                uint32_t st = gst[k] & 0x3fu;
-                if ((st & 7u) == 6u) {
-                    const int cell = nib2allele((int)((gst[k] & 0x100u) ? (gsb[k] & 15u) : (gsb[k] >> 4)));
-                    st = (st & ~7u) | (uint32_t)cell;
-                    if (cell >= 4) st |= (HAP_NONE << 4);
+    }
+    // ---- aligned bases, in query order
+    int js = 0;  // first segment that can still overlap the current step
+    for (; c0 < q_hi; c0 += 1024) {
+        const int32_t qa = c0 + lane * 16;   // this lane's bases [qa, qa + 16)
+        const uint4 bqv = bq_n;
+        const uint2 sqv = sq_n;
+        bq_n = make_uint4(0, 0, 0, 0); sq_n = make_uint2(0, 0);
+        if (qa + 1024 < q_hi) {              // next step's loads
+            bq_n = *reinterpret_cast<const uint4*>(R.bq + qo + qa + 1024);
+            sq_n = *reinterpret_cast<const uint2*>(R.seq + ((qo + qa + 1024) >> 1));
+        }
+        // base i of the lane: quality byte i, nibble i (high nibble first inside each byte)
+        const uint64_t sw = ((uint64_t)sqv.y << 32) | sqv.x;
+        const uint64_t nib = ((sw & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((sw >> 4) & 0x0f0f0f0f0f0f0f0fULL);
+        const uint64_t cells = nib16_to_cells(nib);
+        for (int j = js; j < ns; j++) {
+            const Seg sg = CAP_SEG(j);
+            if ((sg.flags & SEG_DEL) || sg.len == 0) continue;
+            if (sg.q0 >= c0 + 1024) break;
+            if (sg.q0 + sg.len <= c0) { js = j + 1; continue; }
+            // overlap of the segment with this lane's 16 bases
+            const int a = max(sg.q0, qa) - qa, b = min(sg.q0 + sg.len, qa + 16) - qa;
+            uint32_t hits = 0;      // bit i: base i sits on a candidate position
+            uint32_t w0 = 0, w1 = 0;
+            int32_t tp = 0;
+            if (a < b) {
+                tp = sg.t0 + (qa + a - sg.q0);            // reference position of base a
+                const int64_t w = tp >> 5;
+                w0 = CAP_WORD(w); w1 = CAP_WORD(w + 1);
+                const uint64_t two = ((uint64_t)w1 << 32) | w0;
+                hits = (uint32_t)((two >> (tp & 31)) & ((1u << (b - a)) - 1u)) << a;
+            }
+            while (__ballot(hits != 0)) {
+                const bool have = hits != 0;
+                uint32_t rpos = 0, val = 0;
+                if (have) {
+                    const int i = __ffs((int)hits) - 1;
+                    hits &= hits - 1;
+                    rpos = (uint32_t)(tp + (i - a));
+                    const uint32_t cell = (uint32_t)(cells >> (4 * i)) & 7u;
+                    const uint32_t qw = (i < 8) ? ((i < 4) ? bqv.x : bqv.y) : ((i < 12) ? bqv.z : bqv.w);
+                    const uint32_t qv = (qw >> (8 * (i & 3))) & 255u;
+                    const uint32_t insb = (rpos == (uint32_t)sg.t0 && (sg.flags & SEG_INS)) ? CELL_INS : 0u;
+                    // candidate bits below rpos inside its own bitmap word (w0: the word of tp, w1: the next)
+                    const uint32_t word = ((rpos >> 5) == ((uint32_t)tp >> 5)) ? w0 : w1;
+                    val = cell | insb | (qv << 8) | ((uint32_t)__popc(word & ((1u << (rpos & 31)) - 1u)) << 16);
                 }
-                A.colstore[(int64_t)koff[k] + (r - klo[k])] = (uint16_t)(st | (gq[k] << 8));
+                cap_push(Q, have, rpos, val, X, A.colstore, r, lane);
             }
         }
     }
+    while (Q.n > 0) cap_flush(Q, min(Q.n, 64), X, A.colstore, r, lane);
+#undef CAP_SEG
+#undef CAP_WORD
 }
 
 // ---------------------------------------------------------------------------------------
@@ -754,9 +907,11 @@ struct EvalArgs {
     const GtLut* lut;
     const Cand* cands;       // sorted by record key
     int64_t ncand;
-    const int32_t* cstart;   // chunk starts (phase set id of a phased PASS, caller.py:292,584)
-    const uint32_t* win_n;
-    const uint32_t* win_off;
+    Reads R;
+    Derived D;
+    Chunks C;
+    Phase H;
+    PosIndex X;
     const uint16_t* colstore;
     himut_record* recs;      // record j belongs to candidate j
     int* err;
@@ -776,9 +931,16 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
     const int32_t tpos = cd.tpos;
     const int chunk = (int)(cd.chunk_bit >> 4);
     const int ref = (int)((cd.chunk_bit >> 2) & 3), alt = (int)(cd.chunk_bit & 3);
-    const uint32_t n = A.win_n[j];
-    const uint16_t* col = A.colstore + A.win_off[j];
+    const int32_t rpos = tpos - 1;
+    const uint32_t u = pos_rank(A.X, rpos);
+    const uint32_t n = A.X.un[u];
+    const int32_t lo = A.X.ulo[u];
+    const uint16_t* col = A.colstore + A.X.uoff[u];
     const int min_bq = A.P.p.min_bq;
+    const int32_t cs_ = A.C.start[chunk];
+    // Only next to the chunk start can a read lie in the pile of the position without having
+    // been fetched by the chunk (caller.py:299: fetch needs reference_end > chunk_start).
+    const bool edge = rpos <= cs_;
 
     uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
     uint32_t bqs[4] = {0, 0, 0, 0};
@@ -790,6 +952,12 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t v = col[i];
         const uint32_t cell = v & 7u;
+        if ((v & 15u) == CELL_EMPTY) continue;
+        int32_t tend = 0;
+        if (edge || PHASE) {
+            tend = A.R.tend[lo + (int32_t)i];
+            if (edge && !(tend > cs_)) continue;   // not fetched by this chunk
+        }
         if (v & CELL_INS) cnt[4]++;
         if (cell < 4) {
             const uint32_t q = v >> 8;
@@ -807,7 +975,9 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
             if ((int)cell == ref) ref_count++;
             if ((int)cell == alt) { alt_count++; if ((int)q >= min_bq) alt_hi++; }   // caller.py:160-171
             if (PHASE) {
-                const uint32_t hp = (v >> 4) & 3u;
+                uint32_t hp = HAP_NONE;   // the vote counts reads that also cover rpos + 1 (caller.py:558)
+                if (tend > rpos + 1 && ((int)cell == ref || (int)cell == alt))
+                    hp = A.H.hap[A.C.pairoff[chunk] + ((int64_t)(lo + (int32_t)i) - A.C.rlo[chunk])];
                 if ((int)cell == ref) { if (hp == HAP_0) h0_ref++; else if (hp == HAP_1) h1_ref++; }   // caller.py:562-564
                 if ((int)cell == alt) { if (hp == HAP_0) som0 = 1; else if (hp == HAP_1) som1 = 1; }   // caller.py:565-569
             }
@@ -874,7 +1044,7 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
             else if ((int64_t)depth > A.P.p.md_threshold) status = HIMUT_ST_HIGHDEPTH;
             else if (PHASE) {  // caller.py:552-603 (unique query names: the voters are the pile's own rows)
                 if ((int64_t)h0_ref >= A.P.p.min_hap_count && (int64_t)h1_ref >= A.P.p.min_hap_count && (som0 + som1) == 1) {
-                    status = HIMUT_ST_PASS; ps = A.cstart[chunk];
+                    status = HIMUT_ST_PASS; ps = cs_;
                 } else status = HIMUT_ST_UNPHASED;
             } else status = HIMUT_ST_PASS;
         }
@@ -953,17 +1123,6 @@ struct Piece {
     uint32_t flags;  // SEG_DEL, SEG_INS (insertion in front of position x0)
 };
 constexpr int MAXP = 4;
-
-// 16 BAM nibbles (base j at bits 4j..4j+3) -> 16 pile cells (himut allele index, 4 = not ATGC)
-__device__ __forceinline__ uint64_t nib16_to_cells(uint64_t x) {
-    const uint64_t m = 0x1111111111111111ULL;
-    const uint64_t n0 = x & m, n1 = (x >> 1) & m, n2 = (x >> 2) & m, n3 = (x >> 3) & m;  // A C G T one-hot bits
-    const uint64_t sum = n0 + n1 + n2 + n3;
-    const uint64_t inv = ((sum >> 1) | (sum >> 2) | ~sum) & m;     // not exactly one bit set
-    uint64_t code = (n3 | n1) | ((n2 | n1) << 1);                  // T,C -> bit0 ; G,C -> bit1
-    code = (code & ~(inv * 3)) | (inv << 2);
-    return code;
-}
 
 template <int TP, int RB, int NT>
 __global__ void __launch_bounds__(NT) k_pile_dense(DenseArgs A) {

@@ -136,16 +136,17 @@ typedef struct himut_run_stats {
     double ms_bqsum;            /* k_read_filters: whole-read BQ stream (qv), cs-vs-SEQ check, read filters */
     double ms_hap;              /* k_read_hap (phase only) */
     double ms_emit;             /* k_emit_candidates + k_window_index */
-    double ms_sweep;            /* candidate sort + k_cand_windows + k_gather_columns (pile columns -> column store) */
+    double ms_index;            /* candidate sort, position bitmap + rank, column windows / offsets */
+    double ms_capture;          /* k_stream_capture: streams every read once, fills the column store */
     double ms_eval;             /* k_eval_columns: counts, ordered likelihood sums, genotype, filters */
     double ms_finalize;         /* cross-chunk som_seen / counters / compaction */
     int64_t n_reads;
     int64_t read_bases;         /* sum of qlen */
     int64_t positions;          /* sum over chunks of (end - start + 1) */
-    int64_t n_tiles;
+    int64_t n_unique_positions; /* reserved */
     int64_t n_candidates;       /* evaluated candidates before the cross-chunk pass */
     int64_t n_records;
-    int64_t sweep_row_bases;    /* column-store slots gathered (candidate columns x reads in their windows) */
+    int64_t column_slots;       /* column-store slots (unique candidate positions x reads in their windows) */
 } himut_run_stats;
 
 int himut_abi_version(void);

@@ -51,9 +51,8 @@ def test_golden_cases(worker, case):
     recs, log = _run_hip(worker, batch, util.chunks_of(exp), p, pon, com, util.phase_of(exp))
     got = caller.records_to_tuples(exp["contig"], recs)
     want = util.expected_tuples(exp)
+    assert got == want, _diff(got, want) + " | log {} want {}".format(log, exp["log"])
     assert log == exp["log"]
-    assert len(got) == len(want), _diff(got, want)
-    assert got == want, _diff(got, want)
 
 
 def _oracle_vs_hip(worker, cfg, chunks=None, overrides=None, md=52, qlim=None, with_sets=False, phase_block=0):
