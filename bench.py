@@ -105,15 +105,25 @@ def main():
     import torch  # before libhimut_hip.so: both must bind to one HIP runtime
     import torch.distributed as dist
     import numpy as np
+    # rehearsal knobs (not used by the driver): HIMUT_BENCH_BACKEND=gloo runs the N > 1 code path
+    # on a box with one GPU, every rank on cuda:0
+    backend = os.environ.get("HIMUT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from himut_amd import bamlib, caller, synth, util as hutil
+    from himut_amd import dist as hdist
 
     # ---- synthetic workload (BASELINE.json configs[1] shape; one contig per rank)
     t_gen = time.perf_counter()
-    cfg = synth.SynthConfig(seed=2 + rank, contig_len=a.contig_len, depth=a.depth, name="chr20")
+    names = ["chr{}".format(20 + k) for k in range(world)]   # one chr20-sized contig per rank
+    cfg = synth.SynthConfig(seed=2 + rank, contig_len=a.contig_len, depth=a.depth, name=names[rank])
     sample = synth.generate(cfg)
     batch = sample.batch
     chunks = [(c[1], c[2]) for c in hutil.chunkloci((batch.name, 0, batch.length))]
@@ -134,29 +144,24 @@ def main():
     ctx.push_reads(batch)                     # inputs resident in HBM before the timed region
     t_h2d = time.perf_counter() - t_h2d
 
-    gather_buf = None
-
-    def step():
+    def step(materialize=False):
         ctx.run()
         if world > 1:
-            # final gather of the per-contig record buffers to rank 0 over RCCL/xGMI
+            # final gather of the per-contig record buffers + counters to rank 0 (RCCL over xGMI)
             _, n = ctx.records_device()
-            counts = torch.zeros(world, dtype=torch.int64, device="cuda")
-            mine = torch.tensor([n], dtype=torch.int64, device="cuda")
-            dist.all_gather_into_tensor(counts, mine)
-            cnt = counts.tolist()
-            mx = max(cnt)
-            send = torch.empty(max(mx, 1) * 64, dtype=torch.uint8, device="cuda")
-            ctx.copy_records_to_device(send.data_ptr(), mx)
-            recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-            dist.gather(send, recv, dst=0)
-            return cnt
+            if backend == "nccl":
+                return hdist.gather_contig_results({batch.name: (None, ctx.log())}, names, rank, world,
+                                                   device_buffers={batch.name: (ctx, n)}, materialize=materialize)
+            return hdist.gather_contig_results({batch.name: (ctx.records(), ctx.log())}, names, rank, world,
+                                               materialize=materialize)
         return None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    gathered = None
 
     for _ in range(a.warmup):
         step()
@@ -171,20 +176,25 @@ def main():
             stage_ms.setdefault(k, []).append(st[k])
     barrier()
     elapsed = time.perf_counter() - t0
+    gathered = step(materialize=True) if world > 1 else None   # untimed: host copy of the gathered records
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     st = ctx.stats()
     log = ctx.log()
     totals = torch.tensor([st["positions"], log[1], st["read_bases"], st["n_records"]], dtype=torch.float64,
-                          device="cuda")
+                          device=red_dev)
     if world > 1:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     positions, cand_sites, read_bases, n_records = [float(x) for x in totals.tolist()]
 
     if rank == 0:
+        if world > 1:   # the gathered result must hold every rank's contig
+            assert gathered is not None and sorted(gathered) == sorted(names)
+            assert sum(len(v[0]) for v in gathered.values()) == int(n_records)
         ms_per_step = elapsed / a.steps * 1e3
         mbp_s = positions / 1e6 / (elapsed / a.steps)
         avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}

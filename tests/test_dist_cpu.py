@@ -1,0 +1,68 @@
+"""The N > 1 path on CPU: contig packing and the final gather of per-contig record
+buffers to rank 0 (gloo, world_size 2; the GPU run uses the same code over RCCL)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from himut_amd import dist as hdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch.distributed as dist
+from himut_amd import dist as hdist
+from himut_amd._ffi import RECORD_DTYPE
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+lens = {"chr1": 900, "chr2": 500, "chr10": 450, "chrX": 300, "chrM": 0}
+assign = hdist.lpt_assign(lens, world)
+def fake(c):
+    n = lens[c] // 100
+    r = np.zeros(n, RECORD_DTYPE)
+    r["tpos"] = np.arange(n) + len(c) * 1000
+    r["gq"] = len(c)
+    r["counts"][:, 0] = np.arange(n)
+    return r, [len(c) + k for k in range(15)]
+local = {c: fake(c) for c in assign[rank]}
+res = hdist.gather_contig_results(local, list(lens), rank, world)
+if rank == 0:
+    assert list(res) == ["chr1", "chr2", "chr10", "chrM", "chrX"], list(res)
+    for c in lens:
+        recs, log = res[c]
+        want, wlog = fake(c)
+        assert np.array_equal(recs, want), c
+        assert log == wlog, c
+    print("GATHER_OK", json.dumps(assign))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_lpt_assign_balances_and_is_deterministic():
+    lens = {"chr{}".format(i): l for i, l in enumerate([248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114,
+                                                        107, 101, 90, 83, 80, 58, 64, 46, 50, 156, 57], 1)}
+    a = hdist.lpt_assign(lens, 8)
+    assert sorted(c for r in a for c in r) == sorted(lens)
+    loads = [sum(lens[c] for c in r) for r in a]
+    assert max(loads) <= 1.12 * (sum(lens.values()) / 8)
+    assert a == hdist.lpt_assign(lens, 8)
+    assert hdist.lpt_assign({"a": 5}, 4) == [["a"], [], [], []]
+
+
+def test_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2", HIMUT_NO_TORCH="0")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "GATHER_OK" in outs[0]
