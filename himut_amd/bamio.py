@@ -1,0 +1,134 @@
+"""BAM in / out for the hot path (ctypes front-end of csrc/bam_ingest.cpp).
+
+``read_bam`` stands where the reference opens ``pysam.AlignmentFile`` and wraps every record
+in ``bamlib.BAM`` (caller.py:267,299-300; bamlib.py:14-32, 89-129): it returns the header
+facts the driver needs (contig sizes, sample name) and one ReadBatch per contig, reads in
+file order.  ``write_bam`` turns read batches (e.g. synthetic ones) into a BAM file."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build
+from .readbatch import ReadBatch
+
+_lib = None
+
+
+class _WriteContig(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("length", ctypes.c_int64), ("n", ctypes.c_int64)] + [
+        (k, ctypes.c_void_p) for k in ("tstart", "qstart", "qlen", "mapq", "flag", "qid", "qoff", "cs_off", "seq",
+                                       "bq", "cs", "tp")]
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = build.build_host()
+        L = ctypes.CDLL(path)
+        L.bam_load.restype = ctypes.c_void_p
+        L.bam_load.argtypes = [ctypes.c_char_p]
+        for f in ("bam_error", "bam_header_text"):
+            getattr(L, f).restype = ctypes.c_char_p
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        L.bam_ref_name.restype = ctypes.c_char_p
+        L.bam_ref_name.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        L.bam_n_ref.restype = ctypes.c_int64
+        L.bam_n_ref.argtypes = [ctypes.c_void_p]
+        for f in ("bam_ref_len", "bam_ref_nreads", "bam_ref_bases_padded", "bam_ref_cs_bytes"):
+            getattr(L, f).restype = ctypes.c_int64
+            getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        L.bam_count.restype = ctypes.c_int64
+        L.bam_count.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.bam_ref_copy.restype = None
+        L.bam_ref_copy.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 13
+        L.bam_free.restype = None
+        L.bam_free.argtypes = [ctypes.c_void_p]
+        L.bam_write.restype = ctypes.c_int
+        L.bam_write.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_WriteContig), ctypes.c_int64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class BamFile:
+    """All contigs of one BAM, loaded once."""
+
+    def __init__(self, path):
+        L = _load()
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        h = L.bam_load(path.encode())
+        try:
+            err = L.bam_error(h).decode()
+            if err:
+                raise ValueError("{}: {}".format(path, err))
+            if L.bam_count(h, 0):
+                # the reference does line.get_tag("cs") on every record (bamlib.py:32)
+                raise KeyError("tag 'cs' not present in {} records of {}".format(L.bam_count(h, 0), path))
+            if L.bam_count(h, 2):
+                raise ValueError("{} is not coordinate sorted".format(path))
+            self.header_text = L.bam_header_text(h).decode("utf-8", "replace")
+            self.tname2tsize = {}
+            self.batches = {}
+            for i in range(L.bam_n_ref(h)):
+                name = L.bam_ref_name(h, i).decode()
+                length = L.bam_ref_len(h, i)
+                self.tname2tsize[name] = length
+                n = L.bam_ref_nreads(h, i)
+                tot = L.bam_ref_bases_padded(h, i)
+                csb = L.bam_ref_cs_bytes(h, i)
+                a = dict(tstart=np.zeros(n, np.int32), tend=np.zeros(n, np.int32), qstart=np.zeros(n, np.int32),
+                         qlen=np.zeros(n, np.int32), mapq=np.zeros(n, np.uint8), flag=np.zeros(n, np.uint16),
+                         qid=np.zeros(n, np.int32), qoff=np.zeros(n, np.int64), cs_off=np.zeros(n + 1, np.int64),
+                         seq=np.zeros(tot // 2, np.uint8), bq=np.zeros(tot, np.uint8), cs=np.zeros(csb, np.uint8),
+                         tp=np.zeros(n, np.uint8))
+                L.bam_ref_copy(h, i, *[_p(a[k]) for k in ("tstart", "tend", "qstart", "qlen", "mapq", "flag", "qid",
+                                                           "qoff", "cs_off", "seq", "bq", "cs", "tp")])
+                self.batches[name] = ReadBatch(name=name, length=length, **a)
+        finally:
+            L.bam_free(h)
+
+    def sample(self):
+        """SM of the first @RG line (bamlib.get_sample, bamlib.py:89-106)."""
+        for line in self.header_text.strip().split("\n"):
+            if line.startswith("@RG"):
+                for f in line.split():
+                    if f.startswith("SM"):
+                        return f.split(":")[1]
+        raise ValueError("SM field is missing; provide a BAM file with an @RG group")
+
+
+_cache = {}
+
+
+def read_bam(path):
+    key = (os.path.abspath(path), os.path.getmtime(path))
+    if key not in _cache:
+        _cache.clear()
+        _cache[key] = BamFile(path)
+    return _cache[key]
+
+
+def read_contig(path, chrom):
+    return read_bam(path).batches[chrom]
+
+
+def write_bam(path, batches, sample="syn"):
+    """batches: list of ReadBatch in @SQ order.  CIGARs are derived from the cs tags."""
+    L = _load()
+    arr = (_WriteContig * len(batches))()
+    keep = []
+    for k, b in enumerate(batches):
+        cols = [np.ascontiguousarray(x) for x in (b.tstart, b.qstart, b.qlen, b.mapq, b.flag, b.qid, b.qoff, b.cs_off,
+                                                  b.seq, b.bq, b.cs, b.tp)]
+        keep.append(cols)
+        nm = b.name.encode()
+        keep.append(nm)
+        arr[k] = _WriteContig(nm, int(b.length), int(b.n), *[_p(x) for x in cols])
+    rc = L.bam_write(path.encode(), sample.encode(), arr, len(batches))
+    if rc:
+        raise IOError("bam_write failed ({})".format(rc))

