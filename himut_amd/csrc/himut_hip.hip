@@ -87,10 +87,10 @@ struct himut_ctx {
     // reads
     int64_t n = 0, cs_bytes = 0, seq_bytes = 0, bq_bytes = 0, read_bases = 0;
     std::vector<int32_t> h_tstart, h_tend, h_prefmax;
-    bool unique_qnames = true;
+    bool unique_qnames = true, any_longcs = false;
     DevBuf d_tstart, d_tend, d_qstart, d_qlen, d_mapq, d_flag, d_qid, d_qoff, d_csoff, d_seq, d_bq, d_cs, d_prefmax;
     // derived
-    DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs;
+    DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs, d_order;
     // run state
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_winlo_c, d_winn_c, d_winoff_c, d_colstore, d_posbits_c, d_posrank, d_poppc, d_tmp2;
@@ -265,7 +265,9 @@ int check_device_err(himut_ctx* c, int bits) {
 
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, c->params, &sc->err);
+    hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
+    if (c->any_longcs)
+        hipLaunchKernelGGL(k_check_longcs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, &sc->err);
     HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
     hipLaunchKernelGGL(k_read_filters, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
     HCHECK(hipEventRecord(c->ev[EV_BQSUM], st));
@@ -640,6 +642,8 @@ int himut_push_reads(himut_ctx* c, const himut_read_batch* b) {
         upload(c->d_seq, b->seq, (size_t)b->seq_bytes, st); upload(c->d_bq, b->bq, (size_t)b->bq_bytes, st);
         upload(c->d_cs, b->cs, (size_t)b->cs_bytes, st);
         upload(c->d_prefmax, c->h_prefmax, st);
+        // long-form cs ('=' operations) needs one extra checking kernel; find out once, on the host
+        c->any_longcs = memchr(b->cs, '=', (size_t)b->cs_bytes) != nullptr;
         HCHECK(hipStreamSynchronize(st));
         c->have_reads = true;
         c->h_recs_valid = false;

@@ -2,8 +2,8 @@
 //
 // Pipeline for one contig (himut_run in himut_hip.hip launches them in order):
 //
-//   k_parse_cs         one thread per read: cs tag -> gapless segments + mismatch list +
-//                      identity (cslib.py:7-64, bamlib.py:47-63)
+//   k_parse_cs         one wave per read, wave-parallel tokenizer: cs tag -> gapless segments +
+//                      mismatch list + identity (cslib.py:7-64, bamlib.py:47-63)
 //   k_read_filters     one wave per read, 16-byte coalesced loads: sum of BQ over the whole
 //                      query (np.mean, bamlib.py:34-36) = the HBM stream of the path; cs vs SEQ
 //                      check of every substitution; read filters of caller.py:310-317
@@ -61,6 +61,7 @@ constexpr uint32_t SEG_INS = 2;
 constexpr uint8_t RF_SECONDARY = 1;
 constexpr uint8_t RF_PASS = 2;
 constexpr uint8_t RF_IDENT_OK = 4;
+constexpr uint8_t RF_LONGCS = 8;
 
 constexpr uint8_t REC_GERM = 1;        // dropped as germline (caller.py:338-345): counted, no record
 constexpr uint8_t REC_SUPPRESSED = 2;  // tpos already in som_seen from an earlier chunk
@@ -185,172 +186,285 @@ __device__ __forceinline__ unsigned long long wave_reserve(unsigned long long* c
 }
 
 // ---------------------------------------------------------------------------------------
-// cs tokenizer.  Mirrors the regex of cslib.py:8  (:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+).
-// Each thread reads its tag through a private 128-byte window in LDS (dword k of thread
-// t lives at s_win[k * 256 + t]: conflict-free), refilled 64 bytes at a time; the next
-// 64 bytes are already in flight in registers while the current ones are consumed.
-struct CsText {
-    const uint8_t* s;
-    uint32_t* w;          // this thread's column of the LDS window
-    int64_t loaded_end;   // text bytes [loaded_end - 128, loaded_end) are in the window
-    uint4 p0, p1, p2, p3; // the 64 bytes after loaded_end
-    uint32_t cw;
-    int ck;
-    __device__ __forceinline__ void fetch(int64_t off) {
-        __builtin_memcpy(&p0, s + off, 16);       // buffers carry 256 bytes of slack
-        __builtin_memcpy(&p1, s + off + 16, 16);
-        __builtin_memcpy(&p2, s + off + 32, 16);
-        __builtin_memcpy(&p3, s + off + 48, 16);
-    }
-    __device__ __forceinline__ void commit() {
-        const int h = (int)((loaded_end >> 6) & 1) * 16;  // which half of the window
-        w[(h + 0) * 256] = p0.x; w[(h + 1) * 256] = p0.y; w[(h + 2) * 256] = p0.z; w[(h + 3) * 256] = p0.w;
-        w[(h + 4) * 256] = p1.x; w[(h + 5) * 256] = p1.y; w[(h + 6) * 256] = p1.z; w[(h + 7) * 256] = p1.w;
-        w[(h + 8) * 256] = p2.x; w[(h + 9) * 256] = p2.y; w[(h + 10) * 256] = p2.z; w[(h + 11) * 256] = p2.w;
-        w[(h + 12) * 256] = p3.x; w[(h + 13) * 256] = p3.y; w[(h + 14) * 256] = p3.z; w[(h + 15) * 256] = p3.w;
-        loaded_end += 64;
-        ck = -1;
-        fetch(loaded_end);
-    }
-    __device__ __forceinline__ CsText(const uint8_t* p, uint32_t* win) : s(p), w(win), loaded_end(0), cw(0), ck(-1) {
-        fetch(0);
-        commit();
-    }
-    __device__ __forceinline__ int at(int64_t i) {
-        while (i >= loaded_end) commit();
-        const int k = (int)((i >> 2) & 31);
-        if (k != ck) { cw = w[k * 256]; ck = k; }
-        return (int)((cw >> (8 * (i & 3))) & 255u);
-    }
-};
+// k_parse_cs: one WAVE per read, a wave-parallel cs tokenizer.
+//
+// The tag is consumed 1 KB per step, 16 bytes per lane.  Operation starts are the bytes
+// ':' '*' '+' '-' '=' (the alternatives of the reference's regex, cslib.py:8; payload bytes
+// are digits or letters and can never be one of them), found by every lane in its own 16
+// bytes and compacted into an LDS list with one wave scan.  An operation is complete when
+// the NEXT start (or the end of the tag) is known, so lane k takes operation k of the
+// list: kind = its first byte, payload = the bytes up to the next start.  Reference and
+// query offsets are wave prefix sums of the per-operation advances; the mismatch list
+// (cslib.py:47-64) and the gapless segments are written at offsets that come from two more
+// scans.  Only a handful of scalars (running offsets, the open aligned run, the unfinished
+// last operation) carry from one step to the next.
 
-struct CsOp {
-    int kind;     // ':' '*' '=' '+' '-' ; 0 on error
-    int len;      // run length / letters
-    int ref, alt; // '*' only, upper case
-    int64_t text; // offset of the letters ('=' '+' '-')
-};
+constexpr int PB = 1024;  // cs bytes per step
 
-__device__ __forceinline__ int64_t cs_next(CsText& s, int64_t i, int64_t n, CsOp& op) {
-    const int c = s.at(i);
-    op.kind = 0;
-    if (c == ':') {
-        int64_t j = i + 1;
-        int64_t v = 0;
-        while (j < n) {
-            const int d = s.at(j);
-            if (d < '0' || d > '9') break;
-            v = v * 10 + (d - '0');
-            j++;
-        }
-        if (j == i + 1) return n;
-        op.kind = ':'; op.len = (int)v;
-        return j;
-    }
-    if (c == '*') {
-        if (i + 2 >= n) return n;
-        const int a = s.at(i + 1), b = s.at(i + 2);
-        if (!(a >= 'a' && a <= 'z') || !(b >= 'a' && b <= 'z')) return n;
-        op.kind = '*'; op.len = 1; op.ref = a - 32; op.alt = b - 32;
-        return i + 3;
-    }
-    if (c == '=' || c == '+' || c == '-') {
-        int64_t j = i + 1;
-        while (j < n && is_alpha(s.at(j))) j++;
-        if (j == i + 1) return n;
-        op.kind = c; op.len = (int)(j - i - 1); op.text = i + 1;
-        return j;
-    }
-    return n;
+__device__ __forceinline__ int wave_incl_add(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
+    return v;
 }
+__device__ __forceinline__ int wave_incl_max(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d, 64); if (lane >= d) v = max(v, t); }
+    return v;
+}
+__device__ __forceinline__ bool cs_is_start(int c) { return c == ':' || c == '*' || c == '+' || c == '-' || c == '='; }
+__device__ __forceinline__ bool cs_is_digit(int c) { return c >= '0' && c <= '9'; }
 
-// ---------------------------------------------------------------------------------------
-// k_parse_cs: thread per read.  cs -> gapless segments, mismatch list, identity.
 __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err) {
-    __shared__ uint32_t s_win[32 * 256];
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
+    __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
     const int64_t cs0 = R.cs_off[r];
     const int64_t sb = (cs0 >> 1) + r;
     ReadMeta M;
     M.tstart = R.tstart[r]; M.tend = R.tend[r]; M.nseg = 0; M.flags = 0; M.segbase = sb; M.qoff = R.qoff[r];
     if (R.flag[r] & 0x100) {  // bamlib.py:17
-        M.flags = RF_SECONDARY;
-        D.rflag[r] = RF_SECONDARY; D.nseg[r] = 0; D.nmis[r] = 0; D.meta[r] = M;
+        if (lane == 0) {
+            M.flags = RF_SECONDARY;
+            D.rflag[r] = RF_SECONDARY; D.nseg[r] = 0; D.nmis[r] = 0; D.meta[r] = M;
+        }
         return;
     }
-    const int64_t n = R.cs_off[r + 1] - cs0;
-    CsText s(R.cs + cs0, s_win + threadIdx.x);
+    const int n = (int)(R.cs_off[r + 1] - cs0);
+    const uint8_t* cs = R.cs + cs0;
+    uint8_t* txt = s_txt[wv];
+    int32_t* starts = s_start[wv];
     Seg* segs = D.segs + sb;
     int32_t* mis = D.mis + sb;
     uint32_t* mq = D.mq + sb;
-    const int64_t qo = M.qoff;
-    int64_t t = M.tstart, q = R.qstart[r];
     const int32_t qlen = R.qlen[r];
-    int ns = 0, nm = 0;
-    int64_t match = 0, mism = 0;
-    bool open = false, pending_ins = false;
-    Seg cur = {0, 0, 0, 0};
-    int bad = 0;
-    int64_t i = 0;
-    while (i < n) {
-        CsOp op;
-        i = cs_next(s, i, n, op);
-        if (op.kind == 0) { bad = HIMUT_ERR_CS; break; }
-        if (op.kind == ':' || op.kind == '=' || op.kind == '*') {
-            if (!open) {
-                cur.t0 = (int32_t)t; cur.q0 = (int32_t)q; cur.len = 0; cur.flags = pending_ins ? SEG_INS : 0;
-                pending_ins = false; open = true;
-            }
-            if (op.kind == '*') {
-                const int aa = char2allele(op.alt);
-                if (aa < 0) bad = HIMUT_ERR_BASE;                                      // caller.py:62
-                if (op.ref != 'N') {
-                    const int ra = char2allele(op.ref);
-                    if (ra < 0) bad = HIMUT_ERR_BASE;                                  // bamlib.py:188
-                    mis[nm] = (int32_t)(t + 1);                                        // cslib.py:56-60
-                    mq[nm] = ((uint32_t)q << 5) | 16u | ((uint32_t)(ra & 3) << 2) | (uint32_t)(aa & 3);
-                    nm++;
-                }
-                mism += 1;
-            } else {
-                if (op.kind == '=') {  // long form: letters must agree with SEQ
-                    for (int k = 0; k < op.len; k++)
-                        if (upper(R.cs[cs0 + op.text + k]) != nib2char(nib_at(R.seq, qo + q + k))) bad = HIMUT_ERR_CS;
-                }
-                match += op.len;
-            }
-            cur.len += op.len; t += op.len; q += op.len;
-        } else {
-            if (open) { segs[ns++] = cur; open = false; }
-            if (op.kind == '+') {
-                if (pending_ins) bad = HIMUT_ERR_CS;  // two insertions in a row: unsupported
-                pending_ins = true;
-                mis[nm] = (int32_t)(t + 1); mq[nm] = (uint32_t)q << 5; nm++;
-                q += op.len; mism += op.len;
-            } else {
-                Seg d = {(int32_t)t, (int32_t)q, op.len, SEG_DEL | (pending_ins ? SEG_INS : 0u)};
-                pending_ins = false;
-                segs[ns++] = d;
-                mis[nm] = (int32_t)(t + 1); mq[nm] = (uint32_t)q << 5; nm++;
-                t += op.len; mism += op.len;
+    // wave-uniform running state
+    int t = M.tstart, q = R.qstart[r];
+    int ns = 0, nm = 0, bad = 0;
+    long long match = 0, mism = 0;
+    bool have_carry = false; int carry_start = 0, carry_kind = 0;     // unfinished last operation of the previous step
+    bool aligned_open = false; int run_t0 = 0, run_q0 = 0; bool run_ins = false;  // the aligned run still growing
+    int last_kind = 0;                                                 // kind of the last finished operation
+    bool has_long = false;
+
+    for (int base = 0; base < n; base += PB) {
+        const int nb = min(PB, n - base);
+        // ---- text of this step (and the 32 bytes before it) into LDS
+        {
+            uint4 v;
+            __builtin_memcpy(&v, cs + base + 16 * lane, 16);       // buffers carry 256 bytes of slack
+            *reinterpret_cast<uint4*>(txt + 32 + 16 * lane) = v;
+            if (lane < 2) {
+                uint4 b = make_uint4(0, 0, 0, 0);
+                if (base >= 32) __builtin_memcpy(&b, cs + base - 32 + 16 * lane, 16);
+                *reinterpret_cast<uint4*>(txt + 16 * lane) = b;
             }
         }
-        if (bad) break;
+        __builtin_amdgcn_wave_barrier();
+        // ---- operation starts in this lane's 16 bytes
+        uint32_t mask16 = 0;
+        int last_start = -1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int pos = 16 * lane + i;
+            const int c = txt[32 + pos];
+            if (pos < nb) {
+                if (cs_is_start(c)) { mask16 |= 1u << i; last_start = base + pos; }
+                else if (!cs_is_digit(c) && !is_alpha(c)) bad = HIMUT_ERR_CS;
+            }
+        }
+        const int cnt = __popc(mask16);
+        const int incl = wave_incl_add(cnt, lane);
+        const int total = __shfl(incl, 63, 64);
+        const int off0 = have_carry ? 1 : 0;
+        if (have_carry && lane == 0) starts[0] = carry_start;
+        {
+            int w = off0 + incl - cnt;
+            uint32_t mk = mask16;
+            while (mk) { const int i = __ffs((int)mk) - 1; mk &= mk - 1; starts[w++] = base + 16 * lane + i; }
+        }
+        const int m = off0 + total;
+        const bool last_block = base + PB >= n;
+        if (last_block && lane == 0) starts[m] = n;
+        const int nops = last_block ? m : m - 1;
+        __builtin_amdgcn_wave_barrier();
+        if (base == 0 && (m == 0 || starts[0] != 0)) bad = HIMUT_ERR_CS;   // the tag does not begin with an operation
+        if (__ballot(bad != 0)) break;
+        // ---- operations, 64 per round
+        for (int k0 = 0; k0 < nops; k0 += 64) {
+            const int k = k0 + lane;
+            const bool valid = k < nops;
+            int s = 0, e = 0, kind = 0, len = 0, dt = 0, dq = 0, ref = 0, alt = 0;
+            if (valid) {
+                s = starts[k]; e = starts[k + 1];
+                kind = (k == 0 && have_carry) ? carry_kind : (int)txt[32 + (s - base)];
+                len = e - s - 1;
+                if (kind == ':') {
+                    if (len < 1 || len > 9) bad = HIMUT_ERR_CS;
+                    else {
+                        int v = 0;
+                        for (int i = 0; i < len; i++) {
+                            const int c = txt[32 + (s + 1 + i - base)];
+                            if (!cs_is_digit(c)) bad = HIMUT_ERR_CS;
+                            v = v * 10 + (c - '0');
+                        }
+                        dt = v; dq = v;
+                    }
+                } else if (kind == '*') {
+                    const int a = txt[32 + (s + 1 - base)], b = (len >= 2) ? (int)txt[32 + (s + 2 - base)] : 0;
+                    if (len != 2 || !(a >= 'a' && a <= 'z') || !(b >= 'a' && b <= 'z')) bad = HIMUT_ERR_CS;   // \*[a-z][a-z]
+                    ref = a - 32; alt = b - 32;
+                    dt = 1; dq = 1;
+                } else {
+                    if (len < 1) bad = HIMUT_ERR_CS;
+                    if (kind == '=') { dt = len; dq = len; }
+                    else if (kind == '+') dq = len;
+                    else dt = len;
+                }
+            }
+            const bool indel = valid && (kind == '+' || kind == '-');
+            const bool sub = valid && kind == '*';
+            // reference / query offset of every operation
+            const int it = wave_incl_add(dt, lane), iq = wave_incl_add(dq, lane);
+            const int tk = t + it - dt, qk = q + iq - dq;           // at the operation
+            const int ta = t + it, qa = q + iq;                     // after it
+            // previous operation's kind, previous indel in this round
+            int prev_kind = __shfl_up(kind, 1, 64);
+            if (lane == 0) prev_kind = last_kind;
+            const int pidx = wave_incl_max(indel ? lane : -1, lane);
+            int Pk = __shfl_up(pidx, 1, 64);
+            if (lane == 0) Pk = -1;
+            const int src = Pk < 0 ? 0 : Pk;
+            const int p_ta = __shfl(ta, src, 64), p_qa = __shfl(qa, src, 64), p_kind = __shfl(kind, src, 64);
+            // segments: an indel closes the aligned run before it; a deletion is a segment of its own
+            int nseg_here = 0;
+            Seg sg_run = {0, 0, 0, 0}, sg_del = {0, 0, 0, 0};
+            bool run_before = false;
+            if (indel) {
+                run_before = Pk >= 0 ? (lane - 1 - Pk) > 0 : (aligned_open || lane > 0);
+                if (run_before) {
+                    const int rt0 = Pk >= 0 ? p_ta : (aligned_open ? run_t0 : t), rq0 = Pk >= 0 ? p_qa : (aligned_open ? run_q0 : q);
+                    const bool rins = Pk >= 0 ? (p_kind == '+') : (aligned_open ? run_ins : (last_kind == '+'));
+                    sg_run.t0 = rt0; sg_run.q0 = rq0; sg_run.len = tk - rt0; sg_run.flags = rins ? SEG_INS : 0u;
+                    nseg_here++;
+                }
+                if (kind == '-') {
+                    sg_del.t0 = tk; sg_del.q0 = qk; sg_del.len = len; sg_del.flags = SEG_DEL | (prev_kind == '+' ? SEG_INS : 0u);
+                    nseg_here++;
+                } else if (prev_kind == '+') bad = HIMUT_ERR_CS;    // two insertions in a row: unsupported
+            }
+            const int iseg = wave_incl_add(nseg_here, lane);
+            if (nseg_here) {
+                int w = ns + iseg - nseg_here;
+                if (run_before) segs[w++] = sg_run;
+                if (kind == '-') segs[w] = sg_del;
+            }
+            // mismatch list (cslib.py:54-62): substitutions with a non-N reference base, all indels
+            int aa = 0, ra = 0;
+            if (sub) {
+                aa = char2allele(alt);
+                if (aa < 0) bad = HIMUT_ERR_BASE;                    // caller.py:62
+                if (ref != 'N') { ra = char2allele(ref); if (ra < 0) bad = HIMUT_ERR_BASE; }   // bamlib.py:188
+            }
+            const bool ismis = indel || (sub && ref != 'N');
+            const int imis = wave_incl_add(ismis ? 1 : 0, lane);
+            if (ismis) {
+                const int w = nm + imis - 1;
+                mis[w] = tk + 1;
+                mq[w] = sub ? (((uint32_t)qk << 5) | 16u | ((uint32_t)(ra & 3) << 2) | (uint32_t)(aa & 3)) : ((uint32_t)qk << 5);
+            }
+            // identity counts (bamlib.py:47-63)
+            long long dmatch = (valid && (kind == ':' || kind == '=')) ? dt : 0;
+            long long dmism = sub ? 1 : (indel ? len : 0);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { dmatch += __shfl_xor(dmatch, d, 64); dmism += __shfl_xor(dmism, d, 64); }
+            match += dmatch; mism += dmism;
+            if (__ballot(valid && kind == '=')) has_long = true;
+            // ---- carry the round's end state
+            const int nvalid = min(64, nops - k0);
+            const unsigned long long ib = __ballot(indel);
+            t = __shfl(ta, nvalid - 1, 64); q = __shfl(qa, nvalid - 1, 64);
+            ns += __shfl(iseg, 63, 64); nm += __shfl(imis, 63, 64);
+            if (ib) {
+                const int L = 63 - __clzll((long long)ib);
+                run_t0 = __shfl(ta, L, 64); run_q0 = __shfl(qa, L, 64); run_ins = __shfl(kind, L, 64) == '+';
+                aligned_open = L < nvalid - 1;
+            } else if (!aligned_open) {
+                // the run opens at the first operation of this round
+                run_t0 = __shfl(tk, 0, 64); run_q0 = __shfl(qk, 0, 64); run_ins = last_kind == '+';
+                aligned_open = true;
+            }
+            last_kind = __shfl(kind, nvalid - 1, 64);
+            if (__ballot(bad != 0)) break;
+        }
+        if (__ballot(bad != 0)) break;
+        if (!last_block) {
+            if (m > 0) {
+                have_carry = true;
+                carry_start = starts[m - 1];
+                carry_kind = (m == 1 && off0 == 1) ? carry_kind : (int)txt[32 + (carry_start - base)];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    if (open) segs[ns++] = cur;
-    if (pending_ins) { Seg z = {(int32_t)t, (int32_t)q, 0, SEG_INS}; segs[ns++] = z; }
-    if (!bad && (t != M.tend || q > qlen)) bad = HIMUT_ERR_CS;  // cs inconsistent with CIGAR / SEQ
-    if (bad) { set_err(err, bad); ns = 0; nm = 0; }
-    // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow in k_read_filters
-    const double ident = (double)match / (double)(match + mism);
-    uint8_t fl = 0;
-    if (!bad && !(ident < P.p.min_sequence_identity)) fl = RF_IDENT_OK;
-    M.nseg = ns; M.flags = fl;
-    D.nseg[r] = ns;
-    D.nmis[r] = nm;
-    D.rflag[r] = fl;
-    D.meta[r] = M;
+    // a reduction of the lanes' error codes
+    {
+        int b = bad;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) b = max(b, __shfl_xor(b, d, 64));
+        bad = b;
+    }
+    if (!bad) {
+        // end of the tag: close the open run; an insertion at the very end is a marker segment
+        if (lane == 0) {
+            if (aligned_open) { Seg z = {run_t0, run_q0, t - run_t0, run_ins ? SEG_INS : 0u}; segs[ns] = z; }
+            else if (last_kind == '+') { Seg z = {t, q, 0, SEG_INS}; segs[ns] = z; }
+        }
+        if (aligned_open || last_kind == '+') ns++;
+        if (t != M.tend || q > qlen) bad = HIMUT_ERR_CS;   // cs inconsistent with CIGAR / SEQ
+    }
+    if (lane == 0) {
+        if (bad) { set_err(err, bad); ns = 0; nm = 0; }
+        // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow in k_read_filters
+        const double ident = (double)match / (double)(match + mism);
+        uint8_t fl = 0;
+        if (!bad && !(ident < P.p.min_sequence_identity)) fl = RF_IDENT_OK;
+        if (has_long) fl |= RF_LONGCS;
+        M.nseg = ns; M.flags = fl;
+        D.nseg[r] = ns;
+        D.nmis[r] = nm;
+        D.rflag[r] = fl;
+        D.meta[r] = M;
+    }
+}
+
+// long-form tags ('=' with the matched bases spelled out): the letters must be the bases
+// SEQ holds, because the pile takes match bases from SEQ (cslib.py:24 takes them from cs).
+// Thread per flagged read; minimap2 --cs=short (what himut asks for) never gets here.
+__global__ void __launch_bounds__(256) k_check_longcs(Reads R, Derived D, int* err) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n || !(D.rflag[r] & RF_LONGCS)) return;
+    const uint8_t* cs = R.cs + R.cs_off[r];
+    const int64_t n = R.cs_off[r + 1] - R.cs_off[r];
+    int64_t q = R.qstart[r];
+    const int64_t qo = R.qoff[r];
+    int64_t i = 0;
+    while (i < n) {
+        const int c = cs[i];
+        int64_t j = i + 1;
+        while (j < n && !cs_is_start(cs[j])) j++;
+        const int64_t len = j - i - 1;
+        if (c == ':') { int64_t v = 0; for (int64_t k = i + 1; k < j; k++) v = v * 10 + (cs[k] - '0'); q += v; }
+        else if (c == '*') q += 1;
+        else if (c == '+') q += len;
+        else if (c == '=') {
+            for (int64_t k = 0; k < len; k++)
+                if (upper(cs[i + 1 + k]) != nib2char(nib_at(R.seq, qo + q + k))) { set_err(err, HIMUT_ERR_CS); return; }
+            q += len;
+        }
+        i = j;
+    }
 }
 
 // ---------------------------------------------------------------------------------------

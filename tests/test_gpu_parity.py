@@ -181,3 +181,48 @@ def test_error_codes_mirror_reference_failures(worker):
     with pytest.raises(_ffi.HimutError) as e:
         worker.call_contig(b, [(0, 1000)])
     assert e.value.code == 5
+
+
+def test_full_size_chr20_properties_and_prefix_parity(worker):
+    """BASELINE.json configs[1] at full size (64.4 Mb, 30x): size-independent properties on
+    the whole result, and bit-exact parity with the oracle on the first 8 Mb of chunks."""
+    from oracle import oracle as O
+    from himut_amd import bamlib, synth, util as hutil
+    from himut_amd.readbatch import ReadBatch
+    cfg = synth.SynthConfig(seed=2, contig_len=64_444_167, name="chr20")
+    s = synth.generate(cfg)
+    b = s.batch
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((b.name, 0, b.length))]
+    assert len(chunks) == 323 and chunks[0] == (1, 200000) and chunks[-1][1] == b.length - 2
+    ql, qu, md = bamlib.get_thresholds({b.name: b}, [b.name], {b.name: b.length})
+    p = dict(util.CALL_DEFAULTS, qlen_lower_limit=ql, qlen_upper_limit=qu, md_threshold=md)
+    rs = np.random.RandomState(9)
+    from himut_amd import caller
+    sites = [(int(x) + 1, chr(r), chr(a)) for x, r, a in zip(s.snp_pos[::2], s.snp_ref[::2], s.snp_alt[::2])]
+    extra = [(int(rs.randint(1, b.length)), "ACGT"[i], "ACGT"[j]) for i, j in rs.randint(0, 4, (6000, 2)) if i != j]
+    pon, com = caller.site_keys(extra), caller.site_keys(sites)
+    recs, log = _run_hip(worker, b, chunks, p, pon, com)
+    recs2, log2 = _run_hip(worker, b, chunks, p, pon, com)
+    assert log == log2 and np.array_equal(recs.view(np.uint8), recs2.view(np.uint8))      # idempotent
+    # counters partition the candidates (caller.py:328-605)
+    assert log[1] == log[2] + log[3] + log[4] + log[5] + log[6] + log[7]
+    assert log[6] == log[8] + log[9] + log[10] + log[11] + log[12] + log[13] + log[14]
+    # sorted by (tpos, ref, alt) in ASCII order, one record per key, statuses in range
+    key = recs["tpos"].astype(np.int64) * 65536 + recs["ref"].astype(np.int64) * 256 + recs["alt"]
+    assert np.all(np.diff(key) > 0)
+    assert recs["status"].max() <= 10 and np.all(recs["flags"] == 0)
+    d = recs["counts"]
+    assert np.all(d[:, :4].sum(1) >= 1)
+    # prefix parity: oracle on the reads of the first 40 chunks
+    nch = 40
+    end = chunks[nch - 1][1]
+    n = int(np.searchsorted(b.tstart, end, side="left"))
+    tot = int(b.qoff[n - 1] + ((int(b.qlen[n - 1]) + 31) & ~31))
+    sub = ReadBatch(name=b.name, length=b.length, tstart=b.tstart[:n], tend=b.tend[:n], qstart=b.qstart[:n],
+                    qlen=b.qlen[:n], mapq=b.mapq[:n], flag=b.flag[:n], qid=b.qid[:n], qoff=b.qoff[:n],
+                    cs_off=b.cs_off[:n + 1], seq=b.seq[:tot // 2], bq=b.bq[:tot], cs=b.cs[:int(b.cs_off[n])], tp=b.tp[:n])
+    orecs, olog = O.call(sub, chunks[:nch], p, p["germline_snv_prior"], pon, com)
+    mine = recs[recs["chunk"] < nch]
+    assert len(mine) == len(orecs)
+    for name in ("tpos", "chunk", "gq", "ref", "alt", "gt0", "gt1", "status", "gt_state", "counts", "bqsum"):
+        assert np.array_equal(mine[name], orecs[name]), name
