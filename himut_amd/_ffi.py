@@ -74,7 +74,7 @@ def lib():
     if _lib is not None:
         return _lib
     _maybe_import_torch_first()
-    path = build.HIP_LIB
+    path = os.environ.get("HIMUT_HIP_LIB_OVERRIDE") or build.HIP_LIB   # override: diagnostic builds only
     if not os.path.exists(path):
         path = build.build_hip()
     L = ctypes.CDLL(path)

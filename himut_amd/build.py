@@ -54,8 +54,6 @@ def build_hip(force=False, verbose=False):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result",
            "-I", INCLUDE, "-I", CSRC, "-o", HIP_LIB] + srcs
-    if os.environ.get("HIMUT_STAMPS") == "1":   # diagnostic build: per-phase cycle stamps in k_pileup_sweep
-        cmd.insert(1, "-DHIMUT_STAMPS")
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     out = _run(cmd)

@@ -804,61 +804,38 @@ struct CaptureArgs {
     uint16_t* colstore;
 };
 
-constexpr int CQ = 192;    // per-wave hit queue entries
-constexpr int CBW = 1024;  // bitmap words of the read's reference span kept in LDS (32768 positions)
-constexpr int CSG = 32;    // segments of the read kept in LDS
+constexpr int CLQ = 128;   // candidate list entries per wave (circular, power of two)
+constexpr int CSG = 48;    // segments per LDS window
+constexpr int CNB = 4;     // ring of 1024-base blocks (qualities + packed bases) per wave
 
-struct CapQueue {
-    uint32_t* pos;   // rpos of the hit
-    uint32_t* val;   // slot value | (candidate bits below rpos in its bitmap word) << 16
-    int n;           // wave-uniform length
-};
-
-// resolve up to 64 queued hits: rank -> window -> slot
-__device__ __forceinline__ void cap_flush(CapQueue& Q, int count, const PosIndex& X, uint16_t* colstore, int32_t r, int lane) {
-    if (lane < count) {
-        const uint32_t rpos = Q.pos[lane];
-        const uint32_t v = Q.val[lane];
-        const uint32_t u = X.rank[rpos >> 5] + (v >> 16);
-        const int32_t lo = X.ulo[u];
-        const uint32_t off = X.uoff[u];
-        colstore[(int64_t)off + (r - lo)] = (uint16_t)(v & 0xffffu);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int rest = Q.n - count;   // < 64 by construction of cap_push
-    uint32_t p0 = 0, v0 = 0;
-    if (lane < rest) { p0 = Q.pos[count + lane]; v0 = Q.val[count + lane]; }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < rest) { Q.pos[lane] = p0; Q.val[lane] = v0; }
-    __builtin_amdgcn_wave_barrier();
-    Q.n = rest;
+// inclusive wave prefix sum on the DPP network: four shifts inside each row of 16 lanes,
+// then the row totals are carried across with the two row broadcasts
+__device__ __forceinline__ int wave_incl_add_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
 }
 
-// appends the lanes' hits in lane order
-__device__ __forceinline__ void cap_push(CapQueue& Q, bool have, uint32_t rpos, uint32_t val, const PosIndex& X,
-                                         uint16_t* colstore, int32_t r, int lane) {
-    const unsigned long long bal = __ballot(have);
-    if (!bal) return;
-    if (have) {
-        const int slot = Q.n + __popcll(bal & ((1ULL << lane) - 1ULL));
-        Q.pos[slot] = rpos; Q.val[slot] = val;
-    }
-    Q.n += __popcll(bal);
-    __builtin_amdgcn_wave_barrier();
-    if (Q.n >= 64) cap_flush(Q, 64, X, colstore, r, lane);
-}
-
-// One wave per read.  The read's aligned bases are streamed in query order, 1 KB of
-// qualities + 512 B of packed bases per step (16 bases per lane, 16-byte / 8-byte aligned
-// coalesced loads, the next step's loads issued before the current step is consumed).
-// The segment list and the candidate-position bitmap under the read sit in LDS, so
-// mapping a base to its reference position and probing it costs no memory round trip.
-// Hits are queued in LDS and resolved to column-store slots 64 at a time.
+// One wave per read, driven by the candidate-position bitmap under the read.
+//
+// The read's reference span is walked 2048 positions (64 bitmap words, one per lane) at a
+// time.  The set bits are compacted -- one wave prefix sum -- into an LDS list of
+// (position, unique-position rank), so everything after that runs one candidate per lane
+// with all lanes busy: the candidate's gapless segment comes from a binary search over the
+// read's segment list in LDS, the segment turns the position into a query offset, and the
+// base and its quality are picked out of an LDS ring that holds the read's qualities and
+// packed bases around the current query offset.  The ring is fed in query order with 1 KB +
+// 512 B coalesced loads issued three blocks ahead of their use, so every byte of the read
+// is fetched exactly once and HBM latency is covered by the loads in flight.
 __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
-    __shared__ uint32_t s_qpos[4][CQ];
-    __shared__ uint32_t s_qval[4][CQ];
-    __shared__ uint32_t s_bits[4][CBW];
-    __shared__ Seg s_seg[4][CSG];
+    __shared__ __align__(16) uint8_t s_rbq[4][CNB * 1024];
+    __shared__ __align__(16) uint8_t s_rsq[4][CNB * 512];
+    __shared__ __align__(16) Seg s_seg[4][CSG + 1];
+    __shared__ uint2 s_list[4][CLQ];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Reads& R = A.R;
     const PosIndex& X = A.X;
@@ -866,124 +843,148 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     if (r64 >= R.n) return;
     const int32_t r = (int32_t)r64;
     const ReadMeta M = A.D.meta[r];
+    const int32_t qstart = R.qstart[r], qlen = R.qlen[r];
     if ((M.flags & RF_SECONDARY) || M.nseg <= 0) return;
     const Seg* gsegs = A.D.segs + M.segbase;
     const int ns = M.nseg;
-    const bool seg_lds = ns <= CSG;
-    CapQueue Q; Q.pos = s_qpos[wv]; Q.val = s_qval[wv]; Q.n = 0;
-    // segment list and the bitmap words under the read -> LDS, one coalesced sweep each
-    if (seg_lds && lane < ns) s_seg[wv][lane] = gsegs[lane];
-    const int64_t w_lo = M.tstart >> 5;
-    const int nwl = (int)min((int64_t)CBW, ((int64_t)(M.tend + 32) >> 5) - w_lo + 2);
-    uint32_t* lbits = s_bits[wv];
-    for (int k = lane; k < nwl; k += 64) lbits[k] = X.bits[w_lo + k];
-    __builtin_amdgcn_wave_barrier();
-#define CAP_SEG(j) (seg_lds ? s_seg[wv][(j)] : gsegs[(j)])
-#define CAP_WORD(w) ((((w) - w_lo) >= 0 && ((w) - w_lo) < nwl) ? lbits[(w) - w_lo] : X.bits[(w)])
     const int64_t qo = M.qoff;
-    // query range of the aligned segments (soft clips are never touched)
-    int32_t q_lo = 0x7fffffff, q_hi = 0;
-    for (int j = 0; j < ns; j++) {
-        const Seg sg = CAP_SEG(j);
-        if (!(sg.flags & SEG_DEL) && sg.len > 0) { q_lo = min(q_lo, sg.q0); q_hi = max(q_hi, sg.q0 + sg.len); }
-    }
-    // the first step's loads go out before anything else
-    int32_t c0 = q_lo & ~15;
-    uint4 bq_n = make_uint4(0, 0, 0, 0);
-    uint2 sq_n = make_uint2(0, 0);
-    if (c0 + lane * 16 < q_hi) {
-        bq_n = *reinterpret_cast<const uint4*>(R.bq + qo + c0 + lane * 16);      // qoff % 32 == 0
-        sq_n = *reinterpret_cast<const uint2*>(R.seq + ((qo + c0 + lane * 16) >> 1));
-    }
-    // ---- deletions and trailing insertion markers (no query bases involved)
-    for (int j = 0; j < ns; j++) {
-        const Seg sg = CAP_SEG(j);
-        if (sg.flags & SEG_DEL) {
-            for (int i0 = 0; i0 < sg.len; i0 += 64) {
-                const int i = i0 + lane;
-                bool have = false;
-                uint32_t rpos = 0, val = 0;
-                if (i < sg.len) {
-                    rpos = (uint32_t)(sg.t0 + i);
-                    const int64_t w = rpos >> 5;
-                    const uint32_t wbits = CAP_WORD(w);
-                    if ((wbits >> (rpos & 31)) & 1u) {
-                        have = true;
-                        val = CELL_DEL | ((i == 0 && (sg.flags & SEG_INS)) ? CELL_INS : 0u);
-                        val |= (uint32_t)__popc(wbits & ((1u << (rpos & 31)) - 1u)) << 16;
+    uint8_t* rbq = s_rbq[wv];
+    uint8_t* rsq = s_rsq[wv];
+    Seg* lseg = s_seg[wv];
+    uint2* list = s_list[wv];
+
+#define CAP_LOAD(B, S, BLK) do { const int32_t _q = ((BLK) << 10) + lane * 16; B = make_uint4(0, 0, 0, 0); S = make_uint2(0, 0); \
+        if (_q < qlen) { B = *reinterpret_cast<const uint4*>(R.bq + qo + _q); S = *reinterpret_cast<const uint2*>(R.seq + ((qo + _q) >> 1)); } } while (0)
+#define CAP_SEGWIN() do { if (lane <= nw) { int4 z = make_int4(0x7fffffff, 0, 0, 0); if (jb + lane < ns) z = *reinterpret_cast<const int4*>(gsegs + jb + lane); \
+        *reinterpret_cast<int4*>(lseg + lane) = z; } } while (0)
+
+    // ring state: blocks [max(vb, hb - CNB), hb) are in LDS; hb, hb+1, hb+2 are in flight
+    int hb = qstart >> 10, vb = hb;
+    uint4 p0b, p1b, p2b;
+    uint2 p0s, p1s, p2s;
+    CAP_LOAD(p0b, p0s, hb); CAP_LOAD(p1b, p1s, hb + 1); CAP_LOAD(p2b, p2s, hb + 2);
+    // segment window [jb, jb + nw) plus a sentinel that carries the next segment's start
+    int jb = 0, nw = min(ns, CSG);
+    CAP_SEGWIN();
+    // bitmap words of the read's span, tend included (a trailing insertion is counted there)
+    const int64_t w_lo = M.tstart >> 5, w_hi = min((int64_t)(M.tend >> 5), X.nwords - 1);
+    const int nrounds = (int)((w_hi - w_lo) >> 6) + 1;
+    uint32_t nb = 0, nr = 0;
+    if (w_lo + lane <= w_hi) { nb = X.bits[w_lo + lane]; nr = X.rank[w_lo + lane]; }
+    int head = 0, n = 0;   // the list: entries head .. head + n - 1 (mod CLQ)
+    __builtin_amdgcn_wave_barrier();
+
+    for (int rd = 0; rd <= nrounds; rd++) {          // the last turn only drains the list
+        const int64_t w = w_lo + (int64_t)rd * 64 + lane;
+        uint32_t bits = nb, rk = nr;
+        nb = 0; nr = 0;
+        if (rd + 1 < nrounds && w + 64 <= w_hi) { nb = X.bits[w + 64]; nr = X.rank[w + 64]; }
+        if (rd == nrounds) bits = 0;
+        if (w == w_lo) {   // candidates in front of the read still count towards the rank
+            const uint32_t keep = ~0u << (M.tstart & 31);
+            rk += (uint32_t)__popc(bits & ~keep);
+            bits &= keep;
+        }
+        if (w == (int64_t)(M.tend >> 5)) bits &= (2u << (M.tend & 31)) - 1u;
+        const int cnt = __popc(bits);
+        const int incl = wave_incl_add_dpp(cnt);
+        int done = 0, basecnt = 0;
+        while (true) {
+            // ---- compaction: the lanes whose bits still fit go into the list
+            const bool fit = lane >= done && n + incl - basecnt <= CLQ;
+            const int nfit = __popcll(__ballot(fit));
+            if (fit) {
+                int slot = head + n + (incl - cnt - basecnt);
+                uint32_t b = bits, uu = rk;
+                while (b) {
+                    const int k = __ffs((int)b) - 1;
+                    b &= b - 1;
+                    list[slot & (CLQ - 1)] = make_uint2((uint32_t)(w * 32 + k), uu);
+                    slot++; uu++;
+                }
+            }
+            if (nfit) {
+                const int inc = __shfl(incl, done + nfit - 1, 64);
+                n += inc - basecnt; basecnt = inc; done += nfit;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- dense batches: full ones always, the remainder when room is needed or at the end
+            while (n >= 64 || ((done < 64 || rd == nrounds) && n > 0)) {
+                const int bn = min(n, 64);
+                const bool act = lane < bn;
+                uint32_t rpos = 0, u = 0;
+                if (act) { const uint2 e = list[(head + lane) & (CLQ - 1)]; rpos = e.x; u = e.y; }
+                // the segment that holds rpos: last one that starts at or before it
+                int4 sg = make_int4(0, 0, 0, 0);   // t0, q0, len, flags
+                bool res = !act;
+                while (true) {
+                    const int32_t cover = lseg[nw].t0;
+                    if (!res && (int32_t)rpos < cover) {
+                        int lo = 0, hi = nw;
+                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lseg[mid].t0 <= (int32_t)rpos) lo = mid; else hi = mid; }
+                        sg = *reinterpret_cast<const int4*>(lseg + lo);
+                        res = true;
                     }
+                    if (!__ballot(!res)) break;
+                    jb += nw; nw = min(ns - jb, CSG);        // slide the window forward
+                    __builtin_amdgcn_wave_barrier();
+                    CAP_SEGWIN();
+                    __builtin_amdgcn_wave_barrier();
                 }
-                cap_push(Q, have, rpos, val, X, A.colstore, r, lane);
-            }
-        } else if (sg.len == 0 && (sg.flags & SEG_INS)) {
-            bool have = false;
-            const uint32_t rpos = (uint32_t)sg.t0;
-            uint32_t val = 0;
-            if (lane == 0) {
-                const int64_t w = rpos >> 5;
-                const uint32_t wbits = CAP_WORD(w);
-                if ((wbits >> (rpos & 31)) & 1u) {
-                    have = true;
-                    val = CELL_EMPTY | CELL_INS | ((uint32_t)__popc(wbits & ((1u << (rpos & 31)) - 1u)) << 16);
+                bool store = false, isq = false;
+                uint32_t val = 0;
+                int32_t q = 0;
+                if (act) {
+                    const int32_t d = (int32_t)rpos - sg.x;
+                    const uint32_t insb = (d == 0 && ((uint32_t)sg.w & SEG_INS)) ? CELL_INS : 0u;
+                    if ((uint32_t)sg.w & SEG_DEL) { if (d < sg.z) { store = true; val = CELL_DEL | insb; } }
+                    else if (sg.z == 0) { if (d == 0 && insb) { store = true; val = CELL_EMPTY | CELL_INS; } }
+                    else if (d < sg.z) { store = true; isq = true; q = sg.y + d; val = insb; }
                 }
+                // bring the ring up to the highest query offset of the batch (offsets rise with the lane)
+                const unsigned long long qm = __ballot(isq);
+                if (qm) {
+                    const int need = __shfl(q, 63 - __clzll((long long)qm), 64) >> 10;
+                    if (need - hb > 2 * CNB) {           // a long jump in query space: restart the ring there
+                        hb = need - 2; vb = hb;
+                        CAP_LOAD(p0b, p0s, hb); CAP_LOAD(p1b, p1s, hb + 1); CAP_LOAD(p2b, p2s, hb + 2);
+                    }
+                    while (hb <= need) {
+                        const int sl = hb & (CNB - 1);
+                        *reinterpret_cast<uint4*>(rbq + sl * 1024 + lane * 16) = p0b;
+                        *reinterpret_cast<uint2*>(rsq + sl * 512 + lane * 8) = p0s;
+                        p0b = p1b; p0s = p1s; p1b = p2b; p1s = p2s;
+                        CAP_LOAD(p2b, p2s, hb + 3);
+                        hb++;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (isq) {
+                    const int blk = q >> 10;
+                    uint32_t qv, sb;
+                    if (blk >= max(vb, hb - CNB)) {
+                        qv = rbq[(blk & (CNB - 1)) * 1024 + (q & 1023)];
+                        sb = rsq[(blk & (CNB - 1)) * 512 + ((q & 1023) >> 1)];
+                    } else {                              // behind the ring (a batch spread over > 3 blocks)
+                        qv = R.bq[qo + q];
+                        sb = R.seq[(qo + q) >> 1];
+                    }
+                    const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
+                    val |= (uint32_t)nib2allele(nib) | (qv << 8);
+                }
+                if (store) {
+                    const int32_t lo = X.ulo[u];
+                    const uint32_t off = X.uoff[u];
+                    A.colstore[(int64_t)off + (r - lo)] = (uint16_t)val;
+                }
+                head = (head + bn) & (CLQ - 1); n -= bn;
+                __builtin_amdgcn_wave_barrier();
             }
-            cap_push(Q, have, rpos, val, X, A.colstore, r, lane);
+            if (done >= 64) break;
         }
     }
-    // ---- aligned bases, in query order
-    int js = 0;  // first segment that can still overlap the current step
-    for (; c0 < q_hi; c0 += 1024) {
-        const int32_t qa = c0 + lane * 16;   // this lane's bases [qa, qa + 16)
-        const uint4 bqv = bq_n;
-        const uint2 sqv = sq_n;
-        bq_n = make_uint4(0, 0, 0, 0); sq_n = make_uint2(0, 0);
-        if (qa + 1024 < q_hi) {              // next step's loads
-            bq_n = *reinterpret_cast<const uint4*>(R.bq + qo + qa + 1024);
-            sq_n = *reinterpret_cast<const uint2*>(R.seq + ((qo + qa + 1024) >> 1));
-        }
-        // base i of the lane: quality byte i, nibble i (high nibble first inside each byte)
-        const uint64_t sw = ((uint64_t)sqv.y << 32) | sqv.x;
-        const uint64_t nib = ((sw & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((sw >> 4) & 0x0f0f0f0f0f0f0f0fULL);
-        const uint64_t cells = nib16_to_cells(nib);
-        for (int j = js; j < ns; j++) {
-            const Seg sg = CAP_SEG(j);
-            if ((sg.flags & SEG_DEL) || sg.len == 0) continue;
-            if (sg.q0 >= c0 + 1024) break;
-            if (sg.q0 + sg.len <= c0) { js = j + 1; continue; }
-            // overlap of the segment with this lane's 16 bases
-            const int a = max(sg.q0, qa) - qa, b = min(sg.q0 + sg.len, qa + 16) - qa;
-            uint32_t hits = 0;      // bit i: base i sits on a candidate position
-            uint32_t w0 = 0, w1 = 0;
-            int32_t tp = 0;
-            if (a < b) {
-                tp = sg.t0 + (qa + a - sg.q0);            // reference position of base a
-                const int64_t w = tp >> 5;
-                w0 = CAP_WORD(w); w1 = CAP_WORD(w + 1);
-                const uint64_t two = ((uint64_t)w1 << 32) | w0;
-                hits = (uint32_t)((two >> (tp & 31)) & ((1u << (b - a)) - 1u)) << a;
-            }
-            while (__ballot(hits != 0)) {
-                const bool have = hits != 0;
-                uint32_t rpos = 0, val = 0;
-                if (have) {
-                    const int i = __ffs((int)hits) - 1;
-                    hits &= hits - 1;
-                    rpos = (uint32_t)(tp + (i - a));
-                    const uint32_t cell = (uint32_t)(cells >> (4 * i)) & 7u;
-                    const uint32_t qw = (i < 8) ? ((i < 4) ? bqv.x : bqv.y) : ((i < 12) ? bqv.z : bqv.w);
-                    const uint32_t qv = (qw >> (8 * (i & 3))) & 255u;
-                    const uint32_t insb = (rpos == (uint32_t)sg.t0 && (sg.flags & SEG_INS)) ? CELL_INS : 0u;
-                    // candidate bits below rpos inside its own bitmap word (w0: the word of tp, w1: the next)
-                    const uint32_t word = ((rpos >> 5) == ((uint32_t)tp >> 5)) ? w0 : w1;
-                    val = cell | insb | (qv << 8) | ((uint32_t)__popc(word & ((1u << (rpos & 31)) - 1u)) << 16);
-                }
-                cap_push(Q, have, rpos, val, X, A.colstore, r, lane);
-            }
-        }
-    }
-    while (Q.n > 0) cap_flush(Q, min(Q.n, 64), X, A.colstore, r, lane);
-#undef CAP_SEG
-#undef CAP_WORD
+#undef CAP_LOAD
+#undef CAP_SEGWIN
 }
 
 // ---------------------------------------------------------------------------------------
