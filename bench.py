@@ -22,7 +22,7 @@ if ROOT not in sys.path:
 CHR20_LEN = 64_444_167
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # algorithmic HBM bytes per unit of work, per kernel (DESIGN.md "Kernels and their rooflines")
-STAGE_KERNEL = {"ms_parse": "k_parse_cs", "ms_bqsum": "k_read_filters", "ms_emit": "k_emit_candidates",
+STAGE_KERNEL = {"ms_parse": "k_parse_cs", "ms_bqsum": "k_bq_sum", "ms_emit": "k_propose",
                 "ms_capture": "k_stream_capture", "ms_eval": "k_eval_columns"}
 
 

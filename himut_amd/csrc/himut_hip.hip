@@ -57,7 +57,7 @@ void upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
 template <class T>
 void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) { upload(b, v.data(), v.size(), st); }
 
-enum { EV_START = 0, EV_BQSUM, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
+enum { EV_START = 0, EV_FORK, EV_BQ0, EV_BQ1, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
 
 }  // namespace
 
@@ -65,6 +65,7 @@ struct himut_ctx {
     int device = 0;
     int n_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;   // the quality sum runs here, beside the cs decode
     hipEvent_t ev[EV_COUNT] = {};
     std::string err;
 
@@ -74,7 +75,10 @@ struct himut_ctx {
     // inputs
     DevBuf d_lut;
     std::vector<int32_t> cstart, cend;
-    DevBuf d_cstart, d_cend, d_maskoff, d_tileoff, d_sstart, d_sidx, d_spmax, d_rlo, d_rhi, d_pairoff, d_hint;
+    DevBuf d_cstart, d_cend, d_maskoff, d_tileoff, d_sstart, d_sidx, d_spmax, d_rlo, d_rhi, d_pairoff, d_hint, d_crec;
+    std::vector<int32_t> up_cs, up_ce;   // the chunk list the device tables were built for
+    bool tables_valid = false, chunks_in_order = false;
+    int64_t up_positions = 0, up_tiles = 0, up_pairs = 0;
     int64_t nhint = 0;
     std::vector<int64_t> maskoff, tileoff;
     DevBuf d_pon, d_com, d_posbits;
@@ -93,6 +97,7 @@ struct himut_ctx {
     DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs, d_order;
     // run state
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
+    DevBuf d_tilecnt, d_tileoff2;
     DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_winlo_c, d_winn_c, d_winoff_c, d_colstore, d_posbits_c, d_posrank, d_poppc, d_tmp2;
     std::vector<himut_record> h_recs;
     bool h_recs_valid = false;
@@ -174,6 +179,10 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
     const int TP = PD_TP;  // tiles are only used by the dense pile kernel
     const int64_t n = (int64_t)cs.size();
     T.n = n;
+    if (c->tables_valid && cs == c->up_cs && ce == c->up_ce) {   // same chunks, same reads: the tables are on the device
+        T.positions = c->up_positions; T.n_tiles = c->up_tiles; T.npairs = c->up_pairs;
+        return T;
+    }
     c->maskoff.assign(n + 1, 0);
     c->tileoff.assign(n + 1, 0);
     for (int64_t k = 0; k < n; k++) {
@@ -215,19 +224,33 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
             hint[(size_t)b] = (int32_t)j;
         }
     }
+    std::vector<ChunkRec> crec((size_t)n);
+    for (int64_t k = 0; k < n; k++) {
+        const int32_t ci = sidx[k];
+        crec[k].start = cs[ci]; crec[k].end = ce[ci]; crec[k].idx = ci; crec[k].pmaxend = spmax[k];
+        crec[k].maskoff = c->maskoff[ci]; crec[k].pairbase = pairoff[ci] - rlo[ci];
+    }
+    // candidates come out of the mask in (chunk, tpos) order; that is the record order when
+    // no chunk starts before its predecessor's end (the reference's chunking shares only the edge)
+    c->chunks_in_order = true;
+    for (int64_t k = 1; k < n; k++) if (cs[k] < ce[k - 1]) c->chunks_in_order = false;
     hipStream_t st = c->stream;
     upload(c->d_hint, hint, st);
+    upload(c->d_crec, crec, st);
     upload(c->d_cstart, cs, st); upload(c->d_cend, ce, st);
     upload(c->d_maskoff, c->maskoff, st); upload(c->d_tileoff, c->tileoff, st);
     upload(c->d_sstart, sstart, st); upload(c->d_sidx, sidx, st); upload(c->d_spmax, spmax, st);
     upload(c->d_rlo, rlo, st); upload(c->d_rhi, rhi, st); upload(c->d_pairoff, pairoff, st);
     HCHECK(hipStreamSynchronize(st));  // the host vectors above go out of scope
+    c->up_cs = cs; c->up_ce = ce; c->tables_valid = true;
+    c->up_positions = T.positions; c->up_tiles = T.n_tiles; c->up_pairs = T.npairs;
     return T;
 }
 
 Chunks make_chunks(himut_ctx* c, int64_t n) {
     Chunks C;
     C.n = n;
+    C.rec = c->d_crec.as<ChunkRec>();
     C.start = c->d_cstart.as<int32_t>(); C.end = c->d_cend.as<int32_t>();
     C.maskoff = c->d_maskoff.as<int64_t>();
     C.s_start = c->d_sstart.as<int32_t>(); C.s_idx = c->d_sidx.as<int32_t>(); C.s_pmaxend = c->d_spmax.as<int32_t>();
@@ -265,12 +288,17 @@ int check_device_err(himut_ctx* c, int bits) {
 
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {
     hipStream_t st = c->stream;
+    // the quality stream (HBM bound) overlaps the cs decode (VALU bound)
+    HCHECK(hipEventRecord(c->ev[EV_FORK], st));
+    HCHECK(hipStreamWaitEvent(c->side, c->ev[EV_FORK], 0));
+    HCHECK(hipEventRecord(c->ev[EV_BQ0], c->side));
+    hipLaunchKernelGGL(k_bq_sum, dim3(blocks_for(c->n, 4)), dim3(256), 0, c->side, R, D.bqsum);
+    HCHECK(hipEventRecord(c->ev[EV_BQ1], c->side));
     hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
     if (c->any_longcs)
         hipLaunchKernelGGL(k_check_longcs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, &sc->err);
+    HCHECK(hipStreamWaitEvent(st, c->ev[EV_BQ1], 0));
     HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
-    hipLaunchKernelGGL(k_read_filters, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
-    HCHECK(hipEventRecord(c->ev[EV_BQSUM], st));
 }
 
 void alloc_derived(himut_ctx* c) {
@@ -310,8 +338,12 @@ int do_run(himut_ctx* c) {
 
     ChunkTables T = upload_chunks(c, c->cstart, c->cend);
     alloc_derived(c);
-    const size_t mask_bytes = ((size_t)T.positions * 2 + 11) & ~(size_t)3;
+    const int64_t n4 = ((int64_t)T.positions * 2 + 15) / 16;     // the mask in 16-byte pieces (8 positions each)
+    const size_t mask_bytes = (size_t)n4 * 16;
+    const unsigned mtiles = blocks_for(n4, 256);
     c->d_mask.reserve(mask_bytes + 64);
+    c->d_tilecnt.reserve((size_t)mtiles * 4 + 64);
+    c->d_tileoff2.reserve((size_t)mtiles * 4 + 64);
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
 
     Reads R = make_reads(c);
@@ -325,17 +357,26 @@ int do_run(himut_ctx* c) {
     HCHECK(hipMemsetAsync(c->d_mask.p, 0, mask_bytes, st));
     HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
     if (c->n > 0) run_parse_stage(c, R, D, sc);
-    else { HCHECK(hipEventRecord(c->ev[EV_PARSE], st)); HCHECK(hipEventRecord(c->ev[EV_BQSUM], st)); }
+    else HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
     if (phase && T.npairs > 0)
         hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
     HCHECK(hipEventRecord(c->ev[EV_HAP], st));
-    // every substitution op takes at least three characters of cs text, so this bounds the candidate list
-    const int64_t cand_cap = 2 * (c->cs_bytes / 3 + c->n) + 64;
-    c->d_cands.reserve((size_t)cand_cap * sizeof(Cand));
-    if (c->n > 0 && T.n > 0)
-        hipLaunchKernelGGL(k_emit_candidates, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, C, H, c->params,
-                           c->d_mask.as<uint32_t>(), c->d_ccs.as<uint8_t>(), c->d_cands.as<Cand>(), &sc->ncand, cand_cap,
-                           &sc->err);
+    if (c->n > 0)
+        hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, C, H, c->params,
+                           c->d_mask.as<uint32_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
+    // the candidates = the set bits of the mask: bits per tile, then a scan
+    size_t scan_tiles = 0;
+    uint32_t last_tcnt = 0, last_toff = 0;
+    if (n4 > 0) {
+        hipLaunchKernelGGL(k_mask_count, dim3(mtiles), dim3(256), 0, st, c->d_mask.as<uint4>(), n4, c->d_tilecnt.as<uint32_t>());
+        HCHECK(rocprim::exclusive_scan(nullptr, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
+                                       (size_t)mtiles, rocprim::plus<uint32_t>(), st));
+        c->d_tmp2.reserve(scan_tiles + 256);
+        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
+                                       (size_t)mtiles, rocprim::plus<uint32_t>(), st));
+        HCHECK(hipMemcpyAsync(&last_tcnt, c->d_tilecnt.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
+        HCHECK(hipMemcpyAsync(&last_toff, c->d_tileoff2.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
+    }
     // window index for the column kernel
     int32_t maxend = 0;
     for (int32_t e : c->cend) maxend = std::max(maxend, e);
@@ -352,8 +393,7 @@ int do_run(himut_ctx* c) {
     HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
     HCHECK(hipStreamSynchronize(st));
     if (hs.err) return check_device_err(c, hs.err);
-    const int64_t ncand = (int64_t)hs.ncand;
-    if (ncand > cand_cap) return fail(c, HIMUT_ERR_ARG, "internal: candidate list overflow");
+    const int64_t ncand = (int64_t)last_toff + last_tcnt;
     c->d_recs.reserve((size_t)(ncand + 1) * sizeof(himut_record));
     c->d_recs_out.reserve((size_t)(ncand + 1) * sizeof(himut_record));
 
@@ -361,17 +401,24 @@ int do_run(himut_ctx* c) {
     if (ncand > 0) {
         // candidates in the order of the final records (tpos, chunk, ref, alt)
         c->d_keys.reserve((size_t)ncand * 8); c->d_keys2.reserve((size_t)ncand * 8);
+        c->d_cands.reserve((size_t)ncand * sizeof(Cand) + 256);
         c->d_cands2.reserve((size_t)ncand * sizeof(Cand) + 256);
         c->d_emit.reserve((size_t)ncand * 4); c->d_pos.reserve((size_t)ncand * 4);
-        hipLaunchKernelGGL(k_cand_keys, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, c->d_cands.as<Cand>(), ncand,
-                           c->d_keys.as<uint64_t>());
-        HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
-                                         c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
         HCHECK(rocprim::exclusive_scan(nullptr, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
                                        (size_t)ncand, rocprim::plus<uint32_t>(), st));
-        c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
-        HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
-                                         c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
+        if (c->chunks_in_order) {
+            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_mask.as<uint4>(), n4, c->d_tileoff2.as<uint32_t>(),
+                               C, c->d_cands2.as<Cand>(), c->d_keys2.as<uint64_t>());
+            c->d_tmp.reserve(scan_tmp + 256);
+        } else {
+            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_mask.as<uint4>(), n4, c->d_tileoff2.as<uint32_t>(),
+                               C, c->d_cands.as<Cand>(), c->d_keys.as<uint64_t>());
+            HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
+                                             c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
+            c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
+            HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
+                                             c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
+        }
         // bitmap of candidate positions + rank index + per unique position window / column offset
         // the bitmap is probed at every position a read covers, so it spans reads as well as chunks
         int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
@@ -466,8 +513,8 @@ int do_run(himut_ctx* c) {
     himut_run_stats& S = c->stats;
     S.ms_total = ms(EV_START, EV_FINAL);
     S.ms_parse = ms(EV_START, EV_PARSE);
-    S.ms_bqsum = ms(EV_PARSE, EV_BQSUM);
-    S.ms_hap = ms(EV_BQSUM, EV_HAP);
+    S.ms_bqsum = c->n > 0 ? ms(EV_BQ0, EV_BQ1) : 0.0;
+    S.ms_hap = ms(EV_PARSE, EV_HAP);
     S.ms_emit = ms(EV_HAP, EV_EMIT);
     S.ms_index = ms(EV_EMIT, EV_INDEX);
     S.ms_capture = ms(EV_INDEX, EV_GATHER);
@@ -503,6 +550,7 @@ int himut_create(int device, himut_ctx** out) {
         HCHECK(hipGetDeviceProperties(&prop, device));
         c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HCHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         for (auto& e : c->ev) HCHECK(hipEventCreate(&e));
         return HIMUT_OK;
     });
@@ -520,6 +568,7 @@ void himut_destroy(himut_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -646,6 +695,7 @@ int himut_push_reads(himut_ctx* c, const himut_read_batch* b) {
         c->any_longcs = memchr(b->cs, '=', (size_t)b->cs_bytes) != nullptr;
         HCHECK(hipStreamSynchronize(st));
         c->have_reads = true;
+        c->tables_valid = false;   // the chunk tables hold read windows
         c->h_recs_valid = false;
         return HIMUT_OK;
     });

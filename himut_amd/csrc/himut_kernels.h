@@ -4,15 +4,17 @@
 //
 //   k_parse_cs         one wave per read, wave-parallel tokenizer: cs tag -> gapless segments +
 //                      mismatch list + identity (cslib.py:7-64, bamlib.py:47-63)
-//   k_read_filters     one wave per read, 16-byte coalesced loads: sum of BQ over the whole
-//                      query (np.mean, bamlib.py:34-36) = the HBM stream of the path; cs vs SEQ
-//                      check of every substitution; read filters of caller.py:310-317
+//   k_bq_sum           one wave per read, 16-byte coalesced loads: sum of BQ over the whole
+//                      query (np.mean, bamlib.py:34-36); runs beside k_parse_cs on a second stream
 //   k_read_hap         (--phase) one thread per (chunk, read): haplib.py:46-83
-//   k_emit_candidates  one wave per read, lanes = mismatch entries: trim / mismatch-window
-//                      filters (bamlib.py:69-86,222-282); the first read to propose a
-//                      (chunk, tpos, ref, alt) appends it to the candidate list
-//                      (the set() of caller.py:324) using a per-chunk bit mask
-//   k_cand_keys + sort the candidates in the order of the final records
+//   k_propose          one wave per read: read filters of caller.py:310-317, cs vs SEQ check of
+//                      every substitution; lanes = mismatch entries: trim / mismatch-window
+//                      filters (bamlib.py:69-86,222-282); every surviving (chunk, tpos, ref, alt)
+//                      sets its bit in a per-chunk mask (the set() of caller.py:324)
+//   k_mask_count / k_mask_emit + scan
+//                      the set bits of the mask, enumerated in (chunk, tpos, ref, alt) order =
+//                      the candidate list; radix-sorted afterwards only when the chunks are
+//                      not already in coordinate order
 //   k_window_index     per 256-position block: the range of reads that can cover it
 //   k_candpos_set / k_word_popc / k_upos_windows + scans
 //                      bitmap of candidate positions, its rank index, and per unique
@@ -107,8 +109,18 @@ struct ReadMeta {
     int64_t qoff;
 };
 
+// one chunk, in the order of the sorted starts
+struct ChunkRec {
+    int32_t start, end;
+    int32_t idx;        // chunk index
+    int32_t pmaxend;    // running maximum of end up to and including this one
+    int64_t maskoff;    // first mask cell
+    int64_t pairbase;   // pairoff - rlo: + read index = the (chunk, read) pair
+};
+
 struct Chunks {
     int64_t n;
+    const ChunkRec* rec;       // sorted by start
     const int32_t *start, *end;
     const int64_t* maskoff;    // prefix of (end - start + 1)
     const int32_t* s_start;    // starts sorted ascending
@@ -201,14 +213,25 @@ __device__ __forceinline__ unsigned long long wave_reserve(unsigned long long* c
 
 constexpr int PB = 1024;  // cs bytes per step
 
-__device__ __forceinline__ int wave_incl_add(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
+// inclusive wave scans on the DPP network: four shifts inside each row of 16 lanes, then
+// the row totals are carried across with the two row broadcasts
+__device__ __forceinline__ int wave_incl_add(int v, int) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ int wave_incl_max(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d, 64); if (lane >= d) v = max(v, t); }
+__device__ __forceinline__ int wave_incl_max(int v, int) {
+    constexpr int lowest = -0x7fffffff - 1;
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x143, 0xc, 0xf, false));
     return v;
 }
 __device__ __forceinline__ bool cs_is_start(int c) { return c == ':' || c == '*' || c == '+' || c == '-' || c == '='; }
@@ -468,18 +491,15 @@ __global__ void __launch_bounds__(256) k_check_longcs(Reads R, Derived D, int* e
 }
 
 // ---------------------------------------------------------------------------------------
-// k_read_filters: one wave per read.  Streams the read's qualities with 16-byte
-// coalesced loads (np.mean of the whole query, bamlib.py:34-36), checks every
-// substitution of the cs tag against SEQ in parallel, and applies the read filters of
-// caller.py:310-317.
-__global__ void __launch_bounds__(256) k_read_filters(Reads R, Derived D, Params P, int* err) {
+// k_bq_sum: one wave per read; streams the read's qualities with 16-byte coalesced loads
+// (np.mean of the whole query, bamlib.py:34-36).  Needs nothing from the cs decode, so it
+// runs on its own stream beside k_parse_cs: one is bound by HBM, the other by VALU.
+__global__ void __launch_bounds__(256) k_bq_sum(Reads R, uint32_t* bqsum) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R.n) return;
-    const uint8_t fl = D.rflag[r];
-    if (fl & RF_SECONDARY) return;
-    const int64_t qo = R.qoff[r];
-    const uint8_t* base = R.bq + qo;
+    if (R.flag[r] & 0x100) return;
+    const uint8_t* base = R.bq + R.qoff[r];
     const int n = R.qlen[r];
     uint32_t sum = 0;
     for (int o = lane * 16; o < n; o += 64 * 16) {
@@ -494,33 +514,9 @@ __global__ void __launch_bounds__(256) k_read_filters(Reads R, Derived D, Params
             sum += (s2 & 0xffffu) + (s2 >> 16);
         }
     }
-    // substitutions: the base cs names must be the base SEQ holds (caller.py:62 uses cs, the pile uses SEQ)
-    int bad = 0;
-    const int nm = D.nmis[r];
-    const uint32_t* mq = D.mq + seg_base(R, r);
-    for (int e = lane; e < nm; e += 64) {
-        const uint32_t v = mq[e];
-        if (v & 16u) {
-            const int qa = nib2allele(nib_at(R.seq, qo + (v >> 5)));
-            if (qa > 3) bad = HIMUT_ERR_BASE;
-            else if (qa != (int)(v & 3u)) bad = HIMUT_ERR_CS;
-        }
-    }
-    if (bad) set_err(err, bad);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
-    if (lane == 0) {
-        D.bqsum[r] = sum;
-        bool pass = (fl & RF_IDENT_OK) != 0;
-        const double qv = (double)sum / (double)n;                         // bamlib.py:35
-        if (qv < (double)P.p.min_qv) pass = false;
-        if ((int)R.mapq[r] < P.p.min_mapq) pass = false;
-        if (!(P.p.qlen_lower_limit < n && n < P.p.qlen_upper_limit)) pass = false;
-        if (pass) {
-            D.rflag[r] = fl | RF_PASS;
-            D.meta[r].flags = fl | RF_PASS;
-        }
-    }
+    if (lane == 0) bqsum[r] = sum;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -566,156 +562,198 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
 }
 
 // ---------------------------------------------------------------------------------------
-// k_emit_candidates: one wave per read that passed the read filters; lanes = the
-// entries of the read's mismatch list.  For every substitution that survives the trim
-// and mismatch-window filters (bamlib.py:69-86,222-282), and for every chunk that both
-// contains tpos (caller.py:104-108,325) and fetched the read (caller.py:299): set the
-// (ref, alt) bit of the position in that chunk's mask; the lane that sets it first
-// appends the candidate (set() semantics of caller.py:324).
+// k_propose: one wave per read.  Applies the read filters (caller.py:310-317), checks
+// every substitution of the cs tag against SEQ, and for every substitution that survives
+// the trim and mismatch-window filters (bamlib.py:69-86,222-282), and for every chunk that
+// both contains tpos (caller.py:104-108,325) and fetched the read (caller.py:299), sets the
+// (ref, alt) bit of the position in that chunk's mask -- the set() of caller.py:324.
+// Nothing is read back: the atomics carry no return value and the candidates are
+// enumerated from the mask afterwards, so a wave never waits on its own stores.
 constexpr int EMIT_MAXC = 4;   // chunks of one read kept in registers
-constexpr int EMIT_MAXP = 4;   // proposals one lane can hold per round (chunks containing the site)
 
-__global__ void __launch_bounds__(256) k_emit_candidates(Reads R, Derived D, Chunks C, Phase H, Params P,
-                                                         uint32_t* mask, uint8_t* ccs_flag, Cand* cands,
-                                                         unsigned long long* ncand, int64_t cand_cap, int* err) {
-    __shared__ int s_cnt[4];
-    __shared__ unsigned long long s_base;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+__global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, Phase H, Params P, uint32_t* mask,
+                                                 uint8_t* ccs_flag, int* err) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R.n) return;
+    const ReadMeta M = D.meta[r];
+    const int32_t qlen = R.qlen[r];
+    const int mapq = R.mapq[r];
+    const uint32_t bqs = D.bqsum[r];
+    const int nm = D.nmis[r];
+    const int32_t qid = R.qid[r];
+    if (M.flags & RF_SECONDARY) return;
     const bool phase = P.p.phase != 0;
-    ReadMeta M; M.flags = 0; M.tstart = 0; M.tend = 0; M.segbase = 0; M.nseg = 0; M.qoff = 0;
-    if (r < R.n) M = D.meta[r];
-    bool live = (M.flags & RF_PASS) != 0;
+    bool live = (M.flags & RF_IDENT_OK) != 0;                             // bamlib.py:47-63, caller.py:314
+    if ((double)bqs / (double)qlen < (double)P.p.min_qv) live = false;    // bamlib.py:35
+    if (mapq < P.p.min_mapq) live = false;
+    if (!(P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit)) live = false;
     const int32_t ts = M.tstart, te = M.tend;
-    // the chunks that fetched this read (start < tend and end > tstart), newest start first
+
+    // the chunks that fetched this read (start < tend and end > tstart): 16 records of the
+    // sorted table around the look-up hint, one per lane, decided with one ballot
     int nc = 0;
     bool overflow = false;
     int64_t hi = 0;
     int32_t cc[EMIT_MAXC], cst[EMIT_MAXC], cen[EMIT_MAXC];
+    int64_t cmo[EMIT_MAXC];
 #pragma unroll
-    for (int k = 0; k < EMIT_MAXC; k++) { cc[k] = -1; cst[k] = 0; cen[k] = -1; }
-    if (live) {
-        hi = C.hint[min((int64_t)(te > 0 ? te : 0) >> CHUNK_HINT_SHIFT, C.nhint - 1)];
-        while (hi < C.n && C.s_start[hi] < te) hi++;
-        for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts; j--) {
-            const int c = C.s_idx[j];
-            const int32_t e = C.end[c];
-            if (e <= ts) continue;
-            if (phase && H.hap[C.pairoff[c] + (r - C.rlo[c])] == HAP_NONE) continue;   // caller.py:306-309
-            if (nc < EMIT_MAXC) {
-#pragma unroll
-                for (int k = 0; k < EMIT_MAXC; k++) if (k == nc) { cc[k] = c; cst[k] = C.start[c]; cen[k] = e; }
-            } else overflow = true;
-            nc++;
-        }
-        // num_ccs (caller.py:318-320): counted once it passes in any chunk that fetched it
-        if (nc == 0) live = false;
-        else if (lane == 0) ccs_flag[R.qid[r]] = 1;
-    }
-    const int64_t sb = M.segbase;
-    const int32_t* mis = D.mis + sb;
-    const uint32_t* mq = D.mq + sb;
-    const int nm = live ? D.nmis[r] : 0;
-    const int32_t qlen = live ? R.qlen[r] : 1;
-    const double trim_start = floor(P.p.min_trim * (double)qlen);        // bamlib.py:226
-    const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);   // bamlib.py:227
-    const int64_t w = P.p.mismatch_window_size;
-    // rounds of 64 mismatch entries; every round ends with ONE reservation for the whole workgroup
-    int nm_max = nm;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) nm_max = max(nm_max, __shfl_xor(nm_max, d, 64));
-    __shared__ int s_nm[4];
-    if (lane == 0) s_nm[wv] = nm_max;
-    __syncthreads();
-    const int rounds = (max(max(s_nm[0], s_nm[1]), max(s_nm[2], s_nm[3])) + 63) / 64;
-    for (int round = 0; round < rounds; round++) {
-        const int e = round * 64 + lane;
-        Cand mine[EMIT_MAXP];
-        int nmine = 0;
-        if (e < nm) {
-            const uint32_t v = mq[e];
-            const int32_t tp1 = mis[e];
-            const int64_t q = v >> 5;
-            bool ok = (v & 16u) != 0;                                               // substitutions only
-            if (ok && ((double)q < trim_start || (double)q > trim_end)) ok = false;  // bamlib.py:231-242
-            if (ok) {                                                               // bamlib.py:245-282
-                int64_t qs = q - w, qe = q + w, ur, dr;
-                if (qs < 0) { ur = w + qs; dr = w - qs; }
-                else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - q; }
-                else { ur = w; dr = w; }
-                const int32_t ms = (int32_t)(tp1 - ur), me = (int32_t)(tp1 + dr);
-                // bisect_right(me) - bisect_left(ms) - 1 on the sorted list; the entry itself is inside [ms, me]
-                int lo = e, up = e + 1;
-                while (lo > 0 && mis[lo - 1] >= ms) lo--;
-                while (up < nm && mis[up] <= me) up++;
-                if ((int64_t)(up - lo) - 1 > P.p.max_mismatch_count) ok = false;
+    for (int k = 0; k < EMIT_MAXC; k++) { cc[k] = -1; cst[k] = 0; cen[k] = -1; cmo[k] = 0; }
+    if (live && C.n > 0) {
+        const int64_t h0 = C.hint[min((int64_t)(te > 0 ? te : 0) >> CHUNK_HINT_SHIFT, C.nhint - 1)];
+        const int64_t wlo = max(h0 - 8, (int64_t)0);
+        const int64_t j = wlo - 1 + lane;               // lane 0: the record in front of the window
+        ChunkRec rec;
+        rec.start = 0x7fffffff; rec.end = -0x7fffffff - 1; rec.idx = -1; rec.pmaxend = -0x7fffffff - 1; rec.maskoff = 0; rec.pairbase = 0;
+        if (lane <= 16 && j >= 0 && j < C.n) rec = C.rec[j];
+        // complete when no chunk in front of the window reaches the read and none behind it starts inside
+        const bool front_ok = __shfl(rec.pmaxend, 0, 64) <= ts;
+        const bool back_ok = wlo + 16 >= C.n || __ballot(lane >= 1 && lane <= 16 && rec.start >= te) != 0ULL;
+        bool take = lane >= 1 && lane <= 16 && rec.idx >= 0 && rec.start < te && rec.end > ts;
+        if (take && phase && H.hap[rec.pairbase + r] == HAP_NONE) take = false;     // caller.py:306-309
+        const unsigned long long tk = __ballot(take);
+        nc = __popcll(tk);
+        if (!front_ok || !back_ok || nc > EMIT_MAXC) {
+            // unusual chunk tables (deep nesting, a read across many chunks): walk the table per entry
+            overflow = true;
+            hi = h0;
+            while (hi < C.n && C.rec[hi].start < te) hi++;
+            nc = 0;
+            for (int64_t jj = hi - 1; jj >= 0 && C.rec[jj].pmaxend > ts; jj--) {
+                const ChunkRec q = C.rec[jj];
+                if (q.end <= ts) continue;
+                if (phase && H.hap[q.pairbase + r] == HAP_NONE) continue;
+                nc++;
             }
-            if (ok) {
-                const int bit = (int)(v & 15u);
-                auto propose = [&](int c, int32_t cs_) {
-                    // 16 mask bits per position, two positions per 32-bit word
-                    const int64_t cell = C.maskoff[c] + (tp1 - cs_);
-                    const unsigned int m = (1u << bit) << ((cell & 1) ? 16 : 0);
-                    const unsigned int old = atomicOr(mask + (cell >> 1), m);
-                    if (!(old & m)) {
-                        Cand cd; cd.tpos = tp1; cd.chunk_bit = ((uint32_t)c << 4) | (uint32_t)bit;
-                        if (nmine < EMIT_MAXP) {
+        } else {
+            unsigned long long rest = tk;
 #pragma unroll
-                            for (int k = 0; k < EMIT_MAXP; k++) if (k == nmine) mine[k] = cd;
-                            nmine++;
-                        } else {  // more chunks share this site than a lane can buffer: reserve on its own
-                            const unsigned long long slot = atomicAdd(ncand, 1ULL);
-                            if ((int64_t)slot < cand_cap) cands[slot] = cd;
-                        }
-                    }
-                };
-                if (!overflow) {
-#pragma unroll
-                    for (int k = 0; k < EMIT_MAXC; k++)
-                        if (cc[k] >= 0 && cst[k] <= tp1 && tp1 <= cen[k]) propose(cc[k], cst[k]);
-                } else {
-                    // a read that lies in more chunks than fit the registers: walk the table again
-                    for (int64_t j = hi - 1; j >= 0 && C.s_pmaxend[j] > ts; j--) {
-                        const int c = C.s_idx[j];
-                        const int32_t cs_ = C.start[c], ce_ = C.end[c];
-                        if (ce_ <= ts || !(cs_ <= tp1 && tp1 <= ce_)) continue;
-                        if (phase && H.hap[C.pairoff[c] + (r - C.rlo[c])] == HAP_NONE) continue;
-                        propose(c, cs_);
-                    }
+            for (int k = 0; k < EMIT_MAXC; k++) {
+                if (rest) {
+                    const int src = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    cc[k] = __shfl(rec.idx, src, 64); cst[k] = __shfl(rec.start, src, 64); cen[k] = __shfl(rec.end, src, 64);
+                    cmo[k] = ((int64_t)__shfl((int)(rec.maskoff >> 32), src, 64) << 32) | (uint32_t)__shfl((int)rec.maskoff, src, 64);
                 }
             }
         }
-        // exclusive prefix of nmine inside the wave, wave totals through LDS, one atomic per workgroup
-        int incl = nmine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-        const int wtot = __shfl(incl, 63, 64);
-        if (lane == 0) s_cnt[wv] = wtot;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-            s_base = tot ? atomicAdd(ncand, (unsigned long long)tot) : 0ULL;
+        // num_ccs (caller.py:318-320): counted once it passes in any chunk that fetched it
+        if (nc == 0) live = false;
+        else if (lane == 0) ccs_flag[qid] = 1;
+    } else live = false;
+
+    const int32_t* mis = D.mis + M.segbase;
+    const uint32_t* mq = D.mq + M.segbase;
+    const double trim_start = floor(P.p.min_trim * (double)qlen);        // bamlib.py:226
+    const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);   // bamlib.py:227
+    const int64_t w = P.p.mismatch_window_size;
+    int bad = 0;
+    for (int e = lane; e < nm; e += 64) {
+        const uint32_t v = mq[e];
+        const int32_t tp1 = mis[e];
+        const int32_t mprev = e > 0 ? mis[e - 1] : -0x7fffffff - 1;
+        const int32_t mnext = e + 1 < nm ? mis[e + 1] : 0x7fffffff;
+        if (!(v & 16u)) continue;                                             // substitutions only
+        const int64_t q = v >> 5;
+        // the base cs names must be the base SEQ holds (caller.py:62 uses cs, the pile uses SEQ)
+        const int qa = nib2allele(nib_at(R.seq, M.qoff + q));
+        if (qa > 3) bad = HIMUT_ERR_BASE;
+        else if (qa != (int)(v & 3u)) bad = HIMUT_ERR_CS;
+        if (!live) continue;
+        if ((double)q < trim_start || (double)q > trim_end) continue;          // bamlib.py:231-242
+        {                                                                     // bamlib.py:245-282
+            int64_t qs = q - w, qe = q + w, ur, dr;
+            if (qs < 0) { ur = w + qs; dr = w - qs; }
+            else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - q; }
+            else { ur = w; dr = w; }
+            const int32_t ms = (int32_t)(tp1 - ur), me = (int32_t)(tp1 + dr);
+            // bisect_right(me) - bisect_left(ms) - 1 on the sorted list; the entry itself is inside [ms, me]
+            int lo = e, up = e + 1;
+            if (mprev >= ms) { lo = e - 1; while (lo > 0 && mis[lo - 1] >= ms) lo--; }
+            if (mnext <= me) { up = e + 2; while (up < nm && mis[up] <= me) up++; }
+            if ((int64_t)(up - lo) - 1 > P.p.max_mismatch_count) continue;
         }
-        __syncthreads();
-        unsigned long long slot = s_base + (unsigned long long)(incl - nmine);
+        const int bit = (int)(v & 15u);
+        if (!overflow) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (k < wv) slot += (unsigned long long)s_cnt[k];
-#pragma unroll
-        for (int k = 0; k < EMIT_MAXP; k++)
-            if (k < nmine && (int64_t)(slot + k) < cand_cap) cands[slot + k] = mine[k];
-        __syncthreads();
+            for (int k = 0; k < EMIT_MAXC; k++)
+                if (cc[k] >= 0 && cst[k] <= tp1 && tp1 <= cen[k]) {
+                    // 16 mask bits per position, two positions per 32-bit word
+                    const int64_t cell = cmo[k] + (tp1 - cst[k]);
+                    atomicOr(mask + (cell >> 1), (1u << bit) << ((cell & 1) ? 16 : 0));
+                }
+        } else {
+            for (int64_t jj = hi - 1; jj >= 0 && C.rec[jj].pmaxend > ts; jj--) {
+                const ChunkRec qr = C.rec[jj];
+                if (qr.end <= ts || !(qr.start <= tp1 && tp1 <= qr.end)) continue;
+                if (phase && H.hap[qr.pairbase + r] == HAP_NONE) continue;
+                const int64_t cell = qr.maskoff + (tp1 - qr.start);
+                atomicOr(mask + (cell >> 1), (1u << bit) << ((cell & 1) ? 16 : 0));
+            }
+        }
     }
+    if (bad) set_err(err, bad);
 }
 
-// sort key of a candidate == sort key of its record: (tpos, chunk, ref, alt) with the
-// alleles in ASCII order (natsorted order of the reference's tuples, caller.py:622)
-__global__ void __launch_bounds__(256) k_cand_keys(const Cand* cands, int64_t n, uint64_t* keys) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Cand c = cands[i];
-    const int bit = (int)(c.chunk_bit & 15u);
-    keys[i] = ((uint64_t)(uint32_t)c.tpos << 28) | ((uint64_t)(c.chunk_bit >> 4) << 4) |
-              ((uint64_t)asc_rank(bit >> 2) << 2) | (uint64_t)asc_rank(bit & 3);
+// ---------------------------------------------------------------------------------------
+// The candidate list = the set bits of the mask.  Two sweeps over the mask (16 bytes = 8
+// positions per thread): bits per 2048-position tile, then -- after a scan of the tile
+// counts -- the candidates themselves, in mask order: chunk, position, then (ref, alt) in
+// ASCII order.  The sort key of a candidate == the sort key of its record: (tpos, chunk,
+// ref, alt), natsorted order of the reference's tuples (caller.py:622).
+__device__ __forceinline__ int popc128(const uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+__global__ void __launch_bounds__(256) k_mask_count(const uint4* mask4, int64_t n4, uint32_t* tilecnt) {
+    __shared__ int s_w[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int c = 0;
+    if (i < n4) c = popc128(mask4[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+}
+
+__global__ void __launch_bounds__(256) k_mask_emit(const uint4* mask4, int64_t n4, const uint32_t* tileoff, Chunks C,
+                                                   Cand* cands, uint64_t* keys) {
+    __shared__ int s_w[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i < n4) v = mask4[i];
+    const int c = popc128(v);
+    const int incl = wave_incl_add(c, lane);
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    if (!c) return;
+    int64_t slot = (int64_t)tileoff[blockIdx.x] + (incl - c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (k < wv) slot += s_w[k];
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+    // the chunk of the thread's first cell; the eight cells may run into the next chunks
+    int64_t cell = i * 8;
+    int64_t ck = upper_bound(C.maskoff, (int64_t)0, C.n + 1, cell) - 1;
+    int64_t cbeg = C.maskoff[ck], cend_ = C.maskoff[ck + 1];
+    int32_t cstart = C.start[ck];
+#pragma unroll
+    for (int p = 0; p < 8; p++, cell++) {
+        const uint32_t m = (words[p >> 1] >> ((p & 1) * 16)) & 0xffffu;
+        if (!m) continue;
+        while (cell >= cend_) { ck++; cbeg = cend_; cend_ = C.maskoff[ck + 1]; cstart = C.start[ck]; }
+        const int32_t tpos = cstart + (int32_t)(cell - cbeg);
+#pragma unroll
+        for (int rk = 0; rk < 16; rk++) {   // (ref, alt) in ASCII order A C G T = alleles 0 3 2 1
+            const int ra = (0x1230 >> (4 * (rk >> 2))) & 15, aa = (0x1230 >> (4 * (rk & 3))) & 15;
+            const int bit = (ra << 2) | aa;
+            if ((m >> bit) & 1u) {
+                Cand cd; cd.tpos = tpos; cd.chunk_bit = ((uint32_t)ck << 4) | (uint32_t)bit;
+                cands[slot] = cd;
+                keys[slot] = ((uint64_t)(uint32_t)tpos << 28) | ((uint64_t)ck << 4) | (uint64_t)rk;
+                slot++;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -808,18 +846,6 @@ constexpr int CLQ = 128;   // candidate list entries per wave (circular, power o
 constexpr int CSG = 48;    // segments per LDS window
 constexpr int CNB = 4;     // ring of 1024-base blocks (qualities + packed bases) per wave
 
-// inclusive wave prefix sum on the DPP network: four shifts inside each row of 16 lanes,
-// then the row totals are carried across with the two row broadcasts
-__device__ __forceinline__ int wave_incl_add_dpp(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // One wave per read, driven by the candidate-position bitmap under the read.
 //
 // The read's reference span is walked 2048 positions (64 bitmap words, one per lane) at a
@@ -887,7 +913,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
         }
         if (w == (int64_t)(M.tend >> 5)) bits &= (2u << (M.tend & 31)) - 1u;
         const int cnt = __popc(bits);
-        const int incl = wave_incl_add_dpp(cnt);
+        const int incl = wave_incl_add(cnt, lane);
         int done = 0, basecnt = 0;
         while (true) {
             // ---- compaction: the lanes whose bits still fit go into the list

@@ -132,11 +132,12 @@ typedef struct himut_record {
  * context's stream, in milliseconds). */
 typedef struct himut_run_stats {
     double ms_total;
-    double ms_parse;            /* k_parse_cs: cs decode */
-    double ms_bqsum;            /* k_read_filters: whole-read BQ stream (qv), cs-vs-SEQ check, read filters */
+    double ms_parse;            /* k_parse_cs (cs decode) with k_bq_sum running beside it on a second stream */
+    double ms_bqsum;            /* k_bq_sum alone: whole-read BQ stream (qv); overlapped, already inside ms_parse */
     double ms_hap;              /* k_read_hap (phase only) */
-    double ms_emit;             /* k_emit_candidates + k_window_index */
-    double ms_index;            /* candidate sort, position bitmap + rank, column windows / offsets */
+    double ms_emit;             /* k_propose (read filters, proposals -> mask), mask bit count + scan, k_window_index */
+    double ms_index;            /* k_mask_emit (+ sort when chunks are out of order), position bitmap + rank,
+                                   column windows / offsets */
     double ms_capture;          /* k_stream_capture: streams every read once, fills the column store */
     double ms_eval;             /* k_eval_columns: counts, ordered likelihood sums, genotype, filters */
     double ms_finalize;         /* cross-chunk som_seen / counters / compaction */
