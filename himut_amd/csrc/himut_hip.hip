@@ -75,7 +75,7 @@ struct himut_ctx {
     // inputs
     DevBuf d_lut;
     std::vector<int32_t> cstart, cend;
-    DevBuf d_cstart, d_cend, d_maskoff, d_tileoff, d_sstart, d_sidx, d_spmax, d_rlo, d_rhi, d_pairoff, d_hint, d_crec;
+    DevBuf d_cstart, d_cend, d_maskoff, d_tileoff, d_sstart, d_sidx, d_spmax, d_rlo, d_rhi, d_pairoff, d_hint, d_crec, d_mtile;
     std::vector<int32_t> up_cs, up_ce;   // the chunk list the device tables were built for
     bool tables_valid = false, chunks_in_order = false;
     int64_t up_positions = 0, up_tiles = 0, up_pairs = 0;
@@ -234,9 +234,24 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
     // no chunk starts before its predecessor's end (the reference's chunking shares only the edge)
     c->chunks_in_order = true;
     for (int64_t k = 1; k < n; k++) if (cs[k] < ce[k - 1]) c->chunks_in_order = false;
+    // mask tiles (2048 cells each): the chunk their first cell belongs to
+    const int64_t n4 = ((int64_t)T.positions * 2 + 15) / 16;
+    const int64_t ntile = std::max<int64_t>(1, (n4 + 255) / 256);
+    std::vector<MaskTile> mtile((size_t)ntile);
+    {
+        int64_t ck = 0;
+        for (int64_t b = 0; b < ntile; b++) {
+            const int64_t cell = b * 2048;
+            while (ck + 1 < n && c->maskoff[ck + 1] <= cell) ck++;
+            MaskTile& m = mtile[(size_t)b];
+            m.ck0 = (int32_t)ck; m.start0 = n > 0 ? cs[ck] : 0;
+            m.off0 = n > 0 ? c->maskoff[ck] : 0; m.off1 = n > 0 ? c->maskoff[ck + 1] : 0; m.pad = 0;
+        }
+    }
     hipStream_t st = c->stream;
     upload(c->d_hint, hint, st);
     upload(c->d_crec, crec, st);
+    upload(c->d_mtile, mtile, st);
     upload(c->d_cstart, cs, st); upload(c->d_cend, ce, st);
     upload(c->d_maskoff, c->maskoff, st); upload(c->d_tileoff, c->tileoff, st);
     upload(c->d_sstart, sstart, st); upload(c->d_sidx, sidx, st); upload(c->d_spmax, spmax, st);
@@ -250,7 +265,7 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
 Chunks make_chunks(himut_ctx* c, int64_t n) {
     Chunks C;
     C.n = n;
-    C.rec = c->d_crec.as<ChunkRec>();
+    C.rec = c->d_crec.as<ChunkRec>(); C.mtile = c->d_mtile.as<MaskTile>();
     C.start = c->d_cstart.as<int32_t>(); C.end = c->d_cend.as<int32_t>();
     C.maskoff = c->d_maskoff.as<int64_t>();
     C.s_start = c->d_sstart.as<int32_t>(); C.s_idx = c->d_sidx.as<int32_t>(); C.s_pmaxend = c->d_spmax.as<int32_t>();

@@ -118,9 +118,19 @@ struct ChunkRec {
     int64_t pairbase;   // pairoff - rlo: + read index = the (chunk, read) pair
 };
 
+// what k_mask_emit needs about a mask tile (2048 cells): the chunk of its first cell
+struct MaskTile {
+    int32_t ck0;      // chunk of the tile's first cell
+    int32_t start0;   // its start
+    int64_t off0;     // its first cell
+    int64_t off1;     // first cell of the next chunk
+    int64_t pad;
+};
+
 struct Chunks {
     int64_t n;
     const ChunkRec* rec;       // sorted by start
+    const MaskTile* mtile;     // per mask tile
     const int32_t *start, *end;
     const int64_t* maskoff;    // prefix of (end - start + 1)
     const int32_t* s_start;    // starts sorted ascending
@@ -237,7 +247,7 @@ __device__ __forceinline__ int wave_incl_max(int v, int) {
 __device__ __forceinline__ bool cs_is_start(int c) { return c == ':' || c == '*' || c == '+' || c == '-' || c == '='; }
 __device__ __forceinline__ bool cs_is_digit(int c) { return c >= '0' && c <= '9'; }
 
-__global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) k_parse_cs(Reads R, Derived D, Params P, int* err) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
     __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -731,11 +741,12 @@ __global__ void __launch_bounds__(256) k_mask_emit(const uint4* mask4, int64_t n
 #pragma unroll
     for (int k = 0; k < 4; k++) if (k < wv) slot += s_w[k];
     const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-    // the chunk of the thread's first cell; the eight cells may run into the next chunks
+    // the chunk of the tile's first cell comes with the tile; cells may run into the next chunks
     int64_t cell = i * 8;
-    int64_t ck = upper_bound(C.maskoff, (int64_t)0, C.n + 1, cell) - 1;
-    int64_t cbeg = C.maskoff[ck], cend_ = C.maskoff[ck + 1];
-    int32_t cstart = C.start[ck];
+    const MaskTile mt = C.mtile[blockIdx.x];
+    int64_t ck = mt.ck0;
+    int64_t cbeg = mt.off0, cend_ = mt.off1;
+    int32_t cstart = mt.start0;
 #pragma unroll
     for (int p = 0; p < 8; p++, cell++) {
         const uint32_t m = (words[p >> 1] >> ((p & 1) * 16)) & 0xffffu;
