@@ -856,6 +856,7 @@ struct CaptureArgs {
 constexpr int CLQ = 128;   // candidate list entries per wave (circular, power of two)
 constexpr int CSG = 48;    // segments per LDS window
 constexpr int CNB = 4;     // ring of 1024-base blocks (qualities + packed bases) per wave
+constexpr int CPF = 4;     // blocks in flight ahead of the ring (register sets)
 
 // One wave per read, driven by the candidate-position bitmap under the read.
 //
@@ -866,7 +867,7 @@ constexpr int CNB = 4;     // ring of 1024-base blocks (qualities + packed bases
 // read's segment list in LDS, the segment turns the position into a query offset, and the
 // base and its quality are picked out of an LDS ring that holds the read's qualities and
 // packed bases around the current query offset.  The ring is fed in query order with 1 KB +
-// 512 B coalesced loads issued three blocks ahead of their use, so every byte of the read
+// 512 B coalesced loads issued four blocks ahead of their use, so every byte of the read
 // is fetched exactly once and HBM latency is covered by the loads in flight.
 __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     __shared__ __align__(16) uint8_t s_rbq[4][CNB * 1024];
@@ -895,11 +896,12 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
 #define CAP_SEGWIN() do { if (lane <= nw) { int4 z = make_int4(0x7fffffff, 0, 0, 0); if (jb + lane < ns) z = *reinterpret_cast<const int4*>(gsegs + jb + lane); \
         *reinterpret_cast<int4*>(lseg + lane) = z; } } while (0)
 
-    // ring state: blocks [max(vb, hb - CNB), hb) are in LDS; hb, hb+1, hb+2 are in flight
+    // ring state: blocks [max(vb, hb - CNB), hb) are in LDS; hb .. hb + CPF - 1 are in flight
     int hb = qstart >> 10, vb = hb;
-    uint4 p0b, p1b, p2b;
-    uint2 p0s, p1s, p2s;
-    CAP_LOAD(p0b, p0s, hb); CAP_LOAD(p1b, p1s, hb + 1); CAP_LOAD(p2b, p2s, hb + 2);
+    uint4 p0b, p1b, p2b, p3b;
+    uint2 p0s, p1s, p2s, p3s;
+#define CAP_FILL_ALL() do { CAP_LOAD(p0b, p0s, hb); CAP_LOAD(p1b, p1s, hb + 1); CAP_LOAD(p2b, p2s, hb + 2); CAP_LOAD(p3b, p3s, hb + 3); } while (0)
+    CAP_FILL_ALL();
     // segment window [jb, jb + nw) plus a sentinel that carries the next segment's start
     int jb = 0, nw = min(ns, CSG);
     CAP_SEGWIN();
@@ -984,14 +986,14 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
                     const int need = __shfl(q, 63 - __clzll((long long)qm), 64) >> 10;
                     if (need - hb > 2 * CNB) {           // a long jump in query space: restart the ring there
                         hb = need - 2; vb = hb;
-                        CAP_LOAD(p0b, p0s, hb); CAP_LOAD(p1b, p1s, hb + 1); CAP_LOAD(p2b, p2s, hb + 2);
+                        CAP_FILL_ALL();
                     }
                     while (hb <= need) {
                         const int sl = hb & (CNB - 1);
                         *reinterpret_cast<uint4*>(rbq + sl * 1024 + lane * 16) = p0b;
                         *reinterpret_cast<uint2*>(rsq + sl * 512 + lane * 8) = p0s;
-                        p0b = p1b; p0s = p1s; p1b = p2b; p1s = p2s;
-                        CAP_LOAD(p2b, p2s, hb + 3);
+                        p0b = p1b; p0s = p1s; p1b = p2b; p1s = p2s; p2b = p3b; p2s = p3s;
+                        CAP_LOAD(p3b, p3s, hb + CPF);
                         hb++;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -1022,6 +1024,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     }
 #undef CAP_LOAD
 #undef CAP_SEGWIN
+#undef CAP_FILL_ALL
 }
 
 // ---------------------------------------------------------------------------------------
