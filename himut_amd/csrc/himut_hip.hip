@@ -98,7 +98,7 @@ struct himut_ctx {
     // run state
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2;
-    DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_winlo_c, d_winn_c, d_winoff_c, d_colstore, d_posbits_c, d_posrank, d_poppc, d_tmp2;
+    DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_blkslots, d_blkoff, d_blktab, d_colstore, d_posbits_c, d_posrank, d_poppc, d_tmp2;
     std::vector<himut_record> h_recs;
     bool h_recs_valid = false;
     int64_t n_out = 0;
@@ -442,28 +442,33 @@ int do_run(himut_ctx* c) {
         c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
         c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
         c->d_poppc.reserve((size_t)(nwords + 2) * 4 + 256);
-        c->d_winlo_c.reserve((size_t)ncand * 4 + 256); c->d_winn_c.reserve((size_t)ncand * 4 + 256);
-        c->d_winoff_c.reserve((size_t)ncand * 4 + 256);
+        c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
+        c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
         HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
         hipLaunchKernelGGL(k_candpos_set, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand,
                            c->d_posbits_c.as<uint32_t>());
-        hipLaunchKernelGGL(k_word_popc, dim3(blocks_for(nwords, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
-                           nwords, c->d_poppc.as<uint32_t>());
-        size_t scan2 = 0;
+        // rank[w] for w = 0 .. nwords (the last entry is the number of unique candidate positions)
+        hipLaunchKernelGGL(k_word_popc, dim3(blocks_for(nwords + 1, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
+                           nwords + 1, c->d_poppc.as<uint32_t>());
+        size_t scan2 = 0, scan3 = 0;
         HCHECK(rocprim::exclusive_scan(nullptr, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
-                                       (size_t)nwords, rocprim::plus<uint32_t>(), st));
-        c->d_tmp2.reserve(scan2 + 256);
+                                       (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
+        HCHECK(rocprim::exclusive_scan(nullptr, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
+                                       (size_t)nblk, rocprim::plus<uint32_t>(), st));
+        c->d_tmp2.reserve(std::max(std::max(scan2, scan3), scan_tiles) + 256);
         HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
-                                       (size_t)nwords, rocprim::plus<uint32_t>(), st));
-        HCHECK(hipMemsetAsync(c->d_winn_c.p, 0, (size_t)ncand * 4, st));
-        hipLaunchKernelGGL(k_upos_windows, dim3(blocks_for(nwords, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
-                           c->d_posrank.as<uint32_t>(), nwords, c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(),
-                           c->d_winlo_c.as<int32_t>(), c->d_winn_c.as<uint32_t>());
-        HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_tmp, c->d_winn_c.as<uint32_t>(), c->d_winoff_c.as<uint32_t>(), 0u,
-                                       (size_t)ncand, rocprim::plus<uint32_t>(), st));
+                                       (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
+        // per 256-position block: slots = candidate positions x reads of the window, then their offsets
+        hipLaunchKernelGGL(k_block_slots, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
+                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, c->d_blkslots.as<uint32_t>());
+        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
+                                       (size_t)nblk, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
+                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_blkoff.as<uint32_t>(), nblk,
+                           c->d_blktab.as<BlockTab>());
         uint32_t last_off = 0, last_n = 0;
-        HCHECK(hipMemcpyAsync(&last_off, c->d_winoff_c.as<uint32_t>() + (ncand - 1), 4, hipMemcpyDeviceToHost, st));
-        HCHECK(hipMemcpyAsync(&last_n, c->d_winn_c.as<uint32_t>() + (ncand - 1), 4, hipMemcpyDeviceToHost, st));
+        HCHECK(hipMemcpyAsync(&last_off, c->d_blkoff.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
+        HCHECK(hipMemcpyAsync(&last_n, c->d_blkslots.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
         HCHECK(hipStreamSynchronize(st));
         const size_t nslots = (size_t)last_off + last_n;
         c->d_colstore.reserve(nslots * 2 + 256);
@@ -471,7 +476,7 @@ int do_run(himut_ctx* c) {
         if (nslots) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, nslots, st));
         PosIndex X;
         X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
-        X.ulo = c->d_winlo_c.as<int32_t>(); X.un = c->d_winn_c.as<uint32_t>(); X.uoff = c->d_winoff_c.as<uint32_t>();
+        X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
         CaptureArgs G;
         G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>();
         HCHECK(hipEventRecord(c->ev[EV_INDEX], st));

@@ -16,13 +16,14 @@
 //                      the candidate list; radix-sorted afterwards only when the chunks are
 //                      not already in coordinate order
 //   k_window_index     per 256-position block: the range of reads that can cover it
-//   k_candpos_set / k_word_popc / k_upos_windows + scans
-//                      bitmap of candidate positions, its rank index, and per unique
-//                      position the read window and the offset of its column
-//   k_stream_capture   one wave per read: streams the read's qualities and packed bases once
-//                      (16 B + 8 B per lane, coalesced), maps every base to its reference
-//                      position through the segment list, and drops the (allele, BQ) of the
-//                      bases that sit on candidate positions into the column store
+//   k_candpos_set / k_word_popc / k_block_slots / k_block_table + scans
+//                      bitmap of candidate positions, its rank index, and per 256-position
+//                      block the read window and the offset of its columns
+//   k_stream_capture   one wave per read, a software pipeline over windows of 2048 query bases:
+//                      streams the read's qualities and packed bases once (16-byte coalesced
+//                      loads, two windows ahead), enumerates the candidate positions under
+//                      each window from the bitmap, one per lane, and drops their
+//                      (allele, BQ) cells into the column store
 //   k_eval_columns     one THREAD per candidate column: allele counts, BQ sums, the
 //                      genotype likelihood sums added in fetch order exactly as the
 //                      reference's python sum() does, genotype, filter cascade
@@ -793,22 +794,30 @@ __device__ __forceinline__ uint64_t nib16_to_cells(uint64_t x) {
 
 // ---------------------------------------------------------------------------------------
 // The column store.  Candidate columns live at the UNIQUE reference positions that carry
-// a candidate (several chunks / alts can share one).  Unique position u (rank of its bit
-// in the position bitmap) owns the slots [uoff[u], uoff[u] + un[u]): one 16-bit slot per
-// read of its window [ulo[u], ulo[u] + un[u]), in fetch order:
+// a candidate (several chunks / alts can share one).  All positions of a 256-position block
+// share one read window [lo, lo + n) (k_window_index), so the columns of a block are n
+// slots each and lie one after the other: the column of unique position u in block b starts
+// at boff[b] + (u - ufirst[b]) * n[b], and holds one 16-bit slot per read of the window, in
+// fetch order:
 //   bits 0-2 cell (0-3 allele A T G C, 4 base outside ATGC, 5 deletion, 7 not in the pile)
 //   bit 3    an insertion precedes the position
 //   bits 8-15 base quality
 // k_stream_capture fills it while streaming every read once with coalesced loads;
 // k_eval_columns consumes it, one thread per candidate.
 
+struct BlockTab {     // one per 256 reference positions
+    int32_t lo;       // first read of the window
+    uint32_t n;       // reads in the window = slots per column
+    uint32_t boff;    // slot offset of the block's first column
+    uint32_t ufirst;  // unique-position rank of the block's first candidate position
+};
+
 struct PosIndex {
     const uint32_t* bits;    // bit rpos set: some candidate sits at rpos
-    const uint32_t* rank;    // exclusive prefix popcount per 32-bit word
+    const uint32_t* rank;    // exclusive prefix popcount per 32-bit word, nwords + 1 entries
     int64_t nwords;
-    const int32_t* ulo;      // per unique position: window start (read index)
-    const uint32_t* un;      // window size
-    const uint32_t* uoff;    // slot offset
+    const BlockTab* bt;
+    int64_t nblk;
 };
 
 __device__ __forceinline__ uint32_t pos_rank(const PosIndex& X, int32_t rpos) {
@@ -828,22 +837,22 @@ __global__ void __launch_bounds__(256) k_word_popc(const uint32_t* bits, int64_t
     if (w < nwords) out[w] = (uint32_t)__popc(bits[w]);
 }
 
-// per unique candidate position: its read window (from the 256-position window index)
-__global__ void __launch_bounds__(256) k_upos_windows(const uint32_t* bits, const uint32_t* rank, int64_t nwords,
-                                                      const int32_t* winlo, const int32_t* winhi, int32_t* ulo, uint32_t* un) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwords) return;
-    uint32_t b = bits[w];
-    uint32_t u = rank[w];
-    while (b) {
-        const int k = __ffs((int)b) - 1;
-        b &= b - 1;
-        const int64_t rpos = w * 32 + k;
-        const int32_t lo = winlo[rpos >> WIN_SHIFT], hi = winhi[rpos >> WIN_SHIFT];
-        ulo[u] = lo;
-        un[u] = (uint32_t)(hi - lo);
-        u++;
-    }
+// slots per 256-position block = candidate positions in it x reads in its window
+__global__ void __launch_bounds__(256) k_block_slots(const uint32_t* rank, int64_t nwords, const int32_t* winlo,
+                                                     const int32_t* winhi, int64_t nblk, uint32_t* out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const int64_t w0 = min(b * 8, nwords), w1 = min(b * 8 + 8, nwords);
+    out[b] = (rank[w1] - rank[w0]) * (uint32_t)(winhi[b] - winlo[b]);
+}
+
+__global__ void __launch_bounds__(256) k_block_table(const uint32_t* rank, int64_t nwords, const int32_t* winlo,
+                                                     const int32_t* winhi, const uint32_t* boff, int64_t nblk, BlockTab* bt) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    BlockTab t;
+    t.lo = winlo[b]; t.n = (uint32_t)(winhi[b] - winlo[b]); t.boff = boff[b]; t.ufirst = rank[min(b * 8, nwords)];
+    bt[b] = t;
 }
 
 struct CaptureArgs {
@@ -853,26 +862,30 @@ struct CaptureArgs {
     uint16_t* colstore;
 };
 
-constexpr int CLQ = 128;   // candidate list entries per wave (circular, power of two)
-constexpr int CSG = 48;    // segments per LDS window
-constexpr int CNB = 4;     // ring of 1024-base blocks (qualities + packed bases) per wave
-constexpr int CPF = 4;     // blocks in flight ahead of the ring (register sets)
+constexpr int CLQ = 128;    // candidate list entries per wave (circular, power of two)
+constexpr int CSG = 63;     // segments per LDS window (+ 1 sentinel = one per lane)
+constexpr int CWQ = 2048;   // query bases per window
 
-// One wave per read, driven by the candidate-position bitmap under the read.
+// One wave per read; a software pipeline over windows of 2048 query bases.
 //
-// The read's reference span is walked 2048 positions (64 bitmap words, one per lane) at a
-// time.  The set bits are compacted -- one wave prefix sum -- into an LDS list of
-// (position, unique-position rank), so everything after that runs one candidate per lane
-// with all lanes busy: the candidate's gapless segment comes from a binary search over the
-// read's segment list in LDS, the segment turns the position into a query offset, and the
-// base and its quality are picked out of an LDS ring that holds the read's qualities and
-// packed bases around the current query offset.  The ring is fed in query order with 1 KB +
-// 512 B coalesced loads issued four blocks ahead of their use, so every byte of the read
-// is fetched exactly once and HBM latency is covered by the loads in flight.
+// Window k is [c_k, c_k + 2048) of the query.  The segment list turns it into a reference
+// range [tA_k, tB_k) (a deleted position goes with the base that follows it); those ranges
+// tile the read's span.  Every turn of the loop
+//   * stores the window's bytes -- 2 KB of qualities + 1 KB of packed bases, loaded two
+//     turns earlier with 16-byte coalesced loads -- in LDS,
+//   * issues the same five loads for window k + 2 (three for the bytes, one for the
+//     candidate bitmap under it, one for the block table under it): the addresses depend
+//     only on the segment list, never on loaded data, so nothing in the loop waits on a
+//     load younger than two turns and the count of loads in flight is the same every turn,
+//   * compacts the candidate bits of [tA_k, tB_k) -- one wave prefix sum -- into a list, and
+//     handles the list one candidate per lane: segment by binary search in LDS, query
+//     offset, base and quality out of the window in LDS, slot from the block table.
+// Every byte of the read is fetched exactly once; stores return nothing.
 __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
-    __shared__ __align__(16) uint8_t s_rbq[4][CNB * 1024];
-    __shared__ __align__(16) uint8_t s_rsq[4][CNB * 512];
-    __shared__ __align__(16) Seg s_seg[4][CSG + 1];
+    __shared__ __align__(16) uint8_t s_bq[4][CWQ];
+    __shared__ __align__(16) uint8_t s_sq[4][CWQ / 2];
+    __shared__ __align__(16) int4 s_seg[4][CSG + 1];
+    __shared__ __align__(16) uint4 s_bt[4][16];
     __shared__ uint2 s_list[4][CLQ];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Reads& R = A.R;
@@ -886,145 +899,211 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     const Seg* gsegs = A.D.segs + M.segbase;
     const int ns = M.nseg;
     const int64_t qo = M.qoff;
-    uint8_t* rbq = s_rbq[wv];
-    uint8_t* rsq = s_rsq[wv];
-    Seg* lseg = s_seg[wv];
+    const int32_t tstart = M.tstart, tend = M.tend;
+    uint8_t* wbq = s_bq[wv];
+    uint8_t* wsq = s_sq[wv];
+    int4* lseg = s_seg[wv];
+    uint4* lbt = s_bt[wv];
     uint2* list = s_list[wv];
+    const bool all_lds = ns <= CSG;     // the whole segment list fits the LDS window
 
-#define CAP_LOAD(B, S, BLK) do { const int32_t _q = ((BLK) << 10) + lane * 16; B = make_uint4(0, 0, 0, 0); S = make_uint2(0, 0); \
-        if (_q < qlen) { B = *reinterpret_cast<const uint4*>(R.bq + qo + _q); S = *reinterpret_cast<const uint2*>(R.seq + ((qo + _q) >> 1)); } } while (0)
+    const int32_t c0 = qstart & ~(CWQ - 1);
+    const int nwin = ((max(qlen, 1) - 1 - c0) >> 11) + 1;
+    const int32_t qpad = (qlen + 31) & ~31;
+    const int64_t wlastbit = min((int64_t)(tend >> 5), X.nwords - 1);   // last bitmap word the read can touch
+
+    // a load inside a rarely taken branch is waited for inside that branch, so that the join behind it
+    // does not have to wait for every load in flight
+#define CAP_LANDED4(V) asm volatile("" : "+v"(V.x), "+v"(V.y), "+v"(V.z), "+v"(V.w))
+#define CAP_LANDED2(V) asm volatile("" : "+v"(V.x), "+v"(V.y))
+    // the five loads of one window (addresses clamped into the read, so every lane always loads)
+#define CAP_ISSUE(BA, BB, SQ, S1, BT, K, TA) do { \
+        const int32_t _c = c0 + min((K), nwin - 1) * CWQ; \
+        const int32_t _qa = min(_c + lane * 16, qpad - 16), _qb = min(_c + 1024 + lane * 16, qpad - 16), _qs = min(_c + lane * 32, qpad - 32); \
+        BA = *reinterpret_cast<const uint4*>(R.bq + qo + _qa); \
+        BB = *reinterpret_cast<const uint4*>(R.bq + qo + _qb); \
+        SQ = *reinterpret_cast<const uint4*>(R.seq + ((qo + _qs) >> 1)); \
+        const int64_t _w = min((int64_t)((TA) >> 5) + 2 * lane, X.nwords - 1); \
+        __builtin_memcpy(&S1, X.bits + _w, 8);                 /* nwords + 2 words are allocated */ \
+        BT = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)((TA) >> 8) + (lane & 15), X.nblk - 1)); \
+    } while (0)
 #define CAP_SEGWIN() do { if (lane <= nw) { int4 z = make_int4(0x7fffffff, 0, 0, 0); if (jb + lane < ns) z = *reinterpret_cast<const int4*>(gsegs + jb + lane); \
-        *reinterpret_cast<int4*>(lseg + lane) = z; } } while (0)
+        lseg[lane] = z; } } while (0)
 
-    // ring state: blocks [max(vb, hb - CNB), hb) are in LDS; hb .. hb + CPF - 1 are in flight
-    int hb = qstart >> 10, vb = hb;
-    uint4 p0b, p1b, p2b, p3b;
-    uint2 p0s, p1s, p2s, p3s;
-#define CAP_FILL_ALL() do { CAP_LOAD(p0b, p0s, hb); CAP_LOAD(p1b, p1s, hb + 1); CAP_LOAD(p2b, p2s, hb + 2); CAP_LOAD(p3b, p3s, hb + 3); } while (0)
-    CAP_FILL_ALL();
     // segment window [jb, jb + nw) plus a sentinel that carries the next segment's start
     int jb = 0, nw = min(ns, CSG);
     CAP_SEGWIN();
-    // bitmap words of the read's span, tend included (a trailing insertion is counted there)
-    const int64_t w_lo = M.tstart >> 5, w_hi = min((int64_t)(M.tend >> 5), X.nwords - 1);
-    const int nrounds = (int)((w_hi - w_lo) >> 6) + 1;
-    uint32_t nb = 0, nr = 0;
-    if (w_lo + lane <= w_hi) { nb = X.bits[w_lo + lane]; nr = X.rank[w_lo + lane]; }
-    int head = 0, n = 0;   // the list: entries head .. head + n - 1 (mod CLQ)
+    uint4 baA, bbA, sqA, btA, baB, bbB, sqB, btB;
+    uint2 s1A, s1B;
+    CAP_ISSUE(baA, bbA, sqA, s1A, btA, 0, tstart);
+    const uint32_t rk0 = X.rank[min((int64_t)(tstart >> 5), X.nwords)];
     __builtin_amdgcn_wave_barrier();
 
-    for (int rd = 0; rd <= nrounds; rd++) {          // the last turn only drains the list
-        const int64_t w = w_lo + (int64_t)rd * 64 + lane;
-        uint32_t bits = nb, rk = nr;
-        nb = 0; nr = 0;
-        if (rd + 1 < nrounds && w + 64 <= w_hi) { nb = X.bits[w + 64]; nr = X.rank[w + 64]; }
-        if (rd == nrounds) bits = 0;
-        if (w == w_lo) {   // candidates in front of the read still count towards the rank
-            const uint32_t keep = ~0u << (M.tstart & 31);
-            rk += (uint32_t)__popc(bits & ~keep);
-            bits &= keep;
-        }
-        if (w == (int64_t)(M.tend >> 5)) bits &= (2u << (M.tend & 31)) - 1u;
-        const int cnt = __popc(bits);
-        const int incl = wave_incl_add(cnt, lane);
-        int done = 0, basecnt = 0;
+    // end of window kk in reference coordinates: the first position whose query offset is >= c
+    int jq = 0;   // no segment before jq ends behind the last boundary asked for
+    auto window_end = [&](int kk) -> int32_t {
+        if (kk >= nwin - 1) return tend + 1;
+        const int32_t c = c0 + (kk + 1) * CWQ;
         while (true) {
-            // ---- compaction: the lanes whose bits still fit go into the list
-            const bool fit = lane >= done && n + incl - basecnt <= CLQ;
-            const int nfit = __popcll(__ballot(fit));
-            if (fit) {
-                int slot = head + n + (incl - cnt - basecnt);
-                uint32_t b = bits, uu = rk;
-                while (b) {
-                    const int k = __ffs((int)b) - 1;
-                    b &= b - 1;
-                    list[slot & (CLQ - 1)] = make_uint2((uint32_t)(w * 32 + k), uu);
-                    slot++; uu++;
-                }
+            int4 sg = make_int4(tend + 1, 0x7ffffff0, 0, (int)SEG_DEL);        // behind the list: ends nowhere
+            if (jq + lane < ns) {
+                if (all_lds) sg = lseg[jq + lane];
+                else { sg = *reinterpret_cast<const int4*>(gsegs + jq + lane); CAP_LANDED4(sg); }
             }
-            if (nfit) {
-                const int inc = __shfl(incl, done + nfit - 1, 64);
-                n += inc - basecnt; basecnt = inc; done += nfit;
+            const bool isrun = !((uint32_t)sg.w & SEG_DEL) && sg.z > 0;
+            const int32_t qend = isrun ? sg.y + sg.z : sg.y + 1;
+            const unsigned long long bal = __ballot(qend > c);
+            if (bal) {
+                const int src = __ffsll((long long)bal) - 1;
+                const int32_t t0 = __shfl(sg.x, src, 64), q0 = __shfl(sg.y, src, 64);
+                const bool inside = __shfl((int)(isrun && sg.y < c), src, 64) != 0;
+                jq += src;
+                return inside ? t0 + (c - q0) : t0;
             }
-            __builtin_amdgcn_wave_barrier();
-            // ---- dense batches: full ones always, the remainder when room is needed or at the end
-            while (n >= 64 || ((done < 64 || rd == nrounds) && n > 0)) {
-                const int bn = min(n, 64);
-                const bool act = lane < bn;
-                uint32_t rpos = 0, u = 0;
-                if (act) { const uint2 e = list[(head + lane) & (CLQ - 1)]; rpos = e.x; u = e.y; }
-                // the segment that holds rpos: last one that starts at or before it
-                int4 sg = make_int4(0, 0, 0, 0);   // t0, q0, len, flags
-                bool res = !act;
-                while (true) {
-                    const int32_t cover = lseg[nw].t0;
-                    if (!res && (int32_t)rpos < cover) {
-                        int lo = 0, hi = nw;
-                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lseg[mid].t0 <= (int32_t)rpos) lo = mid; else hi = mid; }
-                        sg = *reinterpret_cast<const int4*>(lseg + lo);
-                        res = true;
-                    }
-                    if (!__ballot(!res)) break;
-                    jb += nw; nw = min(ns - jb, CSG);        // slide the window forward
-                    __builtin_amdgcn_wave_barrier();
-                    CAP_SEGWIN();
-                    __builtin_amdgcn_wave_barrier();
-                }
-                bool store = false, isq = false;
-                uint32_t val = 0;
-                int32_t q = 0;
-                if (act) {
-                    const int32_t d = (int32_t)rpos - sg.x;
-                    const uint32_t insb = (d == 0 && ((uint32_t)sg.w & SEG_INS)) ? CELL_INS : 0u;
-                    if ((uint32_t)sg.w & SEG_DEL) { if (d < sg.z) { store = true; val = CELL_DEL | insb; } }
-                    else if (sg.z == 0) { if (d == 0 && insb) { store = true; val = CELL_EMPTY | CELL_INS; } }
-                    else if (d < sg.z) { store = true; isq = true; q = sg.y + d; val = insb; }
-                }
-                // bring the ring up to the highest query offset of the batch (offsets rise with the lane)
-                const unsigned long long qm = __ballot(isq);
-                if (qm) {
-                    const int need = __shfl(q, 63 - __clzll((long long)qm), 64) >> 10;
-                    if (need - hb > 2 * CNB) {           // a long jump in query space: restart the ring there
-                        hb = need - 2; vb = hb;
-                        CAP_FILL_ALL();
-                    }
-                    while (hb <= need) {
-                        const int sl = hb & (CNB - 1);
-                        *reinterpret_cast<uint4*>(rbq + sl * 1024 + lane * 16) = p0b;
-                        *reinterpret_cast<uint2*>(rsq + sl * 512 + lane * 8) = p0s;
-                        p0b = p1b; p0s = p1s; p1b = p2b; p1s = p2s; p2b = p3b; p2s = p3s;
-                        CAP_LOAD(p3b, p3s, hb + CPF);
-                        hb++;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (isq) {
-                    const int blk = q >> 10;
-                    uint32_t qv, sb;
-                    if (blk >= max(vb, hb - CNB)) {
-                        qv = rbq[(blk & (CNB - 1)) * 1024 + (q & 1023)];
-                        sb = rsq[(blk & (CNB - 1)) * 512 + ((q & 1023) >> 1)];
-                    } else {                              // behind the ring (a batch spread over > 3 blocks)
-                        qv = R.bq[qo + q];
-                        sb = R.seq[(qo + q) >> 1];
-                    }
-                    const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
-                    val |= (uint32_t)nib2allele(nib) | (qv << 8);
-                }
-                if (store) {
-                    const int32_t lo = X.ulo[u];
-                    const uint32_t off = X.uoff[u];
-                    A.colstore[(int64_t)off + (r - lo)] = (uint16_t)val;
-                }
-                head = (head + bn) & (CLQ - 1); n -= bn;
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (done >= 64) break;
+            jq += 64;
         }
+    };
+    int32_t tA = tstart;                 // window k
+    int32_t tA1 = window_end(0);         // window k + 1
+    CAP_ISSUE(baB, bbB, sqB, s1B, btB, 1, tA1);
+    int32_t tA2 = window_end(1);         // window k + 2
+    // rank of the first candidate position at or behind tstart
+    uint32_t ubase = 0;
+    {
+        const uint32_t w0 = __shfl((int)s1A.x, 0, 64);
+        ubase = rk0 + (uint32_t)__popc(w0 & ((1u << (tstart & 31)) - 1u));
+        if ((int64_t)(tstart >> 5) > X.nwords - 1) ubase = rk0;
     }
-#undef CAP_LOAD
+    int head = 0, n = 0;   // the list: entries head .. head + n - 1 (mod CLQ)
+
+    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint2& s1, uint4& btv, const int k) {
+        const int32_t tB = tA1;
+        const int32_t cq = c0 + k * CWQ;
+        // ---- this window's bytes and tables -> LDS; its registers take window k + 2
+        *reinterpret_cast<uint4*>(wbq + lane * 16) = ba;
+        *reinterpret_cast<uint4*>(wbq + 1024 + lane * 16) = bb;
+        *reinterpret_cast<uint4*>(wsq + lane * 16) = sq;
+        lbt[lane & 15] = btv;                              // four lanes hold each entry
+        // the window's bitmap words move to registers of their own: the ones they arrived in are reloaded next
+        uint32_t mylo, myhi;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mylo), "=&v"(myhi) : "v"(s1.x), "v"(s1.y));
+        const unsigned long long mybits = ((unsigned long long)myhi << 32) | mylo;
+        CAP_ISSUE(ba, bb, sq, s1, btv, k + 2, tA2);
+        const int32_t tA3 = window_end(k + 2);
+        __builtin_amdgcn_wave_barrier();
+        const int64_t bt0 = tA >> 8;
+        // ---- candidate bits of [tA, tB): 64 positions per lane, 4096 per group
+        for (int64_t wg = tA >> 5; wg <= wlastbit && wg * 32 < tB; wg += 128) {
+            const int64_t w = wg + 2 * lane;
+            unsigned long long bits = mybits;
+            if (wg != (tA >> 5)) {                         // a window across more than 4096 positions (long deletions)
+                uint2 t = make_uint2(0, 0);
+                if (w <= wlastbit) __builtin_memcpy(&t, X.bits + w, 8);
+                CAP_LANDED2(t);
+                bits = ((unsigned long long)t.y << 32) | t.x;
+            }
+            if (w > wlastbit) bits = 0;                    // clamped address
+            {   // keep [tA, tB)
+                const int64_t p0 = w * 32;
+                if (p0 + 64 <= tA || p0 >= tB) bits = 0;
+                else {
+                    if (p0 < tA) bits &= ~0ULL << (tA - p0);
+                    if (p0 + 64 > tB) bits &= ~0ULL >> (p0 + 64 - tB);
+                }
+            }
+            const int cnt = __popcll(bits);
+            const int incl = wave_incl_add(cnt, lane);
+            const int total = __shfl(incl, 63, 64);
+            int done = 0, basecnt = 0;
+            while (true) {
+                // ---- compaction: the lanes whose bits still fit go into the list
+                const bool fit = lane >= done && n + incl - basecnt <= CLQ;
+                const int nfit = __popcll(__ballot(fit));
+                if (fit) {
+                    int slot = head + n + (incl - cnt - basecnt);
+                    unsigned long long b = bits;
+                    uint32_t uu = ubase + (uint32_t)(incl - cnt);
+                    while (b) {
+                        const int i = __ffsll((long long)b) - 1;
+                        b &= b - 1;
+                        list[slot & (CLQ - 1)] = make_uint2((uint32_t)(w * 32 + i), uu);
+                        slot++; uu++;
+                    }
+                }
+                if (nfit) {
+                    const int inc = __shfl(incl, done + nfit - 1, 64);
+                    n += inc - basecnt; basecnt = inc; done += nfit;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- one candidate per lane; the list is emptied before the window's bytes go away
+                const bool last_piece = done >= 64 && !(wg + 128 <= wlastbit && (wg + 128) * 32 < tB);
+                while (n >= 64 || ((done < 64 || last_piece) && n > 0)) {
+                    const int bn = min(n, 64);
+                    const bool act = lane < bn;
+                    uint32_t rpos = 0, u = 0;
+                    if (act) { const uint2 e = list[(head + lane) & (CLQ - 1)]; rpos = e.x; u = e.y; }
+                    // the segment that holds rpos: last one that starts at or before it
+                    int4 sg = make_int4(0, 0, 0, 0);   // t0, q0, len, flags
+                    bool res = !act;
+                    while (true) {
+                        const int32_t cover = lseg[nw].x;
+                        if (!res && (int32_t)rpos < cover) {
+                            int lo = 0, hi = nw;
+                            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lseg[mid].x <= (int32_t)rpos) lo = mid; else hi = mid; }
+                            sg = lseg[lo];
+                            res = true;
+                        }
+                        if (!__ballot(!res)) break;
+                        jb += nw; nw = min(ns - jb, CSG);        // slide the window forward (lists longer than CSG only)
+                        __builtin_amdgcn_wave_barrier();
+                        CAP_SEGWIN();
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (act) {
+                        const int32_t d = (int32_t)rpos - sg.x;
+                        const uint32_t insb = (d == 0 && ((uint32_t)sg.w & SEG_INS)) ? CELL_INS : 0u;
+                        bool store = false;
+                        uint32_t val = 0;
+                        if ((uint32_t)sg.w & SEG_DEL) { if (d < sg.z) { store = true; val = CELL_DEL | insb; } }
+                        else if (sg.z == 0) { if (d == 0 && insb) { store = true; val = CELL_EMPTY | CELL_INS; } }
+                        else if (d < sg.z) {
+                            store = true;
+                            const int32_t q = sg.y + d;
+                            const int32_t o = (q - cq) & (CWQ - 1);       // inside the window by construction
+                            const uint32_t qv = wbq[o], sb = wsq[o >> 1];
+                            const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
+                            val = insb | (uint32_t)nib2allele(nib) | (qv << 8);
+                        }
+                        if (store) {
+                            const int64_t bi = (int64_t)(rpos >> 8) - bt0;
+                            uint4 t;
+                            if (bi >= 0 && bi < 16) t = lbt[bi];
+                            else { t = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)(rpos >> 8), X.nblk - 1)); CAP_LANDED4(t); }
+                            // BlockTab: x = lo, y = n, z = boff, w = ufirst
+                            const int64_t slot = (int64_t)t.z + (int64_t)(u - t.w) * (int64_t)t.y + (int64_t)(r - (int32_t)t.x);
+                            A.colstore[slot] = (uint16_t)val;
+                        }
+                    }
+                    head = (head + bn) & (CLQ - 1); n -= bn;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (done >= 64) break;
+            }
+            ubase += (uint32_t)total;
+        }
+        tA = tA1; tA1 = tA2; tA2 = tA3;
+    };
+
+    // two windows per trip, each with its own registers; a trip's second window may lie behind the
+    // read (empty range): it still issues its loads, so the number in flight never depends on the path
+    for (int k = 0; k < nwin; k += 2) {
+        window(baA, bbA, sqA, s1A, btA, k);
+        window(baB, bbB, sqB, s1B, btB, k + 1);
+    }
+#undef CAP_ISSUE
 #undef CAP_SEGWIN
-#undef CAP_FILL_ALL
+#undef CAP_LANDED4
+#undef CAP_LANDED2
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1088,9 +1167,10 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
     const int ref = (int)((cd.chunk_bit >> 2) & 3), alt = (int)(cd.chunk_bit & 3);
     const int32_t rpos = tpos - 1;
     const uint32_t u = pos_rank(A.X, rpos);
-    const uint32_t n = A.X.un[u];
-    const int32_t lo = A.X.ulo[u];
-    const uint16_t* col = A.colstore + A.X.uoff[u];
+    const BlockTab bt = A.X.bt[rpos >> 8];
+    const uint32_t n = bt.n;
+    const int32_t lo = bt.lo;
+    const uint16_t* col = A.colstore + ((int64_t)bt.boff + (int64_t)(u - bt.ufirst) * (int64_t)n);
     const int min_bq = A.P.p.min_bq;
     const int32_t cs_ = A.C.start[chunk];
     // Only next to the chunk start can a read lie in the pile of the position without having
