@@ -478,7 +478,7 @@ int do_run(himut_ctx* c) {
         X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
         X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
         CaptureArgs G;
-        G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>();
+        G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)nslots;
         HCHECK(hipEventRecord(c->ev[EV_INDEX], st));
         hipLaunchKernelGGL(k_stream_capture, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
         HCHECK(hipEventRecord(c->ev[EV_GATHER], st));

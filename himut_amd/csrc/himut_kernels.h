@@ -197,6 +197,15 @@ __device__ __forceinline__ int64_t upper_bound(const T* a, int64_t lo, int64_t h
 
 __device__ __forceinline__ void set_err(int* err, int code) { atomicOr(err, 1 << code); }
 
+// wave-uniform values belong in scalar registers: everything computed from them then runs on the scalar unit
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int64_t uni(int64_t v) {
+    return ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+// value of lane l, l wave-uniform
+__device__ __forceinline__ int lane_val(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
 // slot reservation for the lanes that reach this point together: one atomic per wave
 __device__ __forceinline__ unsigned long long wave_reserve(unsigned long long* counter) {
     const unsigned long long act = __ballot(1);
@@ -860,11 +869,15 @@ struct CaptureArgs {
     Derived D;
     PosIndex X;
     uint16_t* colstore;
+    int64_t nslots;
 };
 
 constexpr int CLQ = 128;    // candidate list entries per wave (circular, power of two)
 constexpr int CSG = 63;     // segments per LDS window (+ 1 sentinel = one per lane)
 constexpr int CWQ = 2048;   // query bases per window
+constexpr int CPL = 33;     // reference positions per lane when the bitmap is enumerated: 31 + 33 = 64 bits of a
+                            // word pair at most; 64 lanes take 2112 positions per pass
+constexpr int CPD = 2;      // windows in flight (register sets, at most 4); the loop is unrolled by it
 
 // One wave per read; a software pipeline over windows of 2048 query bases.
 //
@@ -872,11 +885,11 @@ constexpr int CWQ = 2048;   // query bases per window
 // range [tA_k, tB_k) (a deleted position goes with the base that follows it); those ranges
 // tile the read's span.  Every turn of the loop
 //   * stores the window's bytes -- 2 KB of qualities + 1 KB of packed bases, loaded two
-//     turns earlier with 16-byte coalesced loads -- in LDS,
-//   * issues the same five loads for window k + 2 (three for the bytes, one for the
+//     turns earlier (four, CPD) with 16-byte coalesced loads -- in LDS,
+//   * issues the same five loads for window k + 4 (three for the bytes, one for the
 //     candidate bitmap under it, one for the block table under it): the addresses depend
 //     only on the segment list, never on loaded data, so nothing in the loop waits on a
-//     load younger than two turns and the count of loads in flight is the same every turn,
+//     load younger than four turns and the count of loads in flight is the same every turn,
 //   * compacts the candidate bits of [tA_k, tB_k) -- one wave prefix sum -- into a list, and
 //     handles the list one candidate per lane: segment by binary search in LDS, query
 //     offset, base and quality out of the window in LDS, slot from the block table.
@@ -885,32 +898,31 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     __shared__ __align__(16) uint8_t s_bq[4][CWQ];
     __shared__ __align__(16) uint8_t s_sq[4][CWQ / 2];
     __shared__ __align__(16) int4 s_seg[4][CSG + 1];
-    __shared__ __align__(16) uint4 s_bt[4][16];
+    __shared__ __align__(16) uint32_t s_bt[4][64];        // 16 block-table entries
     __shared__ uint2 s_list[4][CLQ];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const Reads& R = A.R;
     const PosIndex& X = A.X;
     const int64_t r64 = (int64_t)blockIdx.x * 4 + wv;
     if (r64 >= R.n) return;
     const int32_t r = (int32_t)r64;
-    const ReadMeta M = A.D.meta[r];
-    const int32_t qstart = R.qstart[r], qlen = R.qlen[r];
-    if ((M.flags & RF_SECONDARY) || M.nseg <= 0) return;
-    const Seg* gsegs = A.D.segs + M.segbase;
-    const int ns = M.nseg;
-    const int64_t qo = M.qoff;
-    const int32_t tstart = M.tstart, tend = M.tend;
+    const ReadMeta Mv = A.D.meta[r];
+    const int32_t qstart = uni(R.qstart[r]), qlen = uni(R.qlen[r]);
+    if ((uni(Mv.flags) & RF_SECONDARY) || uni(Mv.nseg) <= 0) return;
+    const Seg* gsegs = A.D.segs + uni(Mv.segbase);
+    const int ns = uni(Mv.nseg);
+    const int64_t qo = uni(Mv.qoff);
+    const int32_t tstart = uni(Mv.tstart), tend = uni(Mv.tend);
     uint8_t* wbq = s_bq[wv];
     uint8_t* wsq = s_sq[wv];
     int4* lseg = s_seg[wv];
-    uint4* lbt = s_bt[wv];
+    uint32_t* lbt = s_bt[wv];
     uint2* list = s_list[wv];
     const bool all_lds = ns <= CSG;     // the whole segment list fits the LDS window
 
     const int32_t c0 = qstart & ~(CWQ - 1);
     const int nwin = ((max(qlen, 1) - 1 - c0) >> 11) + 1;
     const int32_t qpad = (qlen + 31) & ~31;
-    const int64_t wlastbit = min((int64_t)(tend >> 5), X.nwords - 1);   // last bitmap word the read can touch
 
     // a load inside a rarely taken branch is waited for inside that branch, so that the join behind it
     // does not have to wait for every load in flight
@@ -923,9 +935,9 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
         BA = *reinterpret_cast<const uint4*>(R.bq + qo + _qa); \
         BB = *reinterpret_cast<const uint4*>(R.bq + qo + _qb); \
         SQ = *reinterpret_cast<const uint4*>(R.seq + ((qo + _qs) >> 1)); \
-        const int64_t _w = min((int64_t)((TA) >> 5) + 2 * lane, X.nwords - 1); \
+        const int64_t _w = min(((int64_t)(TA) + CPL * lane) >> 5, X.nwords - 1); \
         __builtin_memcpy(&S1, X.bits + _w, 8);                 /* nwords + 2 words are allocated */ \
-        BT = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)((TA) >> 8) + (lane & 15), X.nblk - 1)); \
+        BT = reinterpret_cast<const uint32_t*>(X.bt + min((int64_t)((TA) >> 8) + (lane >> 2), X.nblk - 1))[lane & 3]; \
     } while (0)
 #define CAP_SEGWIN() do { if (lane <= nw) { int4 z = make_int4(0x7fffffff, 0, 0, 0); if (jb + lane < ns) z = *reinterpret_cast<const int4*>(gsegs + jb + lane); \
         lseg[lane] = z; } } while (0)
@@ -933,10 +945,11 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     // segment window [jb, jb + nw) plus a sentinel that carries the next segment's start
     int jb = 0, nw = min(ns, CSG);
     CAP_SEGWIN();
-    uint4 baA, bbA, sqA, btA, baB, bbB, sqB, btB;
-    uint2 s1A, s1B;
-    CAP_ISSUE(baA, bbA, sqA, s1A, btA, 0, tstart);
-    const uint32_t rk0 = X.rank[min((int64_t)(tstart >> 5), X.nwords)];
+    uint4 ba0, bb0, sq0, ba1, bb1, sq1, ba2, bb2, sq2, ba3, bb3, sq3;
+    uint2 s10, s11, s12, s13;
+    uint32_t bt0r, bt1r, bt2r, bt3r;
+    CAP_ISSUE(ba0, bb0, sq0, s10, bt0r, 0, tstart);
+    const uint32_t rk0 = uni(X.rank[min((int64_t)(tstart >> 5), X.nwords)]);
     __builtin_amdgcn_wave_barrier();
 
     // end of window kk in reference coordinates: the first position whose query offset is >= c
@@ -955,65 +968,64 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
             const unsigned long long bal = __ballot(qend > c);
             if (bal) {
                 const int src = __ffsll((long long)bal) - 1;
-                const int32_t t0 = __shfl(sg.x, src, 64), q0 = __shfl(sg.y, src, 64);
-                const bool inside = __shfl((int)(isrun && sg.y < c), src, 64) != 0;
+                const int32_t t0 = lane_val(sg.x, src), q0 = lane_val(sg.y, src);
+                const bool inside = lane_val((int)(isrun && sg.y < c), src) != 0;
                 jq += src;
                 return inside ? t0 + (c - q0) : t0;
             }
             jq += 64;
         }
     };
-    int32_t tA = tstart;                 // window k
-    int32_t tA1 = window_end(0);         // window k + 1
-    CAP_ISSUE(baB, bbB, sqB, s1B, btB, 1, tA1);
-    int32_t tA2 = window_end(1);         // window k + 2
+    // ta[i] = first reference position of window k + i
+    int32_t ta[5];
+    ta[0] = tstart;
+    ta[1] = window_end(0);
+    CAP_ISSUE(ba1, bb1, sq1, s11, bt1r, 1, ta[1]);
+    ta[2] = window_end(1);
+    if constexpr (CPD > 2) { CAP_ISSUE(ba2, bb2, sq2, s12, bt2r, 2, ta[2]); ta[3] = window_end(2); }
+    if constexpr (CPD > 3) { CAP_ISSUE(ba3, bb3, sq3, s13, bt3r, 3, ta[3]); ta[4] = window_end(3); }
     // rank of the first candidate position at or behind tstart
     uint32_t ubase = 0;
     {
-        const uint32_t w0 = __shfl((int)s1A.x, 0, 64);
+        const uint32_t w0 = (uint32_t)lane_val((int)s10.x, 0);
         ubase = rk0 + (uint32_t)__popc(w0 & ((1u << (tstart & 31)) - 1u));
         if ((int64_t)(tstart >> 5) > X.nwords - 1) ubase = rk0;
     }
     int head = 0, n = 0;   // the list: entries head .. head + n - 1 (mod CLQ)
+    int jcur = 0;          // segment cursor of the candidate walk
 
-    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint2& s1, uint4& btv, const int k) {
-        const int32_t tB = tA1;
+    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint2& s1, uint32_t& btv, const int k) {
+        const int32_t tA = ta[0], tB = ta[1];
         const int32_t cq = c0 + k * CWQ;
         // ---- this window's bytes and tables -> LDS; its registers take window k + 2
         *reinterpret_cast<uint4*>(wbq + lane * 16) = ba;
         *reinterpret_cast<uint4*>(wbq + 1024 + lane * 16) = bb;
         *reinterpret_cast<uint4*>(wsq + lane * 16) = sq;
-        lbt[lane & 15] = btv;                              // four lanes hold each entry
+        lbt[lane] = btv;                                   // lane = entry * 4 + field
         // the window's bitmap words move to registers of their own: the ones they arrived in are reloaded next
         uint32_t mylo, myhi;
         asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mylo), "=&v"(myhi) : "v"(s1.x), "v"(s1.y));
         const unsigned long long mybits = ((unsigned long long)myhi << 32) | mylo;
-        CAP_ISSUE(ba, bb, sq, s1, btv, k + 2, tA2);
-        const int32_t tA3 = window_end(k + 2);
+        CAP_ISSUE(ba, bb, sq, s1, btv, k + CPD, ta[CPD]);
+        const int32_t ta_next = window_end(k + CPD);
         __builtin_amdgcn_wave_barrier();
-        const int64_t bt0 = tA >> 8;
-        // ---- candidate bits of [tA, tB): 64 positions per lane, 4096 per group
-        for (int64_t wg = tA >> 5; wg <= wlastbit && wg * 32 < tB; wg += 128) {
-            const int64_t w = wg + 2 * lane;
-            unsigned long long bits = mybits;
-            if (wg != (tA >> 5)) {                         // a window across more than 4096 positions (long deletions)
+        const int64_t btb = tA >> 8;
+        // ---- candidate bits of [tA, tB): lane l takes the CPL positions from tA + CPL * l
+        for (int32_t pg = tA; pg < tB; pg += 64 * CPL) {
+            const int32_t p0 = pg + CPL * lane;
+            unsigned long long pair = mybits;
+            if (pg != tA) {                                // a window across more than 2112 positions (long deletions)
                 uint2 t = make_uint2(0, 0);
-                if (w <= wlastbit) __builtin_memcpy(&t, X.bits + w, 8);
+                __builtin_memcpy(&t, X.bits + min((int64_t)(p0 >> 5), X.nwords - 1), 8);
                 CAP_LANDED2(t);
-                bits = ((unsigned long long)t.y << 32) | t.x;
+                pair = ((unsigned long long)t.y << 32) | t.x;
             }
-            if (w > wlastbit) bits = 0;                    // clamped address
-            {   // keep [tA, tB)
-                const int64_t p0 = w * 32;
-                if (p0 + 64 <= tA || p0 >= tB) bits = 0;
-                else {
-                    if (p0 < tA) bits &= ~0ULL << (tA - p0);
-                    if (p0 + 64 > tB) bits &= ~0ULL >> (p0 + 64 - tB);
-                }
-            }
+            const int nvalid = min(tB - p0, CPL);          // <= 0 behind the window (also where the address was clamped)
+            unsigned long long bits = 0;
+            if (nvalid > 0) bits = (pair >> (p0 & 31)) & ((1ULL << nvalid) - 1ULL);
             const int cnt = __popcll(bits);
             const int incl = wave_incl_add(cnt, lane);
-            const int total = __shfl(incl, 63, 64);
+            const int total = lane_val(incl, 63);
             int done = 0, basecnt = 0;
             while (true) {
                 // ---- compaction: the lanes whose bits still fit go into the list
@@ -1026,38 +1038,41 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
                     while (b) {
                         const int i = __ffsll((long long)b) - 1;
                         b &= b - 1;
-                        list[slot & (CLQ - 1)] = make_uint2((uint32_t)(w * 32 + i), uu);
+                        list[slot & (CLQ - 1)] = make_uint2((uint32_t)(p0 + i), uu);
                         slot++; uu++;
                     }
                 }
                 if (nfit) {
-                    const int inc = __shfl(incl, done + nfit - 1, 64);
+                    const int inc = lane_val(incl, done + nfit - 1);
                     n += inc - basecnt; basecnt = inc; done += nfit;
                 }
                 __builtin_amdgcn_wave_barrier();
                 // ---- one candidate per lane; the list is emptied before the window's bytes go away
-                const bool last_piece = done >= 64 && !(wg + 128 <= wlastbit && (wg + 128) * 32 < tB);
+                const bool last_piece = done >= 64 && !(pg + 64 * CPL < tB);
                 while (n >= 64 || ((done < 64 || last_piece) && n > 0)) {
                     const int bn = min(n, 64);
                     const bool act = lane < bn;
                     uint32_t rpos = 0, u = 0;
                     if (act) { const uint2 e = list[(head + lane) & (CLQ - 1)]; rpos = e.x; u = e.y; }
-                    // the segment that holds rpos: last one that starts at or before it
+                    // the segment that holds rpos = the last one that starts at or before it.  Candidates come
+                    // in reference order, so one cursor walks the list once per read (wave-uniform LDS reads)
                     int4 sg = make_int4(0, 0, 0, 0);   // t0, q0, len, flags
-                    bool res = !act;
-                    while (true) {
-                        const int32_t cover = lseg[nw].x;
-                        if (!res && (int32_t)rpos < cover) {
-                            int lo = 0, hi = nw;
-                            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lseg[mid].x <= (int32_t)rpos) lo = mid; else hi = mid; }
-                            sg = lseg[lo];
-                            res = true;
+                    {
+                        const int32_t rlast = lane_val((int)rpos, bn - 1);
+                        int j = jcur;
+                        while (j < ns) {
+                            if (j < jb || j >= jb + nw) {    // lists longer than the LDS window: reload it from j
+                                jb = j; nw = min(ns - jb, CSG);
+                                __builtin_amdgcn_wave_barrier();
+                                CAP_SEGWIN();
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                            const int4 t = lseg[j - jb];
+                            if (uni(t.x) > rlast) break;
+                            if (act && (int32_t)rpos >= t.x) sg = t;
+                            j++;
                         }
-                        if (!__ballot(!res)) break;
-                        jb += nw; nw = min(ns - jb, CSG);        // slide the window forward (lists longer than CSG only)
-                        __builtin_amdgcn_wave_barrier();
-                        CAP_SEGWIN();
-                        __builtin_amdgcn_wave_barrier();
+                        jcur = max(j - 1, jcur);
                     }
                     if (act) {
                         const int32_t d = (int32_t)rpos - sg.x;
@@ -1075,13 +1090,13 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
                             val = insb | (uint32_t)nib2allele(nib) | (qv << 8);
                         }
                         if (store) {
-                            const int64_t bi = (int64_t)(rpos >> 8) - bt0;
+                            const int64_t bi = (int64_t)(rpos >> 8) - btb;
                             uint4 t;
-                            if (bi >= 0 && bi < 16) t = lbt[bi];
+                            if (bi >= 0 && bi < 16) t = *reinterpret_cast<const uint4*>(lbt + 4 * bi);
                             else { t = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)(rpos >> 8), X.nblk - 1)); CAP_LANDED4(t); }
                             // BlockTab: x = lo, y = n, z = boff, w = ufirst
                             const int64_t slot = (int64_t)t.z + (int64_t)(u - t.w) * (int64_t)t.y + (int64_t)(r - (int32_t)t.x);
-                            A.colstore[slot] = (uint16_t)val;
+                            if ((uint64_t)slot < (uint64_t)A.nslots) A.colstore[slot] = (uint16_t)val;
                         }
                     }
                     head = (head + bn) & (CLQ - 1); n -= bn;
@@ -1091,14 +1106,18 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
             }
             ubase += (uint32_t)total;
         }
-        tA = tA1; tA1 = tA2; tA2 = tA3;
+#pragma unroll
+        for (int i = 0; i < CPD; i++) ta[i] = ta[i + 1];
+        ta[CPD] = ta_next;
     };
 
-    // two windows per trip, each with its own registers; a trip's second window may lie behind the
+    // CPD windows per trip, each with its own registers; the last ones of a trip may lie behind the
     // read (empty range): it still issues its loads, so the number in flight never depends on the path
-    for (int k = 0; k < nwin; k += 2) {
-        window(baA, bbA, sqA, s1A, btA, k);
-        window(baB, bbB, sqB, s1B, btB, k + 1);
+    for (int k = 0; k < nwin; k += CPD) {
+        window(ba0, bb0, sq0, s10, bt0r, k);
+        window(ba1, bb1, sq1, s11, bt1r, k + 1);
+        if constexpr (CPD > 2) window(ba2, bb2, sq2, s12, bt2r, k + 2);
+        if constexpr (CPD > 3) window(ba3, bb3, sq3, s13, bt3r, k + 3);
     }
 #undef CAP_ISSUE
 #undef CAP_SEGWIN
