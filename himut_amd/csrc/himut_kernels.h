@@ -254,38 +254,61 @@ __device__ __forceinline__ int wave_incl_max(int v, int) {
     v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x143, 0xc, 0xf, false));
     return v;
 }
+// inclusive count of the lanes up to and including this one for which p holds
+__device__ __forceinline__ int wave_rank_incl(bool p) {
+    const unsigned long long b = __ballot(p);
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u)) + (p ? 1 : 0);
+}
 __device__ __forceinline__ bool cs_is_start(int c) { return c == ':' || c == '*' || c == '+' || c == '-' || c == '='; }
 __device__ __forceinline__ bool cs_is_digit(int c) { return c >= '0' && c <= '9'; }
+// byte-parallel classification of four ASCII bytes; results carry 0x80 in the bytes that qualify
+__device__ __forceinline__ uint32_t cs_eq_bytes(uint32_t w, uint32_t c) {          // bytes equal to c (bytes < 0x80)
+    return ~((w ^ (c * 0x01010101u)) + 0x7f7f7f7fu) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t cs_ge_bytes(uint32_t w, uint32_t c) {          // bytes >= c (bytes < 0x80, c >= 1)
+    return (w + (0x80u - c) * 0x01010101u) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t cs_start_bytes(uint32_t w) {
+    return cs_eq_bytes(w, ':') | cs_eq_bytes(w, '*') | cs_eq_bytes(w, '+') | cs_eq_bytes(w, '-') | cs_eq_bytes(w, '=');
+}
+__device__ __forceinline__ uint32_t cs_payload_bytes(uint32_t w) {                 // digits and letters
+    return (cs_ge_bytes(w, '0') & ~cs_ge_bytes(w, '9' + 1)) | (cs_ge_bytes(w, 'A') & ~cs_ge_bytes(w, 'Z' + 1)) |
+           (cs_ge_bytes(w, 'a') & ~cs_ge_bytes(w, 'z' + 1));
+}
+__device__ __forceinline__ uint32_t cs_pack4(uint32_t f) {                         // 0x80 flags of bytes 0..3 -> bits 0..3
+    const uint32_t g = f >> 7;
+    return (g | (g >> 7) | (g >> 14) | (g >> 21)) & 15u;
+}
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) k_parse_cs(Reads R, Derived D, Params P, int* err) {
+__global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
     __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
-    const int64_t cs0 = R.cs_off[r];
+    const int64_t cs0 = uni(R.cs_off[r]);
     const int64_t sb = (cs0 >> 1) + r;
     ReadMeta M;
-    M.tstart = R.tstart[r]; M.tend = R.tend[r]; M.nseg = 0; M.flags = 0; M.segbase = sb; M.qoff = R.qoff[r];
-    if (R.flag[r] & 0x100) {  // bamlib.py:17
+    M.tstart = uni(R.tstart[r]); M.tend = uni(R.tend[r]); M.nseg = 0; M.flags = 0; M.segbase = sb; M.qoff = uni(R.qoff[r]);
+    if (uni((int)R.flag[r]) & 0x100) {  // bamlib.py:17
         if (lane == 0) {
             M.flags = RF_SECONDARY;
             D.rflag[r] = RF_SECONDARY; D.nseg[r] = 0; D.nmis[r] = 0; D.meta[r] = M;
         }
         return;
     }
-    const int n = (int)(R.cs_off[r + 1] - cs0);
+    const int n = (int)(uni(R.cs_off[r + 1]) - cs0);
     const uint8_t* cs = R.cs + cs0;
     uint8_t* txt = s_txt[wv];
     int32_t* starts = s_start[wv];
     Seg* segs = D.segs + sb;
     int32_t* mis = D.mis + sb;
     uint32_t* mq = D.mq + sb;
-    const int32_t qlen = R.qlen[r];
+    const int32_t qlen = uni(R.qlen[r]);
     // wave-uniform running state
-    int t = M.tstart, q = R.qstart[r];
+    int t = M.tstart, q = uni(R.qstart[r]);
     int ns = 0, nm = 0, bad = 0;
-    long long match = 0, mism = 0;
+    long long match = 0, mism = 0;   // per lane; summed over the wave after the last step
     bool have_carry = false; int carry_start = 0, carry_kind = 0;     // unfinished last operation of the previous step
     bool aligned_open = false; int run_t0 = 0, run_q0 = 0; bool run_ins = false;  // the aligned run still growing
     int last_kind = 0;                                                 // kind of the last finished operation
@@ -294,32 +317,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
     for (int base = 0; base < n; base += PB) {
         const int nb = min(PB, n - base);
         // ---- text of this step (and the 32 bytes before it) into LDS
-        {
-            uint4 v;
-            __builtin_memcpy(&v, cs + base + 16 * lane, 16);       // buffers carry 256 bytes of slack
-            *reinterpret_cast<uint4*>(txt + 32 + 16 * lane) = v;
-            if (lane < 2) {
-                uint4 b = make_uint4(0, 0, 0, 0);
-                if (base >= 32) __builtin_memcpy(&b, cs + base - 32 + 16 * lane, 16);
-                *reinterpret_cast<uint4*>(txt + 16 * lane) = b;
-            }
+        uint4 v;
+        __builtin_memcpy(&v, cs + base + 16 * lane, 16);           // buffers carry 256 bytes of slack
+        *reinterpret_cast<uint4*>(txt + 32 + 16 * lane) = v;
+        if (lane < 2) {
+            uint4 b = make_uint4(0, 0, 0, 0);
+            if (base >= 32) __builtin_memcpy(&b, cs + base - 32 + 16 * lane, 16);
+            *reinterpret_cast<uint4*>(txt + 16 * lane) = b;
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- operation starts in this lane's 16 bytes
+        // ---- operation starts in this lane's 16 bytes, four bytes at a time in the registers they came in
         uint32_t mask16 = 0;
-        int last_start = -1;
+        {
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+            uint32_t okmask = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int pos = 16 * lane + i;
-            const int c = txt[32 + pos];
-            if (pos < nb) {
-                if (cs_is_start(c)) { mask16 |= 1u << i; last_start = base + pos; }
-                else if (!cs_is_digit(c) && !is_alpha(c)) bad = HIMUT_ERR_CS;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t st = cs_start_bytes(words[k]), ok = st | cs_payload_bytes(words[k]);
+                mask16 |= cs_pack4(st) << (4 * k);
+                okmask |= cs_pack4(ok & ~(words[k] & 0x80808080u)) << (4 * k);
             }
+            const int nhere = min(max(nb - 16 * lane, 0), 16);
+            const uint32_t keep = (1u << nhere) - 1u;
+            mask16 &= keep;
+            if (~okmask & keep) bad = HIMUT_ERR_CS;                  // a byte the reference's pattern has no place for
         }
         const int cnt = __popc(mask16);
         const int incl = wave_incl_add(cnt, lane);
-        const int total = __shfl(incl, 63, 64);
+        const int total = lane_val(incl, 63);
         const int off0 = have_carry ? 1 : 0;
         if (have_carry && lane == 0) starts[0] = carry_start;
         {
@@ -397,7 +422,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
                     nseg_here++;
                 } else if (prev_kind == '+') bad = HIMUT_ERR_CS;    // two insertions in a row: unsupported
             }
-            const int iseg = wave_incl_add(nseg_here, lane);
+            const int iseg = wave_rank_incl(nseg_here >= 1) + wave_rank_incl(nseg_here == 2);
             if (nseg_here) {
                 int w = ns + iseg - nseg_here;
                 if (run_before) segs[w++] = sg_run;
@@ -411,34 +436,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
                 if (ref != 'N') { ra = char2allele(ref); if (ra < 0) bad = HIMUT_ERR_BASE; }   // bamlib.py:188
             }
             const bool ismis = indel || (sub && ref != 'N');
-            const int imis = wave_incl_add(ismis ? 1 : 0, lane);
+            const int imis = wave_rank_incl(ismis);
             if (ismis) {
                 const int w = nm + imis - 1;
                 mis[w] = tk + 1;
                 mq[w] = sub ? (((uint32_t)qk << 5) | 16u | ((uint32_t)(ra & 3) << 2) | (uint32_t)(aa & 3)) : ((uint32_t)qk << 5);
             }
             // identity counts (bamlib.py:47-63)
-            long long dmatch = (valid && (kind == ':' || kind == '=')) ? dt : 0;
-            long long dmism = sub ? 1 : (indel ? len : 0);
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { dmatch += __shfl_xor(dmatch, d, 64); dmism += __shfl_xor(dmism, d, 64); }
-            match += dmatch; mism += dmism;
+            match += (valid && (kind == ':' || kind == '=')) ? dt : 0;
+            mism += sub ? 1 : (indel ? len : 0);
             if (__ballot(valid && kind == '=')) has_long = true;
             // ---- carry the round's end state
             const int nvalid = min(64, nops - k0);
             const unsigned long long ib = __ballot(indel);
-            t = __shfl(ta, nvalid - 1, 64); q = __shfl(qa, nvalid - 1, 64);
-            ns += __shfl(iseg, 63, 64); nm += __shfl(imis, 63, 64);
+            t = lane_val(ta, nvalid - 1); q = lane_val(qa, nvalid - 1);
+            ns += lane_val(iseg, 63); nm += lane_val(imis, 63);
             if (ib) {
                 const int L = 63 - __clzll((long long)ib);
-                run_t0 = __shfl(ta, L, 64); run_q0 = __shfl(qa, L, 64); run_ins = __shfl(kind, L, 64) == '+';
+                run_t0 = lane_val(ta, L); run_q0 = lane_val(qa, L); run_ins = lane_val(kind, L) == '+';
                 aligned_open = L < nvalid - 1;
             } else if (!aligned_open) {
                 // the run opens at the first operation of this round
-                run_t0 = __shfl(tk, 0, 64); run_q0 = __shfl(qk, 0, 64); run_ins = last_kind == '+';
+                run_t0 = lane_val(tk, 0); run_q0 = lane_val(qk, 0); run_ins = last_kind == '+';
                 aligned_open = true;
             }
-            last_kind = __shfl(kind, nvalid - 1, 64);
+            last_kind = lane_val(kind, nvalid - 1);
             if (__ballot(bad != 0)) break;
         }
         if (__ballot(bad != 0)) break;
@@ -467,6 +489,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
         if (aligned_open || last_kind == '+') ns++;
         if (t != M.tend || q > qlen) bad = HIMUT_ERR_CS;   // cs inconsistent with CIGAR / SEQ
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { match += __shfl_xor(match, d, 64); mism += __shfl_xor(mism, d, 64); }
     if (lane == 0) {
         if (bad) { set_err(err, bad); ns = 0; nm = 0; }
         // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow in k_read_filters
