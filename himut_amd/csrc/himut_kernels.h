@@ -540,22 +540,37 @@ __global__ void __launch_bounds__(256) k_check_longcs(Reads R, Derived D, int* e
 // runs on its own stream beside k_parse_cs: one is bound by HBM, the other by VALU.
 __global__ void __launch_bounds__(256) k_bq_sum(Reads R, uint32_t* bqsum) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 4 + uni((int)(threadIdx.x >> 6));
     if (r >= R.n) return;
-    if (R.flag[r] & 0x100) return;
-    const uint8_t* base = R.bq + R.qoff[r];
-    const int n = R.qlen[r];
+    if (uni((int)R.flag[r]) & 0x100) return;
+    const uint8_t* base = R.bq + uni(R.qoff[r]) + lane * 16;
+    const int n = uni(R.qlen[r]);
     uint32_t sum = 0;
-    for (int o = lane * 16; o < n; o += 64 * 16) {
-        uint4 v = *reinterpret_cast<const uint4*>(base + o);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int nfull = n & ~1023;                 // whole 1 KB steps: four byte sums per lane and step
+    int o = 0;
+#define BQ_ADD(V) do { sum = __builtin_amdgcn_sad_u8(V.x, 0u, sum); sum = __builtin_amdgcn_sad_u8(V.y, 0u, sum); \
+        sum = __builtin_amdgcn_sad_u8(V.z, 0u, sum); sum = __builtin_amdgcn_sad_u8(V.w, 0u, sum); } while (0)
+    for (; o + 4096 <= nfull; o += 4096) {       // four loads in flight per lane
+        const uint4 a = *reinterpret_cast<const uint4*>(base + o);
+        const uint4 b = *reinterpret_cast<const uint4*>(base + o + 1024);
+        const uint4 c = *reinterpret_cast<const uint4*>(base + o + 2048);
+        const uint4 d = *reinterpret_cast<const uint4*>(base + o + 3072);
+        BQ_ADD(a); BQ_ADD(b); BQ_ADD(c); BQ_ADD(d);
+    }
+    for (; o < nfull; o += 1024) {
+        const uint4 a = *reinterpret_cast<const uint4*>(base + o);
+        BQ_ADD(a);
+    }
+#undef BQ_ADD
+    if (nfull + lane * 16 < n) {                 // the last, partial step: bytes behind the read are masked off
+        const uint4 v = *reinterpret_cast<const uint4*>(base + nfull);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int rem = n - (o + 4 * k);
+            const int rem = n - (nfull + lane * 16 + 4 * k);
             uint32_t x = w[k];
             if (rem < 4) x = rem <= 0 ? 0u : (x & (0xffffffffu >> (8 * (4 - rem))));
-            uint32_t s2 = (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
-            sum += (s2 & 0xffffu) + (s2 >> 16);
+            sum = __builtin_amdgcn_sad_u8(x, 0u, sum);
         }
     }
 #pragma unroll
