@@ -824,7 +824,9 @@ __global__ void __launch_bounds__(256) k_window_index(Reads R, int64_t nblk, int
     if (b >= nblk) return;
     const int32_t p0 = (int32_t)(b << WIN_SHIFT), p1 = (int32_t)((b + 1) << WIN_SHIFT);
     const int64_t hi = lower_bound(R.tstart, (int64_t)0, R.n, p1);           // reads with tstart < p1
-    const int64_t lo = lower_bound(R.prefmax_tend, (int64_t)0, hi, p0);      // running max of tend >= p0
+    // a read ending exactly at p0 still belongs: a trailing insertion is counted at tend (caller.py:66-67)
+    int64_t lo = lower_bound(R.prefmax_tend, (int64_t)0, hi, p0);            // running max of tend >= p0
+    while (lo < hi && R.tend[lo] < p0) lo++;                                 // ... and the first read that really reaches the block
     winlo[b] = (int32_t)lo;
     winhi[b] = (int32_t)hi;
 }
