@@ -28,6 +28,8 @@ def _load():
         L = ctypes.CDLL(path)
         L.bam_load.restype = ctypes.c_void_p
         L.bam_load.argtypes = [ctypes.c_char_p]
+        L.bam_load_threads.restype = ctypes.c_void_p
+        L.bam_load_threads.argtypes = [ctypes.c_char_p, ctypes.c_int]
         for f in ("bam_error", "bam_header_text"):
             getattr(L, f).restype = ctypes.c_char_p
             getattr(L, f).argtypes = [ctypes.c_void_p]
@@ -57,11 +59,12 @@ def _p(a):
 class BamFile:
     """All contigs of one BAM, loaded once."""
 
-    def __init__(self, path):
+    def __init__(self, path, threads=0):
+        """threads: BGZF inflate threads (0 = HIMUT_INGEST_THREADS or one per hardware thread, at most 16)."""
         L = _load()
         if not os.path.exists(path):
             raise FileNotFoundError(path)
-        h = L.bam_load(path.encode())
+        h = L.bam_load_threads(path.encode(), int(threads))
         try:
             err = L.bam_error(h).decode()
             if err:
@@ -105,11 +108,11 @@ class BamFile:
 _cache = {}
 
 
-def read_bam(path):
+def read_bam(path, threads=0):
     key = (os.path.abspath(path), os.path.getmtime(path))
     if key not in _cache:
         _cache.clear()
-        _cache[key] = BamFile(path)
+        _cache[key] = BamFile(path, threads)
     return _cache[key]
 
 

@@ -70,7 +70,7 @@ def build_host(force=False):
     if not force and _newer(HOST_LIB, srcs + [os.path.join(INCLUDE, "himut_hip.h")]):
         return HOST_LIB
     _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE,
-          "-o", HOST_LIB] + srcs + ["-lz"])
+          "-o", HOST_LIB] + srcs + ["-lz", "-ldl"])
     return HOST_LIB
 
 

@@ -9,10 +9,21 @@
 // Record fields kept: reference_start, reference_end (from CIGAR), leading soft clip
 // (query_alignment_start), query length, MAPQ, FLAG, packed SEQ and QUAL as stored in the
 // BAM, the cs:Z and tp:A tags, and the index of the first read with the same name.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <future>
+#include <thread>
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -20,54 +31,191 @@
 
 namespace {
 
-struct Bgzf {
-    FILE* f = nullptr;
-    std::vector<uint8_t> in, out;
-    size_t pos = 0, len = 0;
-    bool eof = false;
-    std::string err;
+// BGZF reader: the file is mapped, its block headers are walked once (no inflate), and
+// the blocks are inflated a window (~64 MB of output) at a time by a pool of threads --
+// BGZF blocks are independent deflate streams.  The window after the one being parsed is
+// inflated in the background, so record parsing and inflate overlap.
+// libdeflate (about twice as fast as zlib's inflate) is used when the shared library is on the
+// system; its three entry points are looked up at run time, zlib is the fallback.
+struct Deflate {
+    void* (*alloc)() = nullptr;
+    int (*run)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    Deflate() {
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        run = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        release = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !run || !release) { alloc = nullptr; run = nullptr; release = nullptr; }
+    }
+    bool ok() const { return run != nullptr; }
+};
+const Deflate& deflate_lib() { static Deflate d; return d; }
 
-    bool next_block() {
-        uint8_t hdr[18];
-        size_t n = fread(hdr, 1, 18, f);
-        if (n == 0) { eof = true; return false; }
-        if (n != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { err = "not a BGZF block"; return false; }
-        const unsigned xlen = hdr[10] | (hdr[11] << 8);
-        // BC subfield is the first extra field in every BGZF writer; tolerate others by scanning
-        std::vector<uint8_t> extra(xlen);
-        memcpy(extra.data(), hdr + 12, xlen < 6 ? xlen : 6);
-        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6) { err = "truncated BGZF header"; return false; }
-        int bsize = -1;
-        for (size_t k = 0; k + 4 <= xlen;) {
-            const unsigned slen = extra[k + 2] | (extra[k + 3] << 8);
-            if (extra[k] == 'B' && extra[k + 1] == 'C' && slen == 2) bsize = extra[k + 4] | (extra[k + 5] << 8);
-            k += 4 + slen;
+struct BlockRef {
+    size_t cdata_off;     // first byte of the deflate stream
+    uint32_t cdata_len;
+    uint32_t isize;       // inflated size
+    size_t uoff;          // offset inside its window
+};
+
+struct Bgzf {
+    const uint8_t* base = nullptr;   // mapped file
+    size_t fsize = 0;
+    int fd = -1;
+    std::vector<uint8_t> owned;      // fallback when mmap is not possible
+    std::vector<BlockRef> blocks;
+    std::vector<size_t> win_first;   // first block of every window, + one past the end
+    int threads = 1;
+    std::string err;
+    bool eof = false;
+
+    std::vector<uint8_t> buf[2];     // two windows: one being parsed, one being inflated
+    size_t cur = 0;                  // window being parsed
+    size_t pos = 0, len = 0;
+    std::future<std::string> pending;
+    bool started = false;
+
+    size_t WINDOW = (size_t)64 << 20;   // HIMUT_INGEST_WINDOW_KB overrides (tests use small windows)
+
+    bool open(const char* path, int nthreads) {
+        threads = nthreads < 1 ? 1 : nthreads;
+        if (const char* e = getenv("HIMUT_INGEST_WINDOW_KB")) { const long kb = atol(e); if (kb > 0) WINDOW = (size_t)kb << 10; }
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) { err = std::string("cannot open ") + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0) { err = "fstat failed"; return false; }
+        fsize = (size_t)st.st_size;
+        if (fsize == 0) { err = "not a BAM file"; return false; }
+        void* m = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            base = (const uint8_t*)m;
+            (void)madvise(m, fsize, MADV_SEQUENTIAL);
+        } else {
+            owned.resize(fsize);
+            size_t got = 0;
+            while (got < fsize) {
+                const ssize_t k = ::read(fd, owned.data() + got, fsize - got);
+                if (k <= 0) { err = "read failed"; return false; }
+                got += (size_t)k;
+            }
+            base = owned.data();
         }
-        if (bsize < 0) { err = "BGZF block without BC field"; return false; }
-        const size_t cdata = (size_t)bsize + 1 - 12 - xlen - 8;
-        in.resize(cdata + 8);
-        if (fread(in.data(), 1, cdata + 8, f) != cdata + 8) { err = "truncated BGZF block"; return false; }
-        const uint32_t isize = in[cdata + 4] | (in[cdata + 5] << 8) | (in[cdata + 6] << 16) | ((uint32_t)in[cdata + 7] << 24);
-        out.resize(isize);
-        if (isize) {
+        return scan();
+    }
+    void close() {
+        if (pending.valid()) (void)pending.get();
+        if (base && owned.empty()) munmap((void*)base, fsize);
+        if (fd >= 0) ::close(fd);
+        base = nullptr; fd = -1;
+    }
+    // block headers -> (offset, compressed length, inflated length); windows of ~WINDOW output bytes
+    bool scan() {
+        size_t p = 0, wbytes = 0;
+        win_first.push_back(0);
+        while (p < fsize) {
+            if (p + 18 > fsize) { err = "truncated BGZF header"; return false; }
+            const uint8_t* h = base + p;
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
+            const unsigned xlen = h[10] | (h[11] << 8);
+            if (p + 12 + xlen > fsize) { err = "truncated BGZF header"; return false; }
+            int bsize = -1;
+            for (size_t k = 0; k + 4 <= xlen;) {      // BC is normally the first subfield; tolerate others
+                const uint8_t* e = h + 12 + k;
+                const unsigned slen = e[2] | (e[3] << 8);
+                if (e[0] == 'B' && e[1] == 'C' && slen == 2 && k + 6 <= xlen) bsize = e[4] | (e[5] << 8);
+                k += 4 + slen;
+            }
+            if (bsize < 0) { err = "BGZF block without BC field"; return false; }
+            const size_t total = (size_t)bsize + 1;
+            if (total < 12 + xlen + 8 || p + total > fsize) { err = "truncated BGZF block"; return false; }
+            BlockRef b;
+            b.cdata_off = p + 12 + xlen;
+            b.cdata_len = (uint32_t)(total - 12 - xlen - 8);
+            const uint8_t* t = base + p + total - 4;
+            b.isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (wbytes && wbytes + b.isize > WINDOW) { win_first.push_back(blocks.size()); wbytes = 0; }
+            b.uoff = wbytes;
+            wbytes += b.isize;
+            blocks.push_back(b);
+            p += total;
+        }
+        win_first.push_back(blocks.size());
+        return true;
+    }
+    size_t n_windows() const { return win_first.size() - 1; }
+    // inflates window w into out with the pool; returns an error text or ""
+    std::string inflate_window(size_t w, std::vector<uint8_t>& out) const {
+        const size_t b0 = win_first[w], b1 = win_first[w + 1];
+        size_t total = 0;
+        for (size_t k = b0; k < b1; k++) total += blocks[k].isize;
+        out.resize(total);
+        std::atomic<size_t> next(b0);
+        std::atomic<int> bad(0);
+        auto work = [&]() {
+            const Deflate& L = deflate_lib();
+            void* dec = (L.ok() && !getenv("HIMUT_INGEST_ZLIB")) ? L.alloc() : nullptr;   // the variable forces zlib
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
-            if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
-            zs.next_in = in.data(); zs.avail_in = (uInt)cdata;
-            zs.next_out = out.data(); zs.avail_out = isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) { err = "inflate failed"; return false; }
+            if (!dec && inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= b1) break;
+                const BlockRef& b = blocks[k];
+                if (!b.isize) continue;
+                if (dec) {
+                    size_t got = 0;
+                    if (L.run(dec, base + b.cdata_off, b.cdata_len, out.data() + b.uoff, b.isize, &got) != 0 || got != b.isize) { bad = 2; break; }
+                } else {
+                    inflateReset(&zs);
+                    zs.next_in = (Bytef*)(base + b.cdata_off); zs.avail_in = b.cdata_len;
+                    zs.next_out = out.data() + b.uoff; zs.avail_out = b.isize;
+                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 2; break; }
+                }
+            }
+            if (dec) L.release(dec); else inflateEnd(&zs);
+        };
+        const int nt = (int)std::min<size_t>((size_t)threads, b1 - b0 ? b1 - b0 : 1);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+        return bad == 0 ? "" : (bad == 1 ? "inflateInit2 failed" : "inflate failed");
+    }
+    bool next_window() {
+        if (!started) {
+            started = true;
+            if (n_windows() == 0) { eof = true; return false; }
+            const std::string e = inflate_window(0, buf[0]);
+            if (!e.empty()) { err = e; return false; }
+            cur = 0;
+        } else {
+            if (cur + 1 >= n_windows()) { eof = true; return false; }
+            const std::string e = pending.get();
+            if (!e.empty()) { err = e; return false; }
+            cur++;
         }
-        pos = 0; len = isize;
+        if (cur + 1 < n_windows()) {
+            const size_t w = cur + 1;
+            pending = std::async(std::launch::async, [this, w]() { return inflate_window(w, buf[w & 1]); });
+        }
+        pos = 0; len = buf[cur & 1].size();
         return true;
+    }
+    // n bytes of the stream without a copy when they lie inside the current window (scratch otherwise)
+    const uint8_t* view(size_t n, std::vector<uint8_t>& scratch) {
+        if (pos == len && !next_window()) return nullptr;
+        if (len - pos >= n) { const uint8_t* p = buf[cur & 1].data() + pos; pos += n; return p; }
+        scratch.resize(n);
+        return read(scratch.data(), n) ? scratch.data() : nullptr;
     }
     bool read(void* dst, size_t n) {
         uint8_t* d = (uint8_t*)dst;
         while (n) {
-            if (pos == len) { if (!next_block()) return false; continue; }
-            size_t k = len - pos < n ? len - pos : n;
-            memcpy(d, out.data() + pos, k);
+            if (pos == len) { if (!next_window()) return false; continue; }
+            const size_t k = len - pos < n ? len - pos : n;
+            memcpy(d, buf[cur & 1].data() + pos, k);
             d += k; pos += k; n -= k;
         }
         return true;
@@ -173,15 +321,20 @@ struct BgzfWriter {
 
 extern "C" {
 
-// Loads the whole file.  Returns a handle (never null); check bam_error().
-void* bam_load(const char* path) {
+// Loads the whole file with `threads` inflate threads (0: one per hardware thread, at most 16).
+// Returns a handle (never null); check bam_error().
+void* bam_load_threads(const char* path, int threads) {
     Bam* B = new Bam();
     Bgzf z;
-    z.f = fopen(path, "rb");
-    if (!z.f) { B->err = std::string("cannot open ") + path; return B; }
+    if (threads <= 0) {
+        const char* e = getenv("HIMUT_INGEST_THREADS");
+        threads = e ? atoi(e) : 0;
+        if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    }
+    if (!z.open(path, threads)) { B->err = z.err; z.close(); return B; }
     uint8_t magic[4];
     uint8_t b4[4];
-    auto fail = [&](const std::string& m) { B->err = m.empty() ? "unexpected end of BAM" : m; fclose(z.f); return (void*)B; };
+    auto fail = [&](const std::string& m) { B->err = m.empty() ? "unexpected end of BAM" : m; z.close(); return (void*)B; };
     if (!z.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) return fail(z.err.empty() ? "not a BAM file" : z.err);
     if (!z.read(b4, 4)) return fail(z.err);
     const uint32_t l_text = le32(b4);
@@ -201,13 +354,13 @@ void* bam_load(const char* path) {
         B->contigs[i].name = nm;
         B->contigs[i].length = le32(b4);
     }
-    std::vector<uint8_t> rec;
+    std::vector<uint8_t> scratch;
     for (;;) {
         if (!z.read(b4, 4)) { if (z.eof && z.err.empty()) break; return fail(z.err); }
         const uint32_t bs = le32(b4);
         if (bs < 32) return fail("BAM record too short");
-        rec.resize(bs);
-        if (!z.read(rec.data(), bs)) return fail(z.err.empty() ? "truncated BAM record" : z.err);
+        const uint8_t* rec = z.view(bs, scratch);
+        if (!rec) return fail(z.err.empty() ? "truncated BAM record" : z.err);
         const int32_t ref_id = (int32_t)le32(&rec[0]);
         const int32_t pos = (int32_t)le32(&rec[4]);
         const uint8_t l_read_name = rec[8];
@@ -236,7 +389,7 @@ void* bam_load(const char* path) {
         const uint8_t* qual = &rec[o];
         o += l_seq;
         const uint8_t* cs; size_t cs_len; uint8_t tp;
-        if (!scan_tags(&rec[o], rec.data() + bs, &cs, &cs_len, &tp)) return fail("malformed auxiliary data");
+        if (!scan_tags(&rec[o], rec + bs, &cs, &cs_len, &tp)) return fail("malformed auxiliary data");
         if (!cs) { B->n_missing_cs++; continue; }
         Contig& C = B->contigs[(size_t)ref_id];
         if (!C.tstart.empty() && pos < C.tstart.back()) B->n_unsorted++;
@@ -252,19 +405,21 @@ void* bam_load(const char* path) {
         C.qid.push_back(it.first->second);
         C.qoff.push_back(C.bases_padded);
         const int64_t padded = ((int64_t)l_seq + 31) & ~(int64_t)31;
-        C.seq.resize((size_t)((C.bases_padded + padded) / 2), 0);
-        memcpy(&C.seq[(size_t)(C.bases_padded / 2)], seq, (l_seq + 1) / 2);
-        if (l_seq & 1) C.seq[(size_t)(C.bases_padded / 2) + l_seq / 2] &= 0xf0;
+        C.seq.insert(C.seq.end(), seq, seq + (l_seq + 1) / 2);
+        if (l_seq & 1) C.seq.back() &= 0xf0;
+        C.seq.resize((size_t)((C.bases_padded + padded) / 2), 0);     // pad to the 32-base boundary
+        C.bq.insert(C.bq.end(), qual, qual + l_seq);
         C.bq.resize((size_t)(C.bases_padded + padded), 0);
-        memcpy(&C.bq[(size_t)C.bases_padded], qual, l_seq);
         C.bases_padded += padded;
         C.cs_off.push_back((int64_t)C.cs.size());
         C.cs.insert(C.cs.end(), cs, cs + cs_len);
     }
     for (auto& C : B->contigs) { C.cs_off.push_back((int64_t)C.cs.size()); C.first_by_name.clear(); }
-    fclose(z.f);
+    z.close();
     return B;
 }
+
+void* bam_load(const char* path) { return bam_load_threads(path, 0); }
 
 const char* bam_error(void* h) { return ((Bam*)h)->err.c_str(); }
 const char* bam_header_text(void* h) { return ((Bam*)h)->header_text.c_str(); }

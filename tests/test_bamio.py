@@ -81,3 +81,19 @@ def test_missing_cs_tag_is_an_error(tmp_path):
     assert bamio.read_bam(path).batches["c"].n == s.batch.n
     with pytest.raises(FileNotFoundError):
         bamio.read_bam(str(tmp_path / "nope.bam"))
+
+
+def test_threads_and_small_windows_agree(tmp_path, monkeypatch):
+    """Inflate threads and window size are invisible in the result: records that straddle BGZF
+    blocks and inflate windows are reassembled; zlib and libdeflate give the same bytes."""
+    s = synth.generate(synth.SynthConfig(seed=43, contig_len=60_000, read_len_mean=4000, read_len_sd=900,
+                                         read_len_min=1000, read_len_max=8000, name="chr3"))
+    path = str(tmp_path / "y.bam")
+    bamio.write_bam(path, [s.batch])
+    ref = bamio.BamFile(path, threads=1).batches["chr3"]
+    _same(ref, s.batch)
+    monkeypatch.setenv("HIMUT_INGEST_WINDOW_KB", "96")          # windows of one or two BGZF blocks
+    for th in (1, 3, 8):
+        _same(bamio.BamFile(path, threads=th).batches["chr3"], s.batch)
+    monkeypatch.setenv("HIMUT_INGEST_ZLIB", "1")
+    _same(bamio.BamFile(path, threads=2).batches["chr3"], s.batch)
