@@ -33,6 +33,7 @@
 #define ORC_ERR_CAPACITY 5
 #define ORC_ERR_COVER 6       /* KeyError in tpos2qbase (haplib.py:51) */
 #define ORC_ERR_NOMEM 7
+#define ORC_ERR_ARG 8         /* not restated (phased normcounts) / IndexError on the reference string */
 
 enum {
     ST_PASS = 0, ST_LOWBQ = 1, ST_LOWGQ = 2, ST_INDEL = 3, ST_HET = 4, ST_HETALT = 5, ST_HOMALT = 6,
@@ -658,6 +659,283 @@ done:
     if (n_candidates) *n_candidates = m_sbs;
     for (int64_t r = 0; r < n; r++) free(OL[r].ops);
     free(OL); free(som_seen); free(ccs_seen);
+    return rc;
+}
+
+/* ---------------- normcounts.get_callable_tricounts ---------------- */
+
+/* PLs of the ten genotypes with one allele left out: gtlib.get_germ_gq (gtlib.py:138-174) */
+static int column_pls_without(const pile_entry* col, int32_t depth, int skip_bi, const int st[10], const orc_lut* L,
+                              double pl[10]) {
+    for (int g = 0; g < 10; g++) {
+        int b1 = GT_LST[g][0], b2 = GT_LST[g][1];
+        double gt_pl = 0.0;
+        for (int bi = 0; bi < 4; bi++) {
+            if (bi == skip_bi) continue; /* gtlib.py:151-152 */
+            int base = BASES[bi];
+            const double* lut;
+            if (b1 == b2 && (base == b1 || base == b2)) lut = L->lut_hom;
+            else if (b1 != b2 && (base == b1 || base == b2)) lut = L->lut_het;
+            else lut = L->lut_err;
+            double s = 0.0;
+            for (int32_t k = 0; k < depth; k++) {
+                if (col[k].allele != bi) continue;
+                if (col[k].bq == 0) return ORC_ERR_BQ0;
+                s = s + lut[col[k].bq];
+            }
+            gt_pl = gt_pl + s;
+        }
+        gt_pl = gt_pl + L->log_prior[st[g]];
+        pl[g] = gt_pl * -10.0; /* gtlib.py:164 */
+    }
+    return ORC_OK;
+}
+
+/* get_tri_context (normcounts.py:49-63) as class ids; cls maps a reference byte to its id, n_cls = 'N' */
+static int64_t tri_index(const uint8_t* seq, int64_t len, int64_t pos, const uint8_t* cls, int K, int n_cls) {
+    uint8_t t[3];
+    if (pos - 1 < 0 || pos + 2 > len) { t[0] = t[1] = t[2] = 'N'; } /* seq[pos-1:pos+2] shorter than 3 (or empty for pos 0) */
+    else {
+        t[0] = seq[pos - 1]; t[1] = seq[pos]; t[2] = seq[pos + 1];
+        if (t[1] == 'A' || t[1] == 'G') { /* purine: reverse complement, unknown letters -> N (mutlib.py:15) */
+            uint8_t r[3];
+            for (int i = 0; i < 3; i++) {
+                uint8_t b = t[2 - i];
+                r[i] = b == 'A' ? 'T' : b == 'T' ? 'A' : b == 'G' ? 'C' : b == 'C' ? 'G' : 'N';
+            }
+            t[0] = r[0]; t[1] = r[1]; t[2] = r[2];
+        }
+    }
+    (void)n_cls;
+    return ((int64_t)cls[t[0]] * K + cls[t[1]]) * K + cls[t[2]];
+}
+
+/* Non-phased get_callable_tricounts (normcounts.py:206-421).
+ * refseq: the contig as the FASTA holds it (case preserved); cls[256]: byte -> class id (< K); alt_order[ri][0..2]:
+ * list(base_set.difference(ref)) as alleles 0..3 for ref allele ri (python set order, supplied by the caller).
+ * Outputs: ccs_tri/ref_tri [K*K*K] (added to), log[14]. */
+int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, int64_t nchunks, const int32_t* cstart,
+                   const int32_t* cend, const uint64_t* pon, int64_t npon, const uint64_t* com, int64_t ncom,
+                   const uint8_t* refseq, int64_t reflen, const uint8_t* cls, int K, const uint8_t* alt_order,
+                   int non_human_sample, int64_t* ccs_tri, int64_t* ref_tri, int64_t log[14]) {
+    int rc = ORC_OK;
+    const int64_t n = R->n;
+    orc_oplist* OL = (orc_oplist*)calloc((size_t)(n > 0 ? n : 1), sizeof(orc_oplist));
+    int32_t maxqid = 0;
+    uint8_t* seen = NULL;
+    int64_t m[14];
+    memset(m, 0, sizeof(m));
+    if (!OL) return ORC_ERR_NOMEM;
+    if (P->phase) { free(OL); return ORC_ERR_ARG; } /* phased normcounts: not restated yet */
+    for (int64_t r = 0; r < n; r++) {
+        if (R->flag[r] & 0x100) continue; /* bamlib.py:17, normcounts.py:291 */
+        rc = parse_cs(R, r, &OL[r]);
+        if (rc) goto done;
+        if (R->qid[r] > maxqid) maxqid = R->qid[r];
+    }
+    seen = (uint8_t*)calloc((size_t)maxqid + 8, 1);
+    if (!seen) { rc = ORC_ERR_NOMEM; goto done; }
+
+    for (int64_t c = 0; c < nchunks && !rc; c++) {
+        const int32_t s = cstart[c], e = cend[c];
+        if (s > e) { rc = ORC_ERR_CHUNK; goto done; }
+        /* fetch(chrom, s, e): normcounts.py:289 */
+        int64_t nfetch = 0;
+        int64_t* fetch = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+        int32_t pmin = INT32_MAX, pmax = 0;
+        for (int64_t r = 0; r < n; r++) {
+            if (R->tstart[r] >= e) break;
+            if (R->tend[r] <= s) continue;
+            if (R->flag[r] & 0x100) continue;
+            fetch[nfetch++] = r;
+            if (R->tstart[r] < pmin) pmin = R->tstart[r];
+            int64_t t = R->tstart[r];
+            for (int32_t k = 0; k < OL[r].nops; k++) t += OL[r].ops[k].ref_len;
+            if (t + 1 > pmax) pmax = (int32_t)(t + 1);
+        }
+        if (nfetch == 0) { free(fetch); continue; }
+        const int64_t W = (int64_t)pmax - pmin + 1;
+        uint32_t* counts = (uint32_t*)calloc((size_t)W * 6, sizeof(uint32_t));
+        int64_t* loff = (int64_t*)calloc((size_t)W + 1, sizeof(int64_t));
+        uint32_t* callable = (uint32_t*)calloc((size_t)W, sizeof(uint32_t)); /* rpos2count, normcounts.py:286 */
+        for (int64_t f = 0; f < nfetch; f++) {
+            int64_t r = fetch[f];
+            int64_t tpos = R->tstart[r];
+            for (int32_t k = 0; k < OL[r].nops; k++) {
+                const orc_op* op = &OL[r].ops[k];
+                if (op->state == 1) for (int32_t i = 0; i < op->ref_len; i++) loff[tpos + i - pmin + 1]++;
+                else if (op->state == 2) loff[tpos - pmin + 1]++;
+                tpos += op->ref_len;
+            }
+        }
+        for (int64_t w = 0; w < W; w++) loff[w + 1] += loff[w];
+        pile_entry* ent = (pile_entry*)malloc(sizeof(pile_entry) * (size_t)(loff[W] > 0 ? loff[W] : 1));
+        int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)W);
+        memcpy(fill, loff, sizeof(int64_t) * (size_t)W);
+
+        for (int64_t f = 0; f < nfetch && !rc; f++) {
+            int64_t r = fetch[f];
+            const orc_oplist* ol = &OL[r];
+            /* update_allelecounts: normcounts.py:113-140 */
+            int64_t tpos = R->tstart[r];
+            int64_t qpos = R->qstart[r];
+            int64_t match_count = 0, mismatch_count = 0;
+            for (int32_t k = 0; k < ol->nops; k++) {
+                const orc_op* op = &ol->ops[k];
+                if (op->state == 1) {
+                    for (int32_t i = 0; i < op->ref_len; i++) {
+                        int b = base2idx(match_base(R, r, op, qpos, i));
+                        if (b < 0) { rc = ORC_ERR_BASE; break; }
+                        int64_t w = tpos + i - pmin;
+                        counts[w * 6 + b]++;
+                        pile_entry* pe = &ent[fill[w]++];
+                        pe->allele = (uint8_t)b; pe->bq = R->bq[R->qoff[r] + qpos + i]; pe->read = (int32_t)r;
+                    }
+                    match_count += op->ref_len;
+                } else if (op->state == 2) {
+                    int b = base2idx(op->alt);
+                    if (b < 0) { rc = ORC_ERR_BASE; break; }
+                    int64_t w = tpos - pmin;
+                    counts[w * 6 + b]++;
+                    pile_entry* pe = &ent[fill[w]++];
+                    pe->allele = (uint8_t)b; pe->bq = R->bq[R->qoff[r] + qpos]; pe->read = (int32_t)r;
+                    mismatch_count += op->alt_len;
+                } else if (op->state == 3) {
+                    counts[(tpos - pmin) * 6 + 4]++;
+                    mismatch_count += op->alt_len;
+                } else {
+                    for (int32_t j = 0; j < op->ref_len; j++) counts[(tpos + j - pmin) * 6 + 5]++;
+                    mismatch_count += op->ref_len;
+                }
+                tpos += op->ref_len;
+                qpos += op->alt_len;
+            }
+            if (rc) break;
+            /* read filters: normcounts.py:302-309 */
+            int64_t bqs = 0;
+            for (int32_t q = 0; q < R->qlen[r]; q++) bqs += R->bq[R->qoff[r] + q];
+            double qv = (double)bqs / (double)R->qlen[r];
+            if (qv < (double)P->min_qv) continue;
+            if (R->mapq[r] < P->min_mapq) continue;
+            double ident = (double)match_count / (double)(match_count + mismatch_count);
+            if (ident < P->min_sequence_identity) continue;
+            if (!(P->qlen_lower < R->qlen[r] && R->qlen[r] < P->qlen_upper)) continue;
+            if (!seen[R->qid[r]]) { m[0]++; seen[R->qid[r]] = 1; } /* normcounts.py:310-312 */
+            /* update_tri2count: normcounts.py:66-110 */
+            int32_t nmis = 0;
+            int32_t* mis = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ol->nops + 1));
+            tpos = R->tstart[r];
+            for (int32_t k = 0; k < ol->nops; k++) {
+                const orc_op* op = &ol->ops[k];
+                if ((op->state == 2 && op->ref != 'N') || op->state == 3 || op->state == 4) mis[nmis++] = (int32_t)(tpos + 1);
+                tpos += op->ref_len;
+            }
+            const int32_t qlen = R->qlen[r];
+            const double trimmed_qstart = floor(P->min_trim * (double)qlen);
+            const double trimmed_qend = ceil((1.0 - P->min_trim) * (double)qlen);
+            int64_t rpos = R->tstart[r];
+            qpos = R->qstart[r];
+            for (int32_t k = 0; k < ol->nops; k++) {
+                const orc_op* op = &ol->ops[k];
+                if (op->state == 1) {
+                    /* get_mismatch_range(rpos, qpos, ...): 0-based rpos against the 1-based list, evaluated once
+                     * per run and shifted by j (normcounts.py:84-90) */
+                    int64_t w = P->mismatch_window;
+                    int64_t qs = qpos - w, qe = qpos + w, ur, dr;
+                    if (qs < 0) { ur = w + qs; dr = w + (-qs); }
+                    else if (qe > qlen) { ur = w + llabs(qe - qlen); dr = qlen - qpos; }
+                    else { ur = w; dr = w; }
+                    const int64_t ms = rpos - ur, me = rpos + dr;
+                    for (int32_t j = 0; j < op->ref_len; j++) {
+                        int64_t cnt = bisect_right32(mis, nmis, (int32_t)(me + j)) - bisect_left32(mis, nmis, (int32_t)(ms + j));
+                        if ((int)R->bq[R->qoff[r] + qpos + j] < P->min_bq) continue;
+                        if (cnt > P->max_mismatch_count) continue;
+                        if ((double)(qpos + j) < trimmed_qstart || (double)(qpos + j) > trimmed_qend) continue;
+                        callable[rpos + j - pmin]++;
+                    }
+                } else if (op->state == 2) {
+                    callable[rpos - pmin]++; /* the three filters are evaluated and ignored (normcounts.py:97-109) */
+                }
+                rpos += op->ref_len;
+                qpos += op->alt_len;
+            }
+            free(mis);
+        }
+
+        /* positions of the chunk: normcounts.py:315-402 */
+        for (int64_t rp = s; rp < e && !rc; rp++) {
+            if (rp < 0 || rp >= reflen) { rc = ORC_ERR_ARG; break; } /* IndexError in the reference */
+            const int ref = refseq[rp];
+            const int64_t w = rp - pmin;
+            const uint32_t tri_sum = (w >= 0 && w < W) ? callable[w] : 0;
+            const int ridx = base2idx(ref);
+            if (ridx < 0) continue;
+            if (tri_sum == 0) continue;
+            m[1] += tri_sum;
+            const uint32_t* cz = &counts[w * 6];
+            const pile_entry* col = &ent[loff[w]];
+            const int32_t depth_l = (int32_t)(loff[w + 1] - loff[w]);
+            const uint32_t ins_count = cz[4], del_count = cz[5];
+            const uint32_t read_depth = cz[0] + cz[1] + cz[2] + cz[3] + cz[5];
+            double pl[10];
+            int st[10], order[10];
+            rc = column_pls(col, depth_l, ref, L, pl, st);
+            if (rc) break;
+            argsort10(pl, order);
+            double gqf = pl[order[1]] - pl[order[0]];
+            int gq = gqf < 99.0 ? (int)gqf : 99;
+            const int state = st[order[0]];
+            if (state == GS_HET) { m[3] += tri_sum; continue; }
+            if (state == GS_HETALT) { m[4] += tri_sum; continue; }
+            if (state == GS_HOMALT) { m[5] += tri_sum; continue; }
+            m[6] += tri_sum;
+            if (del_count != 0 || ins_count != 0) { m[7] += tri_sum; continue; }
+            if ((int64_t)read_depth > P->md_threshold) { m[8] += tri_sum; continue; }
+            const uint32_t ref_count = cz[ridx];
+            const int64_t tri = tri_index(refseq, reflen, rp, cls, K, 0);
+            if (read_depth == ref_count) {
+                if (gq < P->min_gq) { m[10] += tri_sum; continue; }
+                if ((int64_t)ref_count < P->min_ref_count) { m[9] += tri_sum; continue; }
+            } else {
+                int alt_state = 0;
+                uint32_t alt_counts[3];
+                int n_seen = 0;
+                for (int a = 0; a < 3; a++) { /* normcounts.py:369-385 */
+                    const int aidx = alt_order[ridx * 3 + a];
+                    const uint32_t alt_count = cz[aidx];
+                    alt_counts[n_seen++] = alt_count;
+                    if (alt_count == 0) continue;
+                    const uint64_t key = ((uint64_t)(uint32_t)(rp + 1) << 4) | ((uint64_t)ridx << 2) | (uint64_t)aidx;
+                    if (!non_human_sample && key_in(pon, npon, key)) { alt_state = 1; m[11] += tri_sum; break; }
+                    if (!non_human_sample && key_in(com, ncom, key)) { alt_state = 1; m[12] += tri_sum; break; }
+                }
+                if (alt_state) continue;
+                int best = 0; /* list.index(max(...)): first maximum */
+                for (int a = 1; a < 3; a++) if (alt_counts[a] > alt_counts[best]) best = a;
+                const int aidx = alt_order[ridx * 3 + best];
+                double pl2[10];
+                rc = column_pls_without(col, depth_l, aidx, st, L, pl2);
+                if (rc) break;
+                int order2[10];
+                argsort10(pl2, order2);
+                double g2 = pl2[order2[1]] - pl2[order2[0]];
+                int gq2 = g2 < 99.0 ? (int)g2 : 99;
+                if (gq2 < P->min_gq) { m[10] += tri_sum; continue; }
+                const uint32_t alt_count = cz[aidx];
+                if (!((int64_t)ref_count >= P->min_ref_count && (int64_t)alt_count >= P->min_alt_count)) { m[9] += tri_sum; continue; }
+            }
+            ref_tri[tri] += 1;
+            ccs_tri[tri] += tri_sum;
+            m[13] += tri_sum;
+        }
+        free(fill); free(ent); free(loff); free(counts); free(callable); free(fetch);
+    }
+done:
+    /* chrom2norm_log order (normcounts.py:404-419): ccs, bases, unphased, het, hetalt, homalt, homref, uncallable,
+     * md, ab, low_gq, pon, pop, callable */
+    for (int k = 0; k < 14; k++) log[k] = m[k];
+    for (int64_t r = 0; r < n; r++) free(OL[r].ops);
+    free(OL); free(seen);
     return rc;
 }
 

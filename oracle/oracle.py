@@ -235,3 +235,76 @@ def germ_gt(ref, alleles, bqs, germline_snv_prior=1 / (10 ** 3)):
     if gq < 0:
         raise OracleError(-gq)
     return chr(g0.value) + chr(g1.value), gq, ["homref", "het", "hetalt", "homalt"][st.value], list(pl)
+
+
+TRI_LST = [f + m + l for f in "ACGT" for m in "CT" for l in "ACGT"]   # mutlib.py:17-50
+
+
+def tri_classes(refseq):
+    """Byte -> class id table for a reference string: one class per distinct byte (plus A C G T N).
+    Returns (chars, cls[256])."""
+    raw = refseq.encode("ascii") if isinstance(refseq, str) else bytes(refseq)
+    present = np.flatnonzero(np.bincount(np.frombuffer(raw, np.uint8), minlength=256))
+    chars = sorted(set(int(x) for x in present) | set(b"ACGTN"))
+    cls = np.zeros(256, np.uint8)
+    for i, ch in enumerate(chars):
+        cls[ch] = i
+    return chars, cls
+
+
+def tri_dicts(chars, ccs, ref):
+    """Histograms over class triples -> the two dicts of the reference (keys of tri_lst always present)."""
+    K = len(chars)
+    d_ccs = {t: 0 for t in TRI_LST}
+    d_ref = {t: 0 for t in TRI_LST}
+    for idx in np.flatnonzero((ccs != 0) | (ref != 0)):
+        a, b, c = int(idx) // (K * K), (int(idx) // K) % K, int(idx) % K
+        key = chr(chars[a]) + chr(chars[b]) + chr(chars[c])
+        d_ccs[key] = d_ccs.get(key, 0) + int(ccs[idx])
+        d_ref[key] = d_ref.get(key, 0) + int(ref[idx])
+    return d_ccs, d_ref
+
+
+def alt_order_table(order=None):
+    """alt_order[ref allele][0..2] = alleles of list(base_set.difference(ref)) (normcounts.py:367); the
+    order of a python set of strings depends on the interpreter's hash seed, so the caller supplies it."""
+    tab = np.zeros((4, 3), np.uint8)
+    for ref, ri in BASE2IDX.items():
+        lst = order[ref] if order is not None else list(set("ATGC").difference(ref))
+        tab[ri] = [BASE2IDX[a] for a in lst]
+    return tab
+
+
+def normcounts(batch, chunks, params, refseq, germline_snv_prior=1 / (10 ** 3), pon_keys=None, com_keys=None,
+               alt_order=None, non_human_sample=False):
+    """Restated non-phased normcounts.get_callable_tricounts.  Returns (ccs_tri2count, ref_tri2count, log[14])."""
+    L = lib()
+    L.orc_normcounts.restype = ctypes.c_int
+    hom, het, err, logp = build_lut(germline_snv_prior)
+    lut = _Lut(_ptr(hom), _ptr(het), _ptr(err), _ptr(logp))
+    P = _Params(min_qv=params["min_qv"], min_mapq=params["min_mapq"], qlen_lower=params["qlen_lower_limit"],
+                qlen_upper=params["qlen_upper_limit"], min_gq=params["min_gq"], min_bq=params["min_bq"],
+                max_mismatch_count=params["max_mismatch_count"], mismatch_window=params["mismatch_window_size"],
+                md_threshold=params["md_threshold"], min_ref_count=params["min_ref_count"],
+                min_alt_count=params["min_alt_count"], min_hap_count=params["min_hap_count"], phase=0, pad=0,
+                min_sequence_identity=params["min_sequence_identity"], min_trim=params["min_trim"])
+    R = _reads_struct(batch)
+    cs_ = np.array([c[0] for c in chunks], np.int32)
+    ce_ = np.array([c[1] for c in chunks], np.int32)
+    pon = np.zeros(0, np.uint64) if pon_keys is None else np.ascontiguousarray(pon_keys, np.uint64)
+    com = np.zeros(0, np.uint64) if com_keys is None else np.ascontiguousarray(com_keys, np.uint64)
+    raw = np.frombuffer(refseq.encode("ascii") if isinstance(refseq, str) else bytes(refseq), np.uint8)
+    chars, cls = tri_classes(refseq)
+    K = len(chars)
+    ccs = np.zeros(K * K * K, np.int64)
+    ref = np.zeros(K * K * K, np.int64)
+    tab = np.ascontiguousarray(alt_order_table(alt_order))
+    log = (ctypes.c_int64 * 14)()
+    rc = L.orc_normcounts(ctypes.byref(R), ctypes.byref(P), ctypes.byref(lut), ctypes.c_int64(len(chunks)), _ptr(cs_),
+                          _ptr(ce_), _ptr(pon), ctypes.c_int64(pon.shape[0]), _ptr(com), ctypes.c_int64(com.shape[0]),
+                          _ptr(raw), ctypes.c_int64(raw.shape[0]), _ptr(cls), ctypes.c_int(K), _ptr(tab),
+                          ctypes.c_int(1 if non_human_sample else 0), _ptr(ccs), _ptr(ref), log)
+    if rc:
+        raise OracleError(rc)
+    d_ccs, d_ref = tri_dicts(chars, ccs, ref)
+    return d_ccs, d_ref, [int(x) for x in log]

@@ -134,6 +134,51 @@ def worker_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, phase_bl
     return exp
 
 
+def norm_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, overrides=None, md_threshold=None,
+              qlen_limits=None, mutate_ref=None, non_human_sample=False):
+    """normcounts.get_callable_tricounts (non-phased) on a synthetic contig + its reference sequence."""
+    ref = H.load_reference()
+    s = synth.generate(cfg, want_ref=True)
+    b = s.batch
+    seq = bytes(s.ref).decode()
+    if mutate_ref is not None:
+        seq = mutate_ref(seq)
+    bam = "/fake/{}.bam".format(case)
+    H.register_bam(bam, {b.name: b})
+    sizes = {b.name: b.length}
+    ql, qu, md = thresholds_of(ref, bam, [b.name], sizes)
+    if md_threshold is not None:
+        md = md_threshold
+    if qlen_limits is not None:
+        ql, qu = qlen_limits
+    if chunks is None:
+        _, c2c = ref.util.load_loci(None, None, sizes)
+        chunks = [(s_, e_) for (_, s_, e_) in c2c[b.name]]
+    exp = {"chunks": chunks, "qlen_lower_limit": ql, "qlen_upper_limit": qu, "md_threshold": md,
+           "overrides": overrides or {}, "contig": b.name, "length": b.length, "non_human_sample": non_human_sample}
+    common = pon = None
+    if with_sets:
+        common = os.path.join(tmpdir, case + ".common.vcf")
+        pon = os.path.join(tmpdir, case + ".pon.vcf")
+        # sites where some read carries a non-reference base: candidates of the call worker seed the side files
+        recs0, _ = H.run_reference_worker(bam, b.name, chunks, ql, qu, md, **(overrides or {}))
+        hits = [(r[1], r[2], r[3]) for r in recs0 if len(r[3]) == 1]
+        synth.write_common_snps_vcf(common, s, seed=cfg.seed, extra_sites=hits[3::4])
+        synth.write_pon_vcf(pon, s, seed=cfg.seed, extra_sites=hits[::5])
+        exp["common_set"] = sorted([list(t) for t in ref.vcflib.load_common_snp(b.name, common)])
+        exp["pon_set"] = sorted([list(t) for t in ref.vcflib.load_pon(b.name, pon)])
+    ccs, rf, log, order = H.run_reference_normcounts(bam, b.name, seq, chunks, ql, qu, md, common_snps=common,
+                                                     panel_of_normals=pon, non_human_sample=non_human_sample,
+                                                     **(overrides or {}))
+    exp["ccs_tri2count"] = {k: int(v) for k, v in ccs.items()}
+    exp["ref_tri2count"] = {k: int(v) for k, v in rf.items()}
+    exp["log"] = [int(x) for x in log]
+    exp["alt_order"] = order
+    print("   ", case, exp["log"], "keys", len(ccs))
+    save(case, exp, batch=b, extra_npz={"refseq": np.frombuffer(seq.encode("ascii"), np.uint8)})
+    return exp
+
+
 def small_cfg(seed, **kw):
     d = dict(seed=seed, contig_len=30000, read_len_mean=3000, read_len_sd=500, read_len_min=1200, read_len_max=5000,
              name="chr7")
@@ -399,6 +444,28 @@ def main():
         worker_case("worker_pon_params", small_cfg(109, contig_len=20000, name="chrN", som_rate=2e-4), md_threshold=52,
                     overrides=dict(min_bq=20, min_gq=10, min_qv=20, min_trim=0, min_mapq=30, min_hap_count=0,
                                    min_sequence_identity=0.8), create_pon=True)
+    if want("norm_basic"):
+        norm_case("norm_basic", small_cfg(201, contig_len=40000, name="chrA"), md_threshold=52)
+    if want("norm_sets"):
+        norm_case("norm_sets", small_cfg(202, contig_len=40000, name="chr7", som_rate=3e-4, snp_rate=3e-3),
+                  with_sets=True, md_threshold=52, chunks=[(1, 15000), (15000, 30000), (30000, 39998)])
+    if want("norm_dense"):
+        # deep pile, noisy reads, relaxed filters: every branch of the position loop fires
+        norm_case("norm_dense", small_cfg(203, contig_len=20000, depth=70.0, name="chrD", som_rate=1e-3, snp_rate=4e-3,
+                                          sub_rate=2e-3, ins_rate=5e-4, del_rate=5e-4),
+                  with_sets=True, md_threshold=60,
+                  overrides=dict(min_bq=40, min_gq=70, max_mismatch_count=2, mismatch_window_size=15, min_ref_count=5,
+                                 min_alt_count=2, min_sequence_identity=0.95))
+    if want("norm_softmask"):
+        # lower-case (soft-masked) and N stretches in the reference: skipped positions, odd trinucleotide keys
+        def mask(seq):
+            t = list(seq)
+            for a, z in ((3000, 3400), (9000, 9100), (15000, 15002)):
+                t[a:z] = [c.lower() for c in t[a:z]]
+            for a, z in ((5000, 5050), (12000, 12001)):
+                t[a:z] = ["N"] * (z - a)
+            return "".join(t)
+        norm_case("norm_softmask", small_cfg(204, contig_len=20000, name="chrM"), md_threshold=52, mutate_ref=mask)
     if want("worker_boundary"):
         boundary_case()
 

@@ -1,5 +1,7 @@
 """The CPU oracle (oracle/himut_oracle.c) against golden vectors captured from
 the reference itself (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -54,3 +56,35 @@ def test_cs_tuples():
         for o, t in zip(ops, c["tuples"]):
             if t[0] == 2:
                 assert (o[3], o[4]) == (t[1], t[2])
+
+
+NORM_CASES = ["norm_basic", "norm_sets", "norm_dense", "norm_softmask"]
+
+
+def load_norm_case(case):
+    """(batch, expected, params, refseq bytes, pon keys, common keys) of a normcounts fixture."""
+    import numpy as np
+    from oracle import oracle as O
+    exp = util.load_json(case)
+    with np.load(os.path.join(util.GOLDEN, case + ".npz")) as z:
+        from himut_amd.readbatch import ReadBatch
+        batch = ReadBatch.from_npz_dict(z)
+        refseq = bytes(z["refseq"])
+    p = util.params_of(exp)
+    pon = O.site_keys([tuple(t) for t in exp["pon_set"]]) if "pon_set" in exp else None
+    com = O.site_keys([tuple(t) for t in exp["common_set"]]) if "common_set" in exp else None
+    return batch, exp, p, refseq, pon, com
+
+
+@pytest.mark.parametrize("case", NORM_CASES)
+def test_normcounts_oracle_matches_reference(case):
+    """normcounts.get_callable_tricounts (non-phased): both trinucleotide dicts and the 14 counters."""
+    from oracle import oracle as O
+    batch, exp, p, refseq, pon, com = load_norm_case(case)
+    ccs, rf, log = O.normcounts(batch, util.chunks_of(exp), p, refseq, p["germline_snv_prior"], pon, com,
+                                alt_order=exp["alt_order"], non_human_sample=exp["non_human_sample"])
+    assert log == exp["log"]
+    assert {k: v for k, v in ccs.items() if v or k in O.TRI_LST} == \
+        {k: v for k, v in exp["ccs_tri2count"].items() if v or k in O.TRI_LST}
+    assert {k: v for k, v in rf.items() if v or k in O.TRI_LST} == \
+        {k: v for k, v in exp["ref_tri2count"].items() if v or k in O.TRI_LST}
