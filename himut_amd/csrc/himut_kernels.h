@@ -845,22 +845,25 @@ __device__ __forceinline__ uint64_t nib16_to_cells(uint64_t x) {
 // ---------------------------------------------------------------------------------------
 // The column store.  Candidate columns live at the UNIQUE reference positions that carry
 // a candidate (several chunks / alts can share one).  All positions of a 256-position block
-// share one read window [lo, lo + n) (k_window_index), so the columns of a block are n
-// slots each and lie one after the other: the column of unique position u in block b starts
-// at boff[b] + (u - ufirst[b]) * n[b], and holds one 16-bit slot per read of the window, in
-// fetch order:
+// share one read window [lo, lo + n) (k_window_index), so a block with cnt candidate
+// positions owns n * cnt slots, read-major: the slot of (read r, unique position u) is
+// boff[b] + (r - lo) * cnt + (u - ufirst[b]).  Neighbouring positions of one read are
+// neighbours in memory, which is what lets the dense sweep read its columns coalesced.
+// One 16-bit slot per (read of the window, position), walked in fetch order:
 //   bits 0-2 cell (0-3 allele A T G C, 4 base outside ATGC, 5 deletion, 7 not in the pile)
 //   bit 3    an insertion precedes the position
+//   bit 4    (normcounts) the base counts as callable for its read (normcounts.py:66-110)
 //   bits 8-15 base quality
 // k_stream_capture fills it while streaming every read once with coalesced loads;
 // k_eval_columns consumes it, one thread per candidate.
 
 struct BlockTab {     // one per 256 reference positions
     int32_t lo;       // first read of the window
-    uint32_t n;       // reads in the window = slots per column
+    uint32_t ncnt;    // bits 0-21: reads in the window = slots per column; bits 22-31: candidate positions in the block
     uint32_t boff;    // slot offset of the block's first column
     uint32_t ufirst;  // unique-position rank of the block's first candidate position
 };
+constexpr uint32_t BT_N_MASK = (1u << 22) - 1u;
 
 struct PosIndex {
     const uint32_t* bits;    // bit rpos set: some candidate sits at rpos
@@ -901,7 +904,8 @@ __global__ void __launch_bounds__(256) k_block_table(const uint32_t* rank, int64
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
     BlockTab t;
-    t.lo = winlo[b]; t.n = (uint32_t)(winhi[b] - winlo[b]); t.boff = boff[b]; t.ufirst = rank[min(b * 8, nwords)];
+    const uint32_t u0 = rank[min(b * 8, nwords)], u1 = rank[min(b * 8 + 8, nwords)];
+    t.lo = winlo[b]; t.ncnt = (uint32_t)(winhi[b] - winlo[b]) | ((u1 - u0) << 22); t.boff = boff[b]; t.ufirst = u0;
     bt[b] = t;
 }
 
@@ -1135,8 +1139,8 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
                             uint4 t;
                             if (bi >= 0 && bi < 16) t = *reinterpret_cast<const uint4*>(lbt + 4 * bi);
                             else { t = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)(rpos >> 8), X.nblk - 1)); CAP_LANDED4(t); }
-                            // BlockTab: x = lo, y = n, z = boff, w = ufirst
-                            const int64_t slot = (int64_t)t.z + (int64_t)(u - t.w) * (int64_t)t.y + (int64_t)(r - (int32_t)t.x);
+                            // BlockTab: x = lo, y = n | cnt << 22, z = boff, w = ufirst
+                            const int64_t slot = (int64_t)t.z + (int64_t)(r - (int32_t)t.x) * (int64_t)(t.y >> 22) + (int64_t)(u - t.w);
                             if ((uint64_t)slot < (uint64_t)A.nslots) A.colstore[slot] = (uint16_t)val;
                         }
                     }
@@ -1228,9 +1232,9 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
     const int32_t rpos = tpos - 1;
     const uint32_t u = pos_rank(A.X, rpos);
     const BlockTab bt = A.X.bt[rpos >> 8];
-    const uint32_t n = bt.n;
+    const uint32_t n = bt.ncnt & BT_N_MASK, stride = bt.ncnt >> 22;
     const int32_t lo = bt.lo;
-    const uint16_t* col = A.colstore + ((int64_t)bt.boff + (int64_t)(u - bt.ufirst) * (int64_t)n);
+    const uint16_t* col = A.colstore + ((int64_t)bt.boff + (int64_t)(u - bt.ufirst));
     const int min_bq = A.P.p.min_bq;
     const int32_t cs_ = A.C.start[chunk];
     // Only next to the chunk start can a read lie in the pile of the position without having
@@ -1245,7 +1249,7 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
     uint32_t ref_count = 0, alt_count = 0, alt_hi = 0, h0_ref = 0, h1_ref = 0, som0 = 0, som1 = 0;
     int bad = 0;
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t v = col[i];
+        const uint32_t v = col[(int64_t)i * stride];
         const uint32_t cell = v & 7u;
         if ((v & 15u) == CELL_EMPTY) continue;
         int32_t tend = 0;
