@@ -46,7 +46,8 @@ class RunStats(ctypes.Structure):
 EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_error", "himut_set_params",
            "himut_set_gt_lut", "himut_set_chunks", "himut_set_site_set", "himut_set_phase", "himut_push_reads",
            "himut_run", "himut_get_records", "himut_get_log", "himut_get_stats", "himut_records_device",
-           "himut_copy_records_to_device", "himut_pile_counts"]
+           "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
+           "himut_get_normcounts"]
 
 _lib = None
 
@@ -102,6 +103,9 @@ def lib():
     L.himut_records_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]
     L.himut_copy_records_to_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
     L.himut_pile_counts.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.himut_set_reference.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+    L.himut_run_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.himut_get_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     for name in EXPORTS:
         if name not in ("himut_destroy", "himut_last_error"):
             getattr(L, name).restype = ctypes.c_int
@@ -216,6 +220,24 @@ class Context:
 
     def copy_records_to_device(self, dev_ptr, capacity_records):
         self._check(self._L.himut_copy_records_to_device(self._h, ctypes.c_void_p(dev_ptr), int(capacity_records)))
+
+    def set_reference(self, seq, cls, n_classes):
+        raw = np.frombuffer(seq.encode("ascii") if isinstance(seq, str) else bytes(seq), np.uint8)
+        cls = np.ascontiguousarray(cls, np.uint8)
+        self._n_classes = int(n_classes)
+        self._check(self._L.himut_set_reference(self._h, _ptr(raw), int(raw.shape[0]), _ptr(cls), int(n_classes)))
+
+    def run_normcounts(self, alt_order, non_human_sample=False):
+        tab = np.ascontiguousarray(alt_order, np.uint8).reshape(12)
+        self._check(self._L.himut_run_normcounts(self._h, _ptr(tab), 1 if non_human_sample else 0))
+
+    def normcounts(self):
+        k3 = self._n_classes ** 3
+        ccs = np.zeros(k3, np.int64)
+        ref = np.zeros(k3, np.int64)
+        log = np.zeros(14, np.int64)
+        self._check(self._L.himut_get_normcounts(self._h, _ptr(ccs), _ptr(ref), _ptr(log)))
+        return ccs, ref, [int(x) for x in log]
 
     def pile_counts(self, p0, p1):
         counts = np.zeros((p1 - p0, 6), np.uint32)

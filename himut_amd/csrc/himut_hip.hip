@@ -17,6 +17,7 @@
 
 #include "himut_hip.h"
 #include "himut_kernels.h"
+#include "himut_norm.h"
 
 using namespace himut;
 
@@ -98,6 +99,13 @@ struct himut_ctx {
     // run state
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2;
+    // normcounts
+    DevBuf d_refseq, d_live, d_callable, d_tri;
+    int64_t reflen = 0;
+    uint8_t ref_cls[256] = {};
+    int ref_K = 0;
+    std::vector<unsigned long long> h_tri;   // ccs[K^3], ref[K^3], log[16]
+    bool have_norm = false;
     DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_blkslots, d_blkoff, d_blktab, d_colstore, d_posbits_c, d_posrank, d_poppc, d_tmp2;
     std::vector<himut_record> h_recs;
     bool h_recs_valid = false;
@@ -460,7 +468,8 @@ int do_run(himut_ctx* c) {
                                        (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
         // per 256-position block: slots = candidate positions x reads of the window, then their offsets
         hipLaunchKernelGGL(k_block_slots, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
-                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, c->d_blkslots.as<uint32_t>());
+                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, c->d_blkslots.as<uint32_t>(),
+                           (unsigned long long*)nullptr);
         HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
                                        (size_t)nblk, rocprim::plus<uint32_t>(), st));
         hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
@@ -479,8 +488,9 @@ int do_run(himut_ctx* c) {
         X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
         CaptureArgs G;
         G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)nslots;
+        G.r_begin = 0; G.r_end = c->n; G.callable = nullptr;
         HCHECK(hipEventRecord(c->ev[EV_INDEX], st));
-        hipLaunchKernelGGL(k_stream_capture, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
+        hipLaunchKernelGGL(k_stream_capture<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
         HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
         EvalArgs A;
         A.P = c->params;
@@ -773,6 +783,191 @@ int himut_copy_records_to_device(himut_ctx* c, void* dst, int64_t capacity_recor
         HCHECK(hipStreamSynchronize(c->stream));
         return HIMUT_OK;
     });
+}
+
+namespace {
+
+int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
+    if (!c->have_params) return fail(c, HIMUT_ERR_ARG, "himut_set_params has not been called");
+    if (!c->have_lut) return fail(c, HIMUT_ERR_ARG, "himut_set_gt_lut has not been called");
+    if (!c->have_reads) return fail(c, HIMUT_ERR_ARG, "himut_push_reads has not been called");
+    if (c->reflen <= 0) return fail(c, HIMUT_ERR_ARG, "himut_set_reference has not been called");
+    if (c->params.p.phase) return fail(c, HIMUT_ERR_ARG, "phased normcounts is not implemented");
+    for (size_t k = 0; k < c->cstart.size(); k++)
+        if (c->cstart[k] > c->cend[k]) return fail(c, HIMUT_ERR_CHUNK, "ValueError: invalid coordinates: chunk start > end");
+    for (int k = 0; k < 12; k++) if (alt_order[k] > 3) return fail(c, HIMUT_ERR_ARG, "alt_order holds alleles 0..3");
+    HCHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->have_norm = false;
+    memset(&c->stats, 0, sizeof(c->stats));
+    c->params.unique_qnames = c->unique_qnames ? 1 : 0;
+
+    ChunkTables T = upload_chunks(c, c->cstart, c->cend);
+    alloc_derived(c);
+    Reads R = make_reads(c);
+    Derived D = make_derived(c);
+    Chunks C = make_chunks(c, T.n);
+    Scalars* sc = c->d_scalars.as<Scalars>();
+    const int K = c->ref_K;
+    const size_t ntri = (size_t)K * K * K;
+    c->d_tri.reserve((2 * ntri + 16) * 8);
+    c->d_live.reserve((size_t)c->n + 64);
+    const size_t cwords = (size_t)(c->bq_bytes >> 5) + 64;
+    c->d_callable.reserve(cwords * 4);
+
+    HCHECK(hipEventRecord(c->ev[EV_START], st));
+    HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+    HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
+    HCHECK(hipMemsetAsync(c->d_tri.p, 0, (2 * ntri + 16) * 8, st));
+    HCHECK(hipMemsetAsync(c->d_callable.p, 0, cwords * 4, st));
+    if (c->n > 0) run_parse_stage(c, R, D, sc);
+    else HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+    int32_t maxend = 0;
+    for (int32_t e : c->cend) maxend = std::max(maxend, e);
+    const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
+    c->d_winlo.reserve((size_t)nblk * 4 + 64);
+    c->d_winhi.reserve((size_t)nblk * 4 + 64);
+    if (c->n > 0 && T.n > 0) {
+        hipLaunchKernelGGL(k_read_live, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, C, c->params,
+                           c->d_live.as<uint8_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
+        hipLaunchKernelGGL(k_callable, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, c->d_live.as<uint8_t>(),
+                           c->d_callable.as<uint32_t>());
+        hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, R, nblk, c->d_winlo.as<int32_t>(),
+                           c->d_winhi.as<int32_t>());
+    }
+    HCHECK(hipEventRecord(c->ev[EV_EMIT], st));
+
+    int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
+    maxpos = std::max(maxpos, maxend);
+    const int64_t nwords = ((int64_t)maxpos >> 5) + 2;
+    c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
+    c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
+    c->d_poppc.reserve((size_t)(nwords + 2) * 4 + 256);
+    c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
+    c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
+    size_t scan2 = 0, scan3 = 0;
+    HCHECK(rocprim::exclusive_scan(nullptr, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
+                                   (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
+    HCHECK(rocprim::exclusive_scan(nullptr, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
+                                   (size_t)nblk, rocprim::plus<uint32_t>(), st));
+    c->d_tmp2.reserve(std::max(scan2, scan3) + 256);
+
+    NormArgs A;
+    A.P = c->params;
+    A.S.pon = c->d_pon.as<uint64_t>(); A.S.npon = c->npon; A.S.com = c->d_com.as<uint64_t>(); A.S.ncom = c->ncom;
+    A.S.posbits = c->d_posbits.as<uint32_t>(); A.S.nposbits = c->nposbits;
+    A.lut = c->d_lut.as<GtLut>();
+    A.R = R; A.C = C;
+    A.refseq = c->d_refseq.as<uint8_t>(); A.reflen = c->reflen;
+    memcpy(A.cls, c->ref_cls, 256);
+    A.K = K; A.cA = c->ref_cls['A']; A.cC = c->ref_cls['C']; A.cG = c->ref_cls['G']; A.cT = c->ref_cls['T'];
+    memcpy(A.alt_order, alt_order, 12);
+    A.non_human = non_human;
+    A.ccs_tri = c->d_tri.as<unsigned long long>(); A.ref_tri = A.ccs_tri + ntri; A.log = A.ccs_tri + 2 * ntri;
+    A.err = &sc->err;
+    int32_t maxspan = 1;
+    for (size_t k = 0; k < c->cstart.size(); k++) maxspan = std::max(maxspan, c->cend[k] - c->cstart[k]);
+    const unsigned ex = blocks_for(maxspan, 256 * NE_TILES);
+
+    int64_t slots_total = 0;
+    if (c->n > 0 && T.n > 0) {
+        for (int64_t p_lo = 0; p_lo < (int64_t)maxend; p_lo += NORM_PASS) {
+            const int64_t p_hi = std::min<int64_t>(p_lo + NORM_PASS, maxend);
+            bool any = false;
+            for (size_t k = 0; k < c->cstart.size() && !any; k++) any = c->cstart[k] < p_hi && c->cend[k] > p_lo;
+            if (!any) continue;
+            // ones at the chunk positions of the pass, rank, per-block windows and slot offsets
+            HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
+            hipLaunchKernelGGL(k_fill_bits, dim3(blocks_for((p_hi - p_lo + 31) / 32 + 1, 256)), dim3(256), 0, st, C, p_lo, p_hi,
+                               c->d_posbits_c.as<uint32_t>(), nwords);
+            hipLaunchKernelGGL(k_word_popc, dim3(blocks_for(nwords + 1, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
+                               nwords + 1, c->d_poppc.as<uint32_t>());
+            HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
+                                           (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
+            HCHECK(hipMemsetAsync(&sc->reserved0, 0, 8, st));
+            hipLaunchKernelGGL(k_block_slots, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
+                               c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, c->d_blkslots.as<uint32_t>(),
+                               &sc->reserved0);
+            HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
+                                           (size_t)nblk, rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
+                               c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_blkoff.as<uint32_t>(), nblk,
+                               c->d_blktab.as<BlockTab>());
+            uint32_t last_off = 0, last_n = 0;
+            unsigned long long hs_total = 0;
+            HCHECK(hipMemcpyAsync(&last_off, c->d_blkoff.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
+            HCHECK(hipMemcpyAsync(&last_n, c->d_blkslots.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
+            HCHECK(hipMemcpyAsync(&hs_total, &sc->reserved0, 8, hipMemcpyDeviceToHost, st));
+            HCHECK(hipStreamSynchronize(st));
+            const size_t nslots = (size_t)last_off + last_n;
+            const int64_t rb = std::upper_bound(c->h_prefmax.begin(), c->h_prefmax.end(), (int32_t)p_lo) - c->h_prefmax.begin();
+            const int64_t re = std::lower_bound(c->h_tstart.begin(), c->h_tstart.end(), (int32_t)p_hi) - c->h_tstart.begin();
+            if (hs_total != (unsigned long long)nslots)
+                return fail(c, HIMUT_ERR_ARG, "normcounts: pile too deep for one pass (more than 2^32 column slots)");
+            slots_total += (int64_t)nslots;
+            c->d_colstore.reserve(nslots * 2 + 256);
+            if (nslots) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, nslots, st));
+            PosIndex X;
+            X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
+            X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
+            CaptureArgs G;
+            G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)nslots;
+            G.r_begin = rb; G.r_end = std::max(rb, re); G.callable = c->d_callable.as<uint32_t>();
+            if (re > rb)
+                hipLaunchKernelGGL(k_stream_capture<true>, dim3(blocks_for(re - rb, 4)), dim3(256), 0, st, G);
+            A.X = X; A.colstore = c->d_colstore.as<uint16_t>(); A.p_lo = p_lo; A.p_hi = p_hi;
+            hipLaunchKernelGGL(k_norm_eval, dim3(ex, (unsigned)T.n), dim3(256), 0, st, A);
+        }
+        hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
+    }
+    HCHECK(hipEventRecord(c->ev[EV_FINAL], st));
+    c->h_tri.assign(2 * ntri + 16, 0ULL);
+    Scalars hs;
+    HCHECK(hipMemcpyAsync(c->h_tri.data(), c->d_tri.p, (2 * ntri + 16) * 8, hipMemcpyDeviceToHost, st));
+    HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+    HCHECK(hipStreamSynchronize(st));
+    if (hs.err) return check_device_err(c, hs.err);
+    c->h_tri[2 * ntri + 0] = hs.nccs;
+    float f = 0;
+    (void)hipEventElapsedTime(&f, c->ev[EV_START], c->ev[EV_FINAL]);
+    c->stats.ms_total = (double)f;
+    (void)hipEventElapsedTime(&f, c->ev[EV_START], c->ev[EV_PARSE]);
+    c->stats.ms_parse = (double)f;
+    c->stats.n_reads = c->n; c->stats.read_bases = c->read_bases; c->stats.positions = T.positions;
+    c->stats.column_slots = slots_total;
+    c->have_norm = true;
+    return HIMUT_OK;
+}
+
+}  // namespace
+
+int himut_set_reference(himut_ctx* c, const uint8_t* seq, int64_t len, const uint8_t* cls, int n_classes) {
+    if (!c) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int {
+        if (!seq || len <= 0 || !cls || n_classes < 5 || n_classes > 32) return fail(c, HIMUT_ERR_ARG, "bad reference / class table");
+        HCHECK(hipSetDevice(c->device));
+        upload(c->d_refseq, seq, (size_t)len, c->stream);
+        HCHECK(hipStreamSynchronize(c->stream));
+        c->reflen = len;
+        memcpy(c->ref_cls, cls, 256);
+        c->ref_K = n_classes;
+        for (int k = 0; k < 256; k++) if (cls[k] >= n_classes) return fail(c, HIMUT_ERR_ARG, "class id out of range");
+        return HIMUT_OK;
+    });
+}
+
+int himut_run_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human_sample) {
+    if (!c || !alt_order) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int { return do_normcounts(c, alt_order, non_human_sample); });
+}
+
+int himut_get_normcounts(himut_ctx* c, int64_t* ccs_tri, int64_t* ref_tri, int64_t log[14]) {
+    if (!c) return HIMUT_ERR_ARG;
+    if (!c->have_norm) return fail(c, HIMUT_ERR_ARG, "himut_run_normcounts has not completed");
+    const size_t ntri = (size_t)c->ref_K * c->ref_K * c->ref_K;
+    for (size_t k = 0; k < ntri; k++) { ccs_tri[k] = (int64_t)c->h_tri[k]; ref_tri[k] = (int64_t)c->h_tri[ntri + k]; }
+    for (int k = 0; k < 14; k++) log[k] = (int64_t)c->h_tri[2 * ntri + k];
+    return HIMUT_OK;
 }
 
 int himut_pile_counts(himut_ctx* c, int32_t p0, int32_t p1, uint32_t* counts, uint32_t* bqsum) {

@@ -892,11 +892,20 @@ __global__ void __launch_bounds__(256) k_word_popc(const uint32_t* bits, int64_t
 
 // slots per 256-position block = candidate positions in it x reads in its window
 __global__ void __launch_bounds__(256) k_block_slots(const uint32_t* rank, int64_t nwords, const int32_t* winlo,
-                                                     const int32_t* winhi, int64_t nblk, uint32_t* out) {
+                                                     const int32_t* winhi, int64_t nblk, uint32_t* out,
+                                                     unsigned long long* total) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblk) return;
-    const int64_t w0 = min(b * 8, nwords), w1 = min(b * 8 + 8, nwords);
-    out[b] = (rank[w1] - rank[w0]) * (uint32_t)(winhi[b] - winlo[b]);
+    unsigned long long s = 0;
+    if (b < nblk) {
+        const int64_t w0 = min(b * 8, nwords), w1 = min(b * 8 + 8, nwords);
+        s = (unsigned long long)(rank[w1] - rank[w0]) * (unsigned long long)(uint32_t)(winhi[b] - winlo[b]);
+        out[b] = (uint32_t)s;
+    }
+    if (total) {     // the sum in 64 bits: tells the host when the 32-bit offsets have wrapped
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_block_table(const uint32_t* rank, int64_t nwords, const int32_t* winlo,
@@ -915,6 +924,8 @@ struct CaptureArgs {
     PosIndex X;
     uint16_t* colstore;
     int64_t nslots;
+    int64_t r_begin, r_end;      // reads of this launch
+    const uint32_t* callable;    // normcounts: one bit per query base (bit q of read r at word (qoff[r] + q) >> 5)
 };
 
 constexpr int CLQ = 128;    // candidate list entries per wave (circular, power of two)
@@ -939,17 +950,19 @@ constexpr int CPD = 2;      // windows in flight (register sets, at most 4); the
 //     handles the list one candidate per lane: segment by binary search in LDS, query
 //     offset, base and quality out of the window in LDS, slot from the block table.
 // Every byte of the read is fetched exactly once; stores return nothing.
+template <bool NORM>
 __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     __shared__ __align__(16) uint8_t s_bq[4][CWQ];
     __shared__ __align__(16) uint8_t s_sq[4][CWQ / 2];
     __shared__ __align__(16) int4 s_seg[4][CSG + 1];
     __shared__ __align__(16) uint32_t s_bt[4][64];        // 16 block-table entries
+    __shared__ uint32_t s_cb[4][NORM ? 64 : 1];            // normcounts: the window's callable bits
     __shared__ uint2 s_list[4][CLQ];
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const Reads& R = A.R;
     const PosIndex& X = A.X;
-    const int64_t r64 = (int64_t)blockIdx.x * 4 + wv;
-    if (r64 >= R.n) return;
+    const int64_t r64 = A.r_begin + (int64_t)blockIdx.x * 4 + wv;
+    if (r64 >= A.r_end) return;
     const int32_t r = (int32_t)r64;
     const ReadMeta Mv = A.D.meta[r];
     const int32_t qstart = uni(R.qstart[r]), qlen = uni(R.qlen[r]);
@@ -974,7 +987,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
 #define CAP_LANDED4(V) asm volatile("" : "+v"(V.x), "+v"(V.y), "+v"(V.z), "+v"(V.w))
 #define CAP_LANDED2(V) asm volatile("" : "+v"(V.x), "+v"(V.y))
     // the five loads of one window (addresses clamped into the read, so every lane always loads)
-#define CAP_ISSUE(BA, BB, SQ, S1, BT, K, TA) do { \
+#define CAP_ISSUE(BA, BB, SQ, S1, BT, CB, K, TA) do { \
         const int32_t _c = c0 + min((K), nwin - 1) * CWQ; \
         const int32_t _qa = min(_c + lane * 16, qpad - 16), _qb = min(_c + 1024 + lane * 16, qpad - 16), _qs = min(_c + lane * 32, qpad - 32); \
         BA = *reinterpret_cast<const uint4*>(R.bq + qo + _qa); \
@@ -983,6 +996,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
         const int64_t _w = min(((int64_t)(TA) + CPL * lane) >> 5, X.nwords - 1); \
         __builtin_memcpy(&S1, X.bits + _w, 8);                 /* nwords + 2 words are allocated */ \
         BT = reinterpret_cast<const uint32_t*>(X.bt + min((int64_t)((TA) >> 8) + (lane >> 2), X.nblk - 1))[lane & 3]; \
+        if (NORM) CB = A.callable[((qo + min(_c, qpad - 32)) >> 5) + min(lane, ((qpad - 1 - min(_c, qpad - 32)) >> 5))]; \
     } while (0)
 #define CAP_SEGWIN() do { if (lane <= nw) { int4 z = make_int4(0x7fffffff, 0, 0, 0); if (jb + lane < ns) z = *reinterpret_cast<const int4*>(gsegs + jb + lane); \
         lseg[lane] = z; } } while (0)
@@ -993,7 +1007,8 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     uint4 ba0, bb0, sq0, ba1, bb1, sq1, ba2, bb2, sq2, ba3, bb3, sq3;
     uint2 s10, s11, s12, s13;
     uint32_t bt0r, bt1r, bt2r, bt3r;
-    CAP_ISSUE(ba0, bb0, sq0, s10, bt0r, 0, tstart);
+    uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
+    CAP_ISSUE(ba0, bb0, sq0, s10, bt0r, cb0, 0, tstart);
     const uint32_t rk0 = uni(X.rank[min((int64_t)(tstart >> 5), X.nwords)]);
     __builtin_amdgcn_wave_barrier();
 
@@ -1025,10 +1040,10 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     int32_t ta[5];
     ta[0] = tstart;
     ta[1] = window_end(0);
-    CAP_ISSUE(ba1, bb1, sq1, s11, bt1r, 1, ta[1]);
+    CAP_ISSUE(ba1, bb1, sq1, s11, bt1r, cb1, 1, ta[1]);
     ta[2] = window_end(1);
-    if constexpr (CPD > 2) { CAP_ISSUE(ba2, bb2, sq2, s12, bt2r, 2, ta[2]); ta[3] = window_end(2); }
-    if constexpr (CPD > 3) { CAP_ISSUE(ba3, bb3, sq3, s13, bt3r, 3, ta[3]); ta[4] = window_end(3); }
+    if constexpr (CPD > 2) { CAP_ISSUE(ba2, bb2, sq2, s12, bt2r, cb2, 2, ta[2]); ta[3] = window_end(2); }
+    if constexpr (CPD > 3) { CAP_ISSUE(ba3, bb3, sq3, s13, bt3r, cb3, 3, ta[3]); ta[4] = window_end(3); }
     // rank of the first candidate position at or behind tstart
     uint32_t ubase = 0;
     {
@@ -1039,7 +1054,8 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     int head = 0, n = 0;   // the list: entries head .. head + n - 1 (mod CLQ)
     int jcur = 0;          // segment cursor of the candidate walk
 
-    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint2& s1, uint32_t& btv, const int k) {
+    uint32_t* wcb = s_cb[wv];
+    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint2& s1, uint32_t& btv, uint32_t& cbv, const int k) {
         const int32_t tA = ta[0], tB = ta[1];
         const int32_t cq = c0 + k * CWQ;
         // ---- this window's bytes and tables -> LDS; its registers take window k + 2
@@ -1047,11 +1063,12 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
         *reinterpret_cast<uint4*>(wbq + 1024 + lane * 16) = bb;
         *reinterpret_cast<uint4*>(wsq + lane * 16) = sq;
         lbt[lane] = btv;                                   // lane = entry * 4 + field
+        if (NORM) wcb[lane] = cbv;
         // the window's bitmap words move to registers of their own: the ones they arrived in are reloaded next
         uint32_t mylo, myhi;
         asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mylo), "=&v"(myhi) : "v"(s1.x), "v"(s1.y));
         const unsigned long long mybits = ((unsigned long long)myhi << 32) | mylo;
-        CAP_ISSUE(ba, bb, sq, s1, btv, k + CPD, ta[CPD]);
+        CAP_ISSUE(ba, bb, sq, s1, btv, cbv, k + CPD, ta[CPD]);
         const int32_t ta_next = window_end(k + CPD);
         __builtin_amdgcn_wave_barrier();
         const int64_t btb = tA >> 8;
@@ -1133,6 +1150,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
                             const uint32_t qv = wbq[o], sb = wsq[o >> 1];
                             const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
                             val = insb | (uint32_t)nib2allele(nib) | (qv << 8);
+                            if (NORM) val |= ((wcb[o >> 5] >> (o & 31)) & 1u) << 4;
                         }
                         if (store) {
                             const int64_t bi = (int64_t)(rpos >> 8) - btb;
@@ -1159,10 +1177,10 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     // CPD windows per trip, each with its own registers; the last ones of a trip may lie behind the
     // read (empty range): it still issues its loads, so the number in flight never depends on the path
     for (int k = 0; k < nwin; k += CPD) {
-        window(ba0, bb0, sq0, s10, bt0r, k);
-        window(ba1, bb1, sq1, s11, bt1r, k + 1);
-        if constexpr (CPD > 2) window(ba2, bb2, sq2, s12, bt2r, k + 2);
-        if constexpr (CPD > 3) window(ba3, bb3, sq3, s13, bt3r, k + 3);
+        window(ba0, bb0, sq0, s10, bt0r, cb0, k);
+        window(ba1, bb1, sq1, s11, bt1r, cb1, k + 1);
+        if constexpr (CPD > 2) window(ba2, bb2, sq2, s12, bt2r, cb2, k + 2);
+        if constexpr (CPD > 3) window(ba3, bb3, sq3, s13, bt3r, cb3, k + 3);
     }
 #undef CAP_ISSUE
 #undef CAP_SEGWIN

@@ -1,0 +1,394 @@
+// Device code of the normcounts sweep: himut's `normcounts.get_callable_tricounts`
+// (src/himut/normcounts.py:206-421, non-phased) on the machinery of the call path.
+//
+// Every reference position of the chunks is a "candidate": the position bitmap is all
+// ones inside the chunks, k_stream_capture<true> transposes every (read, position) cell into
+// the read-major column store -- now with one more bit per cell: "this base counts as
+// callable for its read" (update_tri2count, normcounts.py:66-110) -- and k_norm_eval
+// genotypes every position and bins it.  The contig is swept in passes of NORM_PASS
+// positions so that the column store stays a few GB and 32-bit slot offsets suffice.
+//
+//   k_read_live    thread per read: read filters (normcounts.py:302-309), cs-vs-SEQ check, num_ccs
+//   k_callable     wave per read: one bit per query base (the mismatch-window / trim / BQ rules)
+//   k_fill_bits    the bitmap: ones at the chunk positions of the current pass
+//   k_norm_eval    thread per (chunk, position): pile, genotype, classification, histograms
+#pragma once
+
+#include "himut_kernels.h"
+
+namespace himut {
+
+constexpr int64_t NORM_PASS = (int64_t)8 << 20;   // reference positions per pass (multiple of 256)
+
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C, Params P, uint8_t* live, uint8_t* ccs_flag,
+                                                   int* err) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n) return;
+    const ReadMeta M = D.meta[r];
+    uint8_t lv = 0;
+    if (!(M.flags & RF_SECONDARY)) {
+        // substitutions: the base cs names must be the base SEQ holds (the pile takes it from SEQ)
+        const int nm = D.nmis[r];
+        const uint32_t* mq = D.mq + M.segbase;
+        int bad = 0;
+        for (int e = 0; e < nm; e++) {
+            const uint32_t v = mq[e];
+            if (v & 16u) {
+                const int qa = nib2allele(nib_at(R.seq, M.qoff + (v >> 5)));
+                if (qa > 3) bad = HIMUT_ERR_BASE;
+                else if (qa != (int)(v & 3u)) bad = HIMUT_ERR_CS;
+            }
+        }
+        if (bad) set_err(err, bad);
+        const int32_t qlen = R.qlen[r];
+        bool ok = (M.flags & RF_IDENT_OK) != 0;
+        if ((double)D.bqsum[r] / (double)qlen < (double)P.p.min_qv) ok = false;
+        if ((int)R.mapq[r] < P.p.min_mapq) ok = false;
+        if (!(P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit)) ok = false;
+        if (ok) {
+            // fetched by some chunk: start < tend and end > tstart (normcounts.py:289)
+            int64_t lo = 0, hi = C.n;
+            while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (C.rec[m].start < M.tend) lo = m + 1; else hi = m; }
+            ok = lo > 0 && C.rec[lo - 1].pmaxend > M.tstart;
+        }
+        if (ok) { lv = 1; ccs_flag[R.qid[r]] = 1; }
+    }
+    live[r] = lv;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_callable: one wave per passing read; lane = 32 query bases = one output word.
+// A match base counts when its quality is at least min_bq, it is not trimmed, and the
+// number of mismatch-list entries in its window is at most max_mismatch_count; the window
+// is the one get_mismatch_range gives for the START of the base's cs match operation,
+// shifted along (normcounts.py:84-90), in 0-based coordinates against the 1-based list.
+// A substitution always counts (its three tests are evaluated and ignored, :97-109).
+constexpr int CAL_NM = 256;   // mismatch entries kept in LDS per wave
+
+__global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, const uint8_t* live, uint32_t* cbits) {
+    __shared__ int32_t s_mis[4][CAL_NM];
+    __shared__ uint32_t s_mq[4][CAL_NM];
+    __shared__ __align__(16) int4 s_seg[4][64];
+    const int lane = threadIdx.x & 63, wv = uni((int)(threadIdx.x >> 6));
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    if (r >= R.n) return;
+    if (!uni((int)live[r])) return;
+    const ReadMeta Mv = D.meta[r];
+    const int ns = uni(Mv.nseg);
+    const int64_t segbase = uni(Mv.segbase), qo = uni(Mv.qoff);
+    const int nm = uni(D.nmis[r]);
+    const int32_t qlen = uni(R.qlen[r]);
+    const Seg* gsegs = D.segs + segbase;
+    const int32_t* gmis = D.mis + segbase;
+    const uint32_t* gmq = D.mq + segbase;
+    int32_t* lmis = s_mis[wv];
+    uint32_t* lmq = s_mq[wv];
+    int4* lseg = s_seg[wv];
+    for (int k = lane; k < min(nm, CAL_NM); k += 64) { lmis[k] = gmis[k]; lmq[k] = gmq[k]; }
+    if (lane < min(ns, 64)) lseg[lane] = *reinterpret_cast<const int4*>(gsegs + lane);
+    __builtin_amdgcn_wave_barrier();
+    auto MIS = [&](int k) -> int32_t { return k < CAL_NM ? lmis[k] : gmis[k]; };
+    auto MQ = [&](int k) -> uint32_t { return k < CAL_NM ? lmq[k] : gmq[k]; };
+    auto SEG = [&](int j) -> int4 { return j < 64 ? lseg[j] : *reinterpret_cast<const int4*>(gsegs + j); };
+    auto lower = [&](int32_t x) { int lo = 0, hi = nm; while (lo < hi) { const int m = (lo + hi) >> 1; if (MIS(m) < x) lo = m + 1; else hi = m; } return lo; };
+    auto upper = [&](int32_t x) { int lo = 0, hi = nm; while (lo < hi) { const int m = (lo + hi) >> 1; if (x < MIS(m)) hi = m; else lo = m + 1; } return lo; };
+    const int32_t w = P.p.mismatch_window_size;
+    const double trim_start = floor(P.p.min_trim * (double)qlen);
+    const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);
+    const int min_bq = P.p.min_bq;
+    const int maxmm = P.p.max_mismatch_count;
+    const int32_t q_first = uni(lseg[0].y);
+    for (int32_t c0 = q_first & ~2047; c0 < qlen; c0 += 2048) {
+        const int32_t qa = c0 + lane * 32;
+        uint32_t word = 0;
+        if (qa < qlen) {
+            // qualities of the lane's 32 bases
+            const uint4 b0 = *reinterpret_cast<const uint4*>(R.bq + qo + qa);
+            const uint4 b1 = *reinterpret_cast<const uint4*>(R.bq + qo + qa + 16);
+            const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint32_t okq = 0;    // quality and trim tests per base
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const int q = qa + i;
+                const int bq = (int)((bw[i >> 2] >> (8 * (i & 3))) & 255u);
+                if (q < qlen && bq >= min_bq && !((double)q < trim_start || (double)q > trim_end)) okq |= 1u << i;
+            }
+            // segments under [qa, qa + 32)
+            for (int j = 0; j < ns; j++) {
+                const int4 sg = SEG(j);
+                if (sg.y >= qa + 32) break;
+                if (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) continue;
+                const int32_t a = max(sg.y, qa), b = min(sg.y + sg.z, qa + 32);     // query overlap
+                if (a >= b) continue;
+                const int32_t tlo = sg.x + (a - sg.y), thi = sg.x + (b - 1 - sg.y);  // 0-based reference positions
+                // any list entry that could fall into a window of these bases?
+                const int k0 = lower(tlo - 2 * w - 1);
+                if (k0 >= nm || MIS(k0) > thi + 2 * w + 1) {
+                    word |= okq & (((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa));
+                    continue;
+                }
+                for (int32_t q = a; q < b; q++) {
+                    const int32_t t = sg.x + (q - sg.y);
+                    const int bit = q - qa;
+                    int k = lower(t + 1);
+                    bool is_sub = false;
+                    for (int kk = k; kk < nm && MIS(kk) == t + 1; kk++) {
+                        const uint32_t v = MQ(kk);
+                        if ((v & 16u) && (int32_t)(v >> 5) == q) is_sub = true;
+                    }
+                    if (is_sub) { word |= 1u << bit; continue; }
+                    // start of the match operation the base belongs to: behind the previous substitution of this
+                    // segment, else the segment start
+                    int32_t osq = sg.y;
+                    if (k > 0) {
+                        const uint32_t pv = MQ(k - 1);
+                        const int32_t pq = (int32_t)(pv >> 5);
+                        if ((pv & 16u) && pq >= sg.y && pq < q) osq = pq + 1;
+                    }
+                    int64_t qs = (int64_t)osq - w, qe = (int64_t)osq + w, ur, dr;      // bamlib.py:245-258
+                    if (qs < 0) { ur = w + qs; dr = w - qs; }
+                    else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - osq; }
+                    else { ur = w; dr = w; }
+                    const int cnt = upper((int32_t)(t + dr)) - lower((int32_t)(t - ur));
+                    if (cnt <= maxmm && ((okq >> bit) & 1u)) word |= 1u << bit;
+                }
+            }
+            cbits[((qo + qa) >> 5)] = word;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ones at the positions of [p_lo, p_hi) that lie in some chunk [start, end)
+__global__ void __launch_bounds__(256) k_fill_bits(Chunks C, int64_t p_lo, int64_t p_hi, uint32_t* bits, int64_t nwords) {
+    const int64_t w = (p_lo >> 5) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords || w * 32 >= p_hi) return;
+    const int64_t a = max(w * 32, p_lo), b = min(w * 32 + 32, p_hi);
+    uint32_t m = 0;
+    // chunks with start < b, newest first, while the running maximum of end can still reach a
+    int64_t lo = 0, hi = C.n;
+    while (lo < hi) { const int64_t k = (lo + hi) >> 1; if (C.rec[k].start < b) lo = k + 1; else hi = k; }
+    for (int64_t j = lo - 1; j >= 0 && C.rec[j].pmaxend > a; j--) {
+        const int64_t s = max((int64_t)C.rec[j].start, a), e = min((int64_t)C.rec[j].end, b);
+        if (s < e) m |= (uint32_t)(((1ULL << (e - s)) - 1ULL) << (s - w * 32));
+    }
+    bits[w] = m;
+}
+
+// ---------------------------------------------------------------------------------------
+struct NormArgs {
+    Params P;
+    SiteSets S;
+    const GtLut* lut;
+    Reads R;
+    Chunks C;
+    PosIndex X;
+    const uint16_t* colstore;
+    const uint8_t* refseq;       // the contig as the FASTA holds it
+    int64_t reflen;
+    uint8_t cls[256];            // byte -> class id
+    int K;                       // number of classes
+    int cA, cC, cG, cT;          // class ids of the four bases
+    uint8_t alt_order[12];       // [ref allele][0..2]: list(base_set.difference(ref)) as alleles
+    int non_human;
+    int64_t p_lo, p_hi;          // positions of this pass
+    unsigned long long* ccs_tri; // [K^3]
+    unsigned long long* ref_tri;
+    unsigned long long* log;     // [14]
+    int* err;
+};
+
+constexpr int NE_TILES = 16;     // 256-position tiles per workgroup
+
+__global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
+    __shared__ double s_lut[3 * 256];
+    __shared__ double s_prior[4];
+    __shared__ unsigned int s_log[16];
+    __shared__ unsigned int s_ccs[32], s_ref[32];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = A.lut->t[i >> 8][i & 255];
+    if (tid < 4) s_prior[tid] = A.lut->prior[tid];
+    if (tid < 16) s_log[tid] = 0;
+    if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
+    __syncthreads();
+    const int chunk = blockIdx.y;
+    const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
+    int bad = 0;
+    for (int t = 0; t < NE_TILES; t++) {
+        const int64_t rpos = (int64_t)cs_ + ((int64_t)blockIdx.x * NE_TILES + t) * 256 + tid;
+        if (rpos >= ce_ || rpos < A.p_lo || rpos >= A.p_hi) continue;
+        if (rpos < 0 || rpos >= A.reflen) { bad |= 1 << HIMUT_ERR_ARG; continue; }   // IndexError in the reference
+        const int refc = A.refseq[rpos];
+        const int ref = char2allele(refc);
+        const uint32_t u = pos_rank(A.X, (int32_t)rpos);
+        const BlockTab bt = A.X.bt[rpos >> 8];
+        const uint32_t n = bt.ncnt & BT_N_MASK, stride = bt.ncnt >> 22;
+        const int32_t lo = bt.lo;
+        const uint16_t* col = A.colstore + ((int64_t)bt.boff + (int64_t)(u - bt.ufirst));
+        const bool edge = rpos <= cs_;
+        uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+        double S[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
+        uint32_t tri_sum = 0;
+        bool bq0 = false;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t v = col[(int64_t)i * stride];
+            const uint32_t cell = v & 7u;
+            if ((v & 15u) == CELL_EMPTY) continue;
+            if (edge && !(A.R.tend[lo + (int32_t)i] > cs_)) continue;       // not fetched by this chunk (normcounts.py:289)
+            if (v & CELL_INS) cnt[4]++;
+            if (cell < 4) {
+                const uint32_t q = v >> 8;
+                if (q == 0) bq0 = true;
+                const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if ((int)cell == b) {
+                        cnt[b]++;
+                        S[0][b] = S[0][b] + vh;
+                        S[1][b] = S[1][b] + vt;
+                        S[2][b] = S[2][b] + ve;
+                    }
+                }
+                tri_sum += (v >> 4) & 1u;
+            } else if (cell == CELL_DEL) cnt[5]++;
+            else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;           // normcounts.py:126
+        }
+        if (ref < 0 || tri_sum == 0) continue;                                  // normcounts.py:318-321
+        if (bq0) { bad |= 1 << HIMUT_ERR_BQ0; continue; }
+        int slot = 1;   // which counter takes tri_sum besides num_bases; 13 = callable
+        // get_germ_gt (gtlib.py:72-135)
+        double best = 0.0, second = 0.0;
+        int ibest = 0;
+#pragma unroll
+        for (int g = 0; g < 10; g++) {
+            const int b1 = (int)HIMUT_GT_B1(g), b2 = (int)HIMUT_GT_B2(g);
+            double acc = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                double term;
+                if (b1 == b2 && b == b1) term = S[0][b];
+                else if (b1 != b2 && (b == b1 || b == b2)) term = S[1][b];
+                else term = S[2][b];
+                acc = acc + term;
+            }
+            acc = acc + s_prior[gt_state_of(b1, b2, ref)];
+            const double pl = -10.0 * acc;
+            if (g == 0) { best = pl; ibest = 0; }
+            else if (pl < best) { second = best; best = pl; ibest = g; }
+            else if (g == 1 || pl < second) second = pl;
+        }
+        const double gqf = second - best;
+        const int gq = gqf < 99.0 ? (int)gqf : 99;
+        const int state = gt_state_of((int)HIMUT_GT_B1(ibest), (int)HIMUT_GT_B2(ibest), ref);
+        const uint32_t depth = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[5];
+        uint32_t ref_count = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) if (b == ref) ref_count = cnt[b];
+        if (state == 1) slot = 3;
+        else if (state == 2) slot = 4;
+        else if (state == 3) slot = 5;
+        else {
+            atomicAdd(&s_log[6], tri_sum);                                      // num_homref_bases
+            if (cnt[5] != 0 || cnt[4] != 0) slot = 7;
+            else if ((int64_t)depth > A.P.p.md_threshold) slot = 8;
+            else if (depth == ref_count) {
+                if (gq < A.P.p.min_gq) slot = 10;
+                else if ((int64_t)ref_count < A.P.p.min_ref_count) slot = 9;
+                else slot = 13;
+            } else {
+                // the alternative alleles in the order python's set gives them (normcounts.py:367-385)
+                bool filtered = false;
+                uint32_t ac[3] = {0, 0, 0};
+                const int32_t tpos = (int32_t)rpos + 1;
+                const SiteSets& St = A.S;
+                const bool site_maybe = !A.non_human && (int64_t)tpos < St.nposbits && ((St.posbits[tpos >> 5] >> (tpos & 31)) & 1u);
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    if (filtered) continue;
+                    const int aidx = A.alt_order[ref * 3 + a];
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) if (b == aidx) c = cnt[b];
+                    ac[a] = c;
+                    if (c == 0 || !site_maybe) continue;
+                    const uint64_t key = ((uint64_t)(uint32_t)tpos << 4) | ((uint64_t)ref << 2) | (uint64_t)aidx;
+                    if (key_in(St.pon, St.npon, key)) { filtered = true; slot = 11; }
+                    else if (key_in(St.com, St.ncom, key)) { filtered = true; slot = 12; }
+                }
+                if (!filtered) {
+                    int bi = 0;
+                    if (ac[1] > ac[bi]) bi = 1;
+                    if (ac[2] > ac[bi]) bi = 2;
+                    const int aidx = A.alt_order[ref * 3 + bi];
+                    // get_germ_gq(alt, ...): the same ten sums without the alternative allele (gtlib.py:138-174)
+                    double b2best = 0.0, b2second = 0.0;
+#pragma unroll
+                    for (int g = 0; g < 10; g++) {
+                        const int b1 = (int)HIMUT_GT_B1(g), b2 = (int)HIMUT_GT_B2(g);
+                        double acc = 0.0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            if (b == aidx) continue;
+                            double term;
+                            if (b1 == b2 && b == b1) term = S[0][b];
+                            else if (b1 != b2 && (b == b1 || b == b2)) term = S[1][b];
+                            else term = S[2][b];
+                            acc = acc + term;
+                        }
+                        acc = acc + s_prior[gt_state_of(b1, b2, ref)];
+                        const double pl = acc * -10.0;
+                        if (g == 0) b2best = pl;
+                        else if (pl < b2best) { b2second = b2best; b2best = pl; }
+                        else if (g == 1 || pl < b2second) b2second = pl;
+                    }
+                    const double g2 = b2second - b2best;
+                    const int gq2 = g2 < 99.0 ? (int)g2 : 99;
+                    uint32_t alt_count = ac[bi];
+                    if (gq2 < A.P.p.min_gq) slot = 10;
+                    else if (!((int64_t)ref_count >= A.P.p.min_ref_count && (int64_t)alt_count >= A.P.p.min_alt_count)) slot = 9;
+                    else slot = 13;
+                }
+            }
+        }
+        atomicAdd(&s_log[1], tri_sum);
+        atomicAdd(&s_log[slot], tri_sum);
+        if (slot == 13) {
+            // get_tri_context (normcounts.py:49-63)
+            int t0 = 'N', t1 = 'N', t2 = 'N';
+            if (rpos - 1 >= 0 && rpos + 2 <= A.reflen) {
+                t0 = A.refseq[rpos - 1]; t1 = refc; t2 = A.refseq[rpos + 1];
+                if (t1 == 'A' || t1 == 'G') {
+                    const int a0 = t2, a2 = t0;
+                    t0 = a0 == 'A' ? 'T' : a0 == 'T' ? 'A' : a0 == 'G' ? 'C' : a0 == 'C' ? 'G' : 'N';
+                    t1 = t1 == 'A' ? 'T' : 'C';
+                    t2 = a2 == 'A' ? 'T' : a2 == 'T' ? 'A' : a2 == 'G' ? 'C' : a2 == 'C' ? 'G' : 'N';
+                }
+            }
+            auto acgt = [](int c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
+            const int i0 = acgt(t0), i2 = acgt(t2);
+            if (i0 >= 0 && i2 >= 0 && (t1 == 'C' || t1 == 'T')) {
+                const int k = i0 * 8 + (t1 == 'T' ? 4 : 0) + i2;
+                atomicAdd(&s_ccs[k], tri_sum);
+                atomicAdd(&s_ref[k], 1u);
+            } else {
+                const int64_t k = ((int64_t)A.cls[t0] * A.K + A.cls[t1]) * A.K + A.cls[t2];
+                atomicAdd(&A.ccs_tri[k], (unsigned long long)tri_sum);
+                atomicAdd(&A.ref_tri[k], 1ULL);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
+    if (tid < 32 && (s_ccs[tid] || s_ref[tid])) {
+        const int cl[4] = {A.cA, A.cC, A.cG, A.cT};
+        const int64_t k = ((int64_t)cl[tid >> 3] * A.K + ((tid & 4) ? A.cT : A.cC)) * A.K + cl[tid & 3];
+        atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
+        atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
+    }
+    if (bad) atomicOr(A.err, bad);
+}
+
+}  // namespace himut

@@ -181,6 +181,23 @@ int himut_get_stats(himut_ctx* ctx, himut_run_stats* out);
 int himut_records_device(himut_ctx* ctx, const void** dev_ptr, int64_t* n);
 int himut_copy_records_to_device(himut_ctx* ctx, void* dst_device, int64_t capacity_records);
 
+/* ---- next row: normcounts.get_callable_tricounts, non-phased ------------------
+ * The worker's arguments (normcounts.py:206-241) map onto the same calls as the call path
+ * (params, LUT, chunks, site sets, reads) plus the contig's reference string:
+ *   seq (str(refseq[chrom]), normcounts.py:504)          himut_set_reference
+ *   the body of the worker (normcounts.py:243-402)       himut_run_normcounts
+ *   chrom2{ccs,ref}_callable_tri2count, chrom2norm_log   himut_get_normcounts
+ * seq is passed as the FASTA holds it (case matters: the reference skips positions whose base
+ * is not an upper-case A/C/G/T).  cls[256] maps every byte of seq to a class id < n_classes
+ * (one class per distinct byte, A C G T N always present, at most 32); the two histograms
+ * are indexed (c0 * K + c1) * K + c2 over the class ids of the trinucleotide key.
+ * alt_order[ref * 3 + i] = allele of list(base_set.difference(ref))[i] (normcounts.py:367): the
+ * order python gives that set decides PoN/common precedence and ties, so the host supplies it.
+ * log[14] in the order of chrom2norm_log (normcounts.py:404-419). */
+int himut_set_reference(himut_ctx* ctx, const uint8_t* seq, int64_t len, const uint8_t cls[256], int n_classes);
+int himut_run_normcounts(himut_ctx* ctx, const uint8_t alt_order[12], int non_human_sample);
+int himut_get_normcounts(himut_ctx* ctx, int64_t* ccs_tri, int64_t* ref_tri, int64_t log[14]);
+
 /* Dense pile of [p0, p1) over ALL pushed reads (no chunk restriction):
  * counts[(p - p0) * 6 + a], bqsum[(p - p0) * 4 + b]  (caller.py:44-72). */
 int himut_pile_counts(himut_ctx* ctx, int32_t p0, int32_t p1, uint32_t* counts, uint32_t* bqsum);
