@@ -1266,8 +1266,14 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
     for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
     uint32_t ref_count = 0, alt_count = 0, alt_hi = 0, h0_ref = 0, h1_ref = 0, som0 = 0, som1 = 0;
     int bad = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t v = col[(int64_t)i * stride];
+    for (uint32_t i0 = 0; i0 < n; i0 += 8) {     // eight slots in flight: their addresses do not depend on each other
+      uint32_t vv[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t i = i0 + k;
+        const uint32_t v = vv[k];
         const uint32_t cell = v & 7u;
         if ((v & 15u) == CELL_EMPTY) continue;
         int32_t tend = 0;
@@ -1300,6 +1306,7 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
             }
         } else if (cell == CELL_DEL) cnt[5]++;
         else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;       // caller.py:57
+      }
     }
 
     // ten PLs, gtlib.py:72-110; np.argsort with the scalar insertion sort: ties -> lower index (gtlib.py:113-119)

@@ -128,29 +128,46 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                     word |= okq & (((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa));
                     continue;
                 }
+                // the few entries near these bases, in registers (value, query offset | substitution flag)
+                constexpr int NE = 8;
+                int32_t ev[NE];
+                uint32_t eq[NE];
+                int ne = 0;
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    ev[i] = 0x7fffffff; eq[i] = 0;
+                    if (k0 + i < nm) { const int32_t m = MIS(k0 + i); if (m <= thi + 2 * w + 1) { ev[i] = m; eq[i] = MQ(k0 + i); ne = i + 1; } }
+                }
+                const bool overflow = k0 + NE < nm && MIS(k0 + NE) <= thi + 2 * w + 1;   // more than NE entries nearby
+                // start of the match operation the first base belongs to: behind the previous substitution of this
+                // segment, else the segment start
+                int32_t osq = sg.y;
+                {
+                    const int kp = lower(tlo + 1) - 1;
+                    if (kp >= 0) {
+                        const uint32_t pv = MQ(kp);
+                        const int32_t pq = (int32_t)(pv >> 5);
+                        if ((pv & 16u) && pq >= sg.y && pq < a) osq = pq + 1;
+                    }
+                }
                 for (int32_t q = a; q < b; q++) {
                     const int32_t t = sg.x + (q - sg.y);
                     const int bit = q - qa;
-                    int k = lower(t + 1);
                     bool is_sub = false;
-                    for (int kk = k; kk < nm && MIS(kk) == t + 1; kk++) {
-                        const uint32_t v = MQ(kk);
-                        if ((v & 16u) && (int32_t)(v >> 5) == q) is_sub = true;
-                    }
-                    if (is_sub) { word |= 1u << bit; continue; }
-                    // start of the match operation the base belongs to: behind the previous substitution of this
-                    // segment, else the segment start
-                    int32_t osq = sg.y;
-                    if (k > 0) {
-                        const uint32_t pv = MQ(k - 1);
-                        const int32_t pq = (int32_t)(pv >> 5);
-                        if ((pv & 16u) && pq >= sg.y && pq < q) osq = pq + 1;
-                    }
+#pragma unroll
+                    for (int i = 0; i < NE; i++) if (ev[i] == t + 1 && (eq[i] & 16u) && (int32_t)(eq[i] >> 5) == q) is_sub = true;
+                    if (overflow && !is_sub)
+                        for (int kk = lower(t + 1); kk < nm && MIS(kk) == t + 1; kk++) { const uint32_t v = MQ(kk); if ((v & 16u) && (int32_t)(v >> 5) == q) is_sub = true; }
+                    if (is_sub) { word |= 1u << bit; osq = q + 1; continue; }
                     int64_t qs = (int64_t)osq - w, qe = (int64_t)osq + w, ur, dr;      // bamlib.py:245-258
                     if (qs < 0) { ur = w + qs; dr = w - qs; }
                     else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - osq; }
                     else { ur = w; dr = w; }
-                    const int cnt = upper((int32_t)(t + dr)) - lower((int32_t)(t - ur));
+                    int cnt = 0;
+                    if (!overflow) {
+#pragma unroll
+                        for (int i = 0; i < NE; i++) cnt += (ev[i] >= t - ur && ev[i] <= t + dr) ? 1 : 0;
+                    } else cnt = upper((int32_t)(t + dr)) - lower((int32_t)(t - ur));
                     if (cnt <= maxmm && ((okq >> bit) & 1u)) word |= 1u << bit;
                 }
             }
@@ -233,28 +250,35 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
         for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
         uint32_t tri_sum = 0;
         bool bq0 = false;
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t v = col[(int64_t)i * stride];
-            const uint32_t cell = v & 7u;
-            if ((v & 15u) == CELL_EMPTY) continue;
-            if (edge && !(A.R.tend[lo + (int32_t)i] > cs_)) continue;       // not fetched by this chunk (normcounts.py:289)
-            if (v & CELL_INS) cnt[4]++;
-            if (cell < 4) {
-                const uint32_t q = v >> 8;
-                if (q == 0) bq0 = true;
-                const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q];
+        // eight slots of the column are in flight at a time (their addresses do not depend on each other)
+        for (uint32_t i0 = 0; i0 < n; i0 += 8) {
+            uint32_t vv[8];
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    if ((int)cell == b) {
-                        cnt[b]++;
-                        S[0][b] = S[0][b] + vh;
-                        S[1][b] = S[1][b] + vt;
-                        S[2][b] = S[2][b] + ve;
+            for (int k = 0; k < 8; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t v = vv[k];
+                const uint32_t cell = v & 7u;
+                if ((v & 15u) == CELL_EMPTY) continue;
+                if (edge && !(A.R.tend[lo + (int32_t)(i0 + k)] > cs_)) continue;   // not fetched by this chunk (normcounts.py:289)
+                if (v & CELL_INS) cnt[4]++;
+                if (cell < 4) {
+                    const uint32_t q = v >> 8;
+                    if (q == 0) bq0 = true;
+                    const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        if ((int)cell == b) {
+                            cnt[b]++;
+                            S[0][b] = S[0][b] + vh;
+                            S[1][b] = S[1][b] + vt;
+                            S[2][b] = S[2][b] + ve;
+                        }
                     }
-                }
-                tri_sum += (v >> 4) & 1u;
-            } else if (cell == CELL_DEL) cnt[5]++;
-            else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;           // normcounts.py:126
+                    tri_sum += (v >> 4) & 1u;
+                } else if (cell == CELL_DEL) cnt[5]++;
+                else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;           // normcounts.py:126
+            }
         }
         if (ref < 0 || tri_sum == 0) continue;                                  // normcounts.py:318-321
         if (bq0) { bad |= 1 << HIMUT_ERR_BQ0; continue; }
