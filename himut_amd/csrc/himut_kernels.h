@@ -957,6 +957,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     __shared__ __align__(16) int4 s_seg[4][CSG + 1];
     __shared__ __align__(16) uint32_t s_bt[4][64];        // 16 block-table entries
     __shared__ uint32_t s_cb[4][NORM ? 64 : 1];            // normcounts: the window's callable bits
+    __shared__ uint32_t s_wb[4][NORM ? 128 : 1];           // normcounts: the bitmap words under the window
     __shared__ uint2 s_list[4][CLQ];
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const Reads& R = A.R;
@@ -993,8 +994,13 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
         BA = *reinterpret_cast<const uint4*>(R.bq + qo + _qa); \
         BB = *reinterpret_cast<const uint4*>(R.bq + qo + _qb); \
         SQ = *reinterpret_cast<const uint4*>(R.seq + ((qo + _qs) >> 1)); \
-        const int64_t _w = min(((int64_t)(TA) + CPL * lane) >> 5, X.nwords - 1); \
-        __builtin_memcpy(&S1, X.bits + _w, 8);                 /* nwords + 2 words are allocated */ \
+        if (NORM) {   /* dense: words (TA >> 5) + lane and + 64 + lane, word aligned */ \
+            S1.x = X.bits[min((int64_t)((TA) >> 5) + lane, X.nwords - 1)]; \
+            S1.y = X.bits[min((int64_t)((TA) >> 5) + 64 + lane, X.nwords - 1)]; \
+        } else { \
+            const int64_t _w = min(((int64_t)(TA) + CPL * lane) >> 5, X.nwords - 1); \
+            __builtin_memcpy(&S1, X.bits + _w, 8);             /* nwords + 2 words are allocated */ \
+        } \
         BT = reinterpret_cast<const uint32_t*>(X.bt + min((int64_t)((TA) >> 8) + (lane >> 2), X.nblk - 1))[lane & 3]; \
         if (NORM) CB = A.callable[((qo + min(_c, qpad - 32)) >> 5) + min(lane, ((qpad - 1 - min(_c, qpad - 32)) >> 5))]; \
     } while (0)
@@ -1072,6 +1078,78 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
         const int32_t ta_next = window_end(k + CPD);
         __builtin_amdgcn_wave_barrier();
         const int64_t btb = tA >> 8;
+        // one candidate per lane: segment, cell value, slot, store
+        auto batch = [&](const bool act, const uint32_t rpos, const uint32_t u, const int32_t rlast) {
+            // the segment that holds rpos = the last one that starts at or before it.  Candidates come
+            // in reference order, so one cursor walks the list once per read (wave-uniform LDS reads)
+            int4 sg = make_int4(0, 0, 0, 0);   // t0, q0, len, flags
+            {
+                int j = jcur;
+                while (j < ns) {
+                    if (j < jb || j >= jb + nw) {    // lists longer than the LDS window: reload it from j
+                        jb = j; nw = min(ns - jb, CSG);
+                        __builtin_amdgcn_wave_barrier();
+                        CAP_SEGWIN();
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    const int4 t = lseg[j - jb];
+                    if (uni(t.x) > rlast) break;
+                    if (act && (int32_t)rpos >= t.x) sg = t;
+                    j++;
+                }
+                jcur = max(j - 1, jcur);
+            }
+            if (act) {
+                const int32_t d = (int32_t)rpos - sg.x;
+                const uint32_t insb = (d == 0 && ((uint32_t)sg.w & SEG_INS)) ? CELL_INS : 0u;
+                bool store = false;
+                uint32_t val = 0;
+                if ((uint32_t)sg.w & SEG_DEL) { if (d < sg.z) { store = true; val = CELL_DEL | insb; } }
+                else if (sg.z == 0) { if (d == 0 && insb) { store = true; val = CELL_EMPTY | CELL_INS; } }
+                else if (d < sg.z) {
+                    store = true;
+                    const int32_t q = sg.y + d;
+                    const int32_t o = (q - cq) & (CWQ - 1);       // inside the window by construction
+                    const uint32_t qv = wbq[o], sb = wsq[o >> 1];
+                    const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
+                    val = insb | (uint32_t)nib2allele(nib) | (qv << 8);
+                    if (NORM) val |= ((wcb[o >> 5] >> (o & 31)) & 1u) << 4;
+                }
+                if (store) {
+                    const int64_t bi = (int64_t)(rpos >> 8) - btb;
+                    uint4 t;
+                    if (bi >= 0 && bi < 16) t = *reinterpret_cast<const uint4*>(lbt + 4 * bi);
+                    else { t = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)(rpos >> 8), X.nblk - 1)); CAP_LANDED4(t); }
+                    // BlockTab: x = lo, y = n | cnt << 22, z = boff, w = ufirst
+                    const int64_t slot = (int64_t)t.z + (int64_t)(r - (int32_t)t.x) * (int64_t)(t.y >> 22) + (int64_t)(u - t.w);
+                    if ((uint64_t)slot < (uint64_t)A.nslots) A.colstore[slot] = (uint16_t)val;
+                }
+            }
+        };
+        if constexpr (NORM) {
+            // ---- dense: (nearly) every position of [tA, tB) is a candidate, so lane = position, 64 at a time; the
+            // bitmap words under the window sit in LDS, the rank is a running count
+            uint32_t* wb = s_wb[wv];
+            wb[lane] = mylo; wb[64 + lane] = myhi;
+            __builtin_amdgcn_wave_barrier();
+            const int64_t wbase = tA >> 5;
+            for (int32_t pg = tA; pg < tB; pg += 64) {
+                const int32_t p = pg + lane;
+                bool bit = false;
+                if (p < tB) {
+                    const int64_t wi = ((int64_t)p >> 5) - wbase;
+                    uint32_t word;
+                    if (wi < 128) word = wb[wi];
+                    else { word = X.bits[min((int64_t)p >> 5, X.nwords - 1)]; asm volatile("" : "+v"(word)); }   // long deletions
+                    bit = (word >> (p & 31)) & 1u;
+                }
+                const unsigned long long m = __ballot(bit);
+                if (!m) continue;
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                batch(bit, (uint32_t)p, ubase + below, pg + 63 - (int)__builtin_clzll(m));
+                ubase += (uint32_t)__popcll(m);
+            }
+        } else {
         // ---- candidate bits of [tA, tB): lane l takes the CPL positions from tA + CPL * l
         for (int32_t pg = tA; pg < tB; pg += 64 * CPL) {
             const int32_t p0 = pg + CPL * lane;
@@ -1116,58 +1194,14 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
                     const bool act = lane < bn;
                     uint32_t rpos = 0, u = 0;
                     if (act) { const uint2 e = list[(head + lane) & (CLQ - 1)]; rpos = e.x; u = e.y; }
-                    // the segment that holds rpos = the last one that starts at or before it.  Candidates come
-                    // in reference order, so one cursor walks the list once per read (wave-uniform LDS reads)
-                    int4 sg = make_int4(0, 0, 0, 0);   // t0, q0, len, flags
-                    {
-                        const int32_t rlast = lane_val((int)rpos, bn - 1);
-                        int j = jcur;
-                        while (j < ns) {
-                            if (j < jb || j >= jb + nw) {    // lists longer than the LDS window: reload it from j
-                                jb = j; nw = min(ns - jb, CSG);
-                                __builtin_amdgcn_wave_barrier();
-                                CAP_SEGWIN();
-                                __builtin_amdgcn_wave_barrier();
-                            }
-                            const int4 t = lseg[j - jb];
-                            if (uni(t.x) > rlast) break;
-                            if (act && (int32_t)rpos >= t.x) sg = t;
-                            j++;
-                        }
-                        jcur = max(j - 1, jcur);
-                    }
-                    if (act) {
-                        const int32_t d = (int32_t)rpos - sg.x;
-                        const uint32_t insb = (d == 0 && ((uint32_t)sg.w & SEG_INS)) ? CELL_INS : 0u;
-                        bool store = false;
-                        uint32_t val = 0;
-                        if ((uint32_t)sg.w & SEG_DEL) { if (d < sg.z) { store = true; val = CELL_DEL | insb; } }
-                        else if (sg.z == 0) { if (d == 0 && insb) { store = true; val = CELL_EMPTY | CELL_INS; } }
-                        else if (d < sg.z) {
-                            store = true;
-                            const int32_t q = sg.y + d;
-                            const int32_t o = (q - cq) & (CWQ - 1);       // inside the window by construction
-                            const uint32_t qv = wbq[o], sb = wsq[o >> 1];
-                            const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
-                            val = insb | (uint32_t)nib2allele(nib) | (qv << 8);
-                            if (NORM) val |= ((wcb[o >> 5] >> (o & 31)) & 1u) << 4;
-                        }
-                        if (store) {
-                            const int64_t bi = (int64_t)(rpos >> 8) - btb;
-                            uint4 t;
-                            if (bi >= 0 && bi < 16) t = *reinterpret_cast<const uint4*>(lbt + 4 * bi);
-                            else { t = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)(rpos >> 8), X.nblk - 1)); CAP_LANDED4(t); }
-                            // BlockTab: x = lo, y = n | cnt << 22, z = boff, w = ufirst
-                            const int64_t slot = (int64_t)t.z + (int64_t)(r - (int32_t)t.x) * (int64_t)(t.y >> 22) + (int64_t)(u - t.w);
-                            if ((uint64_t)slot < (uint64_t)A.nslots) A.colstore[slot] = (uint16_t)val;
-                        }
-                    }
+                    batch(act, rpos, u, lane_val((int)rpos, bn - 1));
                     head = (head + bn) & (CLQ - 1); n -= bn;
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (done >= 64) break;
             }
             ubase += (uint32_t)total;
+        }
         }
 #pragma unroll
         for (int i = 0; i < CPD; i++) ta[i] = ta[i + 1];

@@ -97,6 +97,8 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
     const double trim_start = floor(P.p.min_trim * (double)qlen);
     const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);
     const int min_bq = P.p.min_bq;
+    const int min_bq_c = min(max(min_bq, 1), 127);
+    const int32_t trim_lo = (int32_t)trim_start, trim_hi = (int32_t)trim_end;
     const int maxmm = P.p.max_mismatch_count;
     const int32_t q_first = uni(lseg[0].y);
     for (int32_t c0 = q_first & ~2047; c0 < qlen; c0 += 2048) {
@@ -107,12 +109,16 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
             const uint4 b0 = *reinterpret_cast<const uint4*>(R.bq + qo + qa);
             const uint4 b1 = *reinterpret_cast<const uint4*>(R.bq + qo + qa + 16);
             const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            uint32_t okq = 0;    // quality and trim tests per base
+            uint32_t okq = 0;    // quality and trim tests per base, four bytes at a time (qualities are < 128)
 #pragma unroll
-            for (int i = 0; i < 32; i++) {
-                const int q = qa + i;
-                const int bq = (int)((bw[i >> 2] >> (8 * (i & 3))) & 255u);
-                if (q < qlen && bq >= min_bq && !((double)q < trim_start || (double)q > trim_end)) okq |= 1u << i;
+            for (int k = 0; k < 8; k++) okq |= cs_pack4(cs_ge_bytes(bw[k], (uint32_t)min_bq_c) & ~(bw[k] & 0x80808080u)) << (4 * k);
+            if (min_bq <= 0) okq = ~0u;
+            if (min_bq > 127) okq = 0;
+            {
+                // not trimmed: trim_lo <= q <= trim_hi (the two bounds are whole numbers), and q < qlen
+                const int32_t lo_q = max(trim_lo, 0), hi_q = min(trim_hi, qlen - 1);
+                const int32_t a0 = max(lo_q - qa, 0), a1 = min(hi_q - qa, 31);
+                okq &= (a0 <= a1) ? ((a1 - a0 >= 31 ? ~0u : ((1u << (a1 - a0 + 1)) - 1u)) << a0) : 0u;
             }
             // segments under [qa, qa + 32)
             for (int j = 0; j < ns; j++) {
