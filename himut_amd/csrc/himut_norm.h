@@ -156,6 +156,39 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                         if ((pv & 16u) && pq >= sg.y && pq < a) osq = pq + 1;
                     }
                 }
+                // Away from the read's ends every match operation has the window (w, w), so "how many entries see
+                // this base" is a sum of bit ranges: bit-sliced counters instead of a loop over the bases.
+                if (!overflow && osq >= w && (int64_t)qa + 32 + w <= (int64_t)qlen) {
+                    const int32_t shift = sg.y - sg.x - qa;           // bit of reference position t = t + shift
+                    const uint32_t span = ((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa);
+                    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, sub = 0;
+#pragma unroll
+                    for (int i = 0; i < NE; i++) {
+                        if (i >= ne) continue;
+                        const int lo = max(ev[i] - w + shift, 0), hi = min(ev[i] + w + shift, 31);
+                        uint32_t rr = 0;
+                        if (lo <= hi) rr = ((hi - lo) >= 31 ? ~0u : ((1u << (hi - lo + 1)) - 1u)) << lo;
+                        const uint32_t k0_ = c0 & rr; c0 ^= rr;
+                        const uint32_t k1_ = c1 & k0_; c1 ^= k0_;
+                        const uint32_t k2_ = c2 & k1_; c2 ^= k1_;
+                        c3 ^= k2_;
+                        const int32_t sq = (int32_t)(eq[i] >> 5);
+                        if ((eq[i] & 16u) && sq >= a && sq < b && ev[i] == sg.x + (sq - sg.y) + 1) sub |= 1u << (sq - qa);
+                    }
+                    uint32_t gt = 0;                                   // bases seen by more than maxmm entries
+                    if (maxmm < 8) {
+                        uint32_t same = ~0u;
+                        const uint32_t planes[4] = {c0, c1, c2, c3};
+#pragma unroll
+                        for (int pbit = 3; pbit >= 0; pbit--) {
+                            const uint32_t kb = ((maxmm >> pbit) & 1) ? ~0u : 0u;
+                            gt |= same & planes[pbit] & ~kb;
+                            same &= ~(planes[pbit] ^ kb);
+                        }
+                    }
+                    word |= span & ((okq & ~gt) | sub);
+                    continue;
+                }
                 for (int32_t q = a; q < b; q++) {
                     const int32_t t = sg.x + (q - sg.y);
                     const int bit = q - qa;
@@ -256,13 +289,13 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
         for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
         uint32_t tri_sum = 0;
         bool bq0 = false;
-        // eight slots of the column are in flight at a time (their addresses do not depend on each other)
-        for (uint32_t i0 = 0; i0 < n; i0 += 8) {
-            uint32_t vv[8];
+        // sixteen slots of the column are in flight at a time (their addresses do not depend on each other)
+        for (uint32_t i0 = 0; i0 < n; i0 += 16) {
+            uint32_t vv[16];
 #pragma unroll
-            for (int k = 0; k < 8; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
+            for (int k = 0; k < 16; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 16; k++) {
                 const uint32_t v = vv[k];
                 const uint32_t cell = v & 7u;
                 if ((v & 15u) == CELL_EMPTY) continue;
