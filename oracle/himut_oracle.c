@@ -710,14 +710,14 @@ static int64_t tri_index(const uint8_t* seq, int64_t len, int64_t pos, const uin
     return ((int64_t)cls[t[0]] * K + cls[t[1]]) * K + cls[t[2]];
 }
 
-/* Non-phased get_callable_tricounts (normcounts.py:206-421).
+/* get_callable_tricounts (normcounts.py:206-421), with or without --phase.
  * refseq: the contig as the FASTA holds it (case preserved); cls[256]: byte -> class id (< K); alt_order[ri][0..2]:
  * list(base_set.difference(ref)) as alleles 0..3 for ref allele ri (python set order, supplied by the caller).
  * Outputs: ccs_tri/ref_tri [K*K*K] (added to), log[14]. */
 int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, int64_t nchunks, const int32_t* cstart,
                    const int32_t* cend, const uint64_t* pon, int64_t npon, const uint64_t* com, int64_t ncom,
                    const uint8_t* refseq, int64_t reflen, const uint8_t* cls, int K, const uint8_t* alt_order,
-                   int non_human_sample, int64_t* ccs_tri, int64_t* ref_tri, int64_t log[14]) {
+                   int non_human_sample, const orc_phase* PH, int64_t* ccs_tri, int64_t* ref_tri, int64_t log[14]) {
     int rc = ORC_OK;
     const int64_t n = R->n;
     orc_oplist* OL = (orc_oplist*)calloc((size_t)(n > 0 ? n : 1), sizeof(orc_oplist));
@@ -726,7 +726,7 @@ int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, in
     int64_t m[14];
     memset(m, 0, sizeof(m));
     if (!OL) return ORC_ERR_NOMEM;
-    if (P->phase) { free(OL); return ORC_ERR_ARG; } /* phased normcounts: not restated yet */
+    if (P->phase && !PH) { free(OL); return ORC_ERR_ARG; }
     for (int64_t r = 0; r < n; r++) {
         if (R->flag[r] & 0x100) continue; /* bamlib.py:17, normcounts.py:291 */
         rc = parse_cs(R, r, &OL[r]);
@@ -758,6 +758,7 @@ int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, in
         uint32_t* counts = (uint32_t*)calloc((size_t)W * 6, sizeof(uint32_t));
         int64_t* loff = (int64_t*)calloc((size_t)W + 1, sizeof(int64_t));
         uint32_t* callable = (uint32_t*)calloc((size_t)W, sizeof(uint32_t)); /* rpos2count, normcounts.py:286 */
+        uint32_t* hapcnt = (uint32_t*)calloc((size_t)W * 2, sizeof(uint32_t)); /* rpos2hap2count for "0" and "1", :288 */
         for (int64_t f = 0; f < nfetch; f++) {
             int64_t r = fetch[f];
             int64_t tpos = R->tstart[r];
@@ -776,7 +777,12 @@ int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, in
         for (int64_t f = 0; f < nfetch && !rc; f++) {
             int64_t r = fetch[f];
             const orc_oplist* ol = &OL[r];
-            /* update_allelecounts: normcounts.py:113-140 */
+            int hap = '.';
+            if (P->phase) { /* normcounts.py:293-295 */
+                hap = ccs_hap(R, OL, r, PH, c);
+                if (hap < 0) { rc = ORC_ERR_COVER; break; }
+            }
+            /* update_allelecounts / update_phased_allelecounts: normcounts.py:113-172 */
             int64_t tpos = R->tstart[r];
             int64_t qpos = R->qstart[r];
             int64_t match_count = 0, mismatch_count = 0;
@@ -790,6 +796,7 @@ int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, in
                         counts[w * 6 + b]++;
                         pile_entry* pe = &ent[fill[w]++];
                         pe->allele = (uint8_t)b; pe->bq = R->bq[R->qoff[r] + qpos + i]; pe->read = (int32_t)r;
+                        if (hap == '0') hapcnt[w * 2]++; else if (hap == '1') hapcnt[w * 2 + 1]++;
                     }
                     match_count += op->ref_len;
                 } else if (op->state == 2) {
@@ -799,6 +806,7 @@ int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, in
                     counts[w * 6 + b]++;
                     pile_entry* pe = &ent[fill[w]++];
                     pe->allele = (uint8_t)b; pe->bq = R->bq[R->qoff[r] + qpos]; pe->read = (int32_t)r;
+                    if (hap == '0') hapcnt[w * 2]++; else if (hap == '1') hapcnt[w * 2 + 1]++;
                     mismatch_count += op->alt_len;
                 } else if (op->state == 3) {
                     counts[(tpos - pmin) * 6 + 4]++;
@@ -811,6 +819,7 @@ int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, in
                 qpos += op->alt_len;
             }
             if (rc) break;
+            if (P->phase && !(hap == '0' || hap == '1')) continue; /* normcounts.py:297-298 */
             /* read filters: normcounts.py:302-309 */
             int64_t bqs = 0;
             for (int32_t q = 0; q < R->qlen[r]; q++) bqs += R->bq[R->qoff[r] + q];
@@ -872,6 +881,10 @@ int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, in
             if (ridx < 0) continue;
             if (tri_sum == 0) continue;
             m[1] += tri_sum;
+            if (P->phase && !((int64_t)hapcnt[w * 2] >= P->min_hap_count && (int64_t)hapcnt[w * 2 + 1] >= P->min_hap_count)) {
+                m[2] += tri_sum; /* is_rpos_phased, normcounts.py:198-205,324-328 */
+                continue;
+            }
             const uint32_t* cz = &counts[w * 6];
             const pile_entry* col = &ent[loff[w]];
             const int32_t depth_l = (int32_t)(loff[w + 1] - loff[w]);
@@ -928,7 +941,7 @@ int orc_normcounts(const orc_reads* R, const orc_params* P, const orc_lut* L, in
             ccs_tri[tri] += tri_sum;
             m[13] += tri_sum;
         }
-        free(fill); free(ent); free(loff); free(counts); free(callable); free(fetch);
+        free(fill); free(ent); free(loff); free(counts); free(callable); free(hapcnt); free(fetch);
     }
 done:
     /* chrom2norm_log order (normcounts.py:404-419): ccs, bases, unphased, het, hetalt, homalt, homref, uncallable,

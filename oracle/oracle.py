@@ -276,8 +276,9 @@ def alt_order_table(order=None):
 
 
 def normcounts(batch, chunks, params, refseq, germline_snv_prior=1 / (10 ** 3), pon_keys=None, com_keys=None,
-               alt_order=None, non_human_sample=False):
-    """Restated non-phased normcounts.get_callable_tricounts.  Returns (ccs_tri2count, ref_tri2count, log[14])."""
+               alt_order=None, non_human_sample=False, phase=None):
+    """Restated normcounts.get_callable_tricounts (phase = (hbit, hpos, hetsnp) dicts or None).
+    Returns (ccs_tri2count, ref_tri2count, log[14])."""
     L = lib()
     L.orc_normcounts.restype = ctypes.c_int
     hom, het, err, logp = build_lut(germline_snv_prior)
@@ -286,13 +287,18 @@ def normcounts(batch, chunks, params, refseq, germline_snv_prior=1 / (10 ** 3), 
                 qlen_upper=params["qlen_upper_limit"], min_gq=params["min_gq"], min_bq=params["min_bq"],
                 max_mismatch_count=params["max_mismatch_count"], mismatch_window=params["mismatch_window_size"],
                 md_threshold=params["md_threshold"], min_ref_count=params["min_ref_count"],
-                min_alt_count=params["min_alt_count"], min_hap_count=params["min_hap_count"], phase=0, pad=0,
+                min_alt_count=params["min_alt_count"], min_hap_count=params["min_hap_count"],
+                phase=1 if phase is not None else 0, pad=0,
                 min_sequence_identity=params["min_sequence_identity"], min_trim=params["min_trim"])
     R = _reads_struct(batch)
     cs_ = np.array([c[0] for c in chunks], np.int32)
     ce_ = np.array([c[1] for c in chunks], np.int32)
     pon = np.zeros(0, np.uint64) if pon_keys is None else np.ascontiguousarray(pon_keys, np.uint64)
     com = np.zeros(0, np.uint64) if com_keys is None else np.ascontiguousarray(com_keys, np.uint64)
+    ph = None
+    if phase is not None:
+        arrs = pack_phase(chunks, *phase)
+        ph = _Phase(*[_ptr(a) for a in arrs])
     raw = np.frombuffer(refseq.encode("ascii") if isinstance(refseq, str) else bytes(refseq), np.uint8)
     chars, cls = tri_classes(refseq)
     K = len(chars)
@@ -303,7 +309,8 @@ def normcounts(batch, chunks, params, refseq, germline_snv_prior=1 / (10 ** 3), 
     rc = L.orc_normcounts(ctypes.byref(R), ctypes.byref(P), ctypes.byref(lut), ctypes.c_int64(len(chunks)), _ptr(cs_),
                           _ptr(ce_), _ptr(pon), ctypes.c_int64(pon.shape[0]), _ptr(com), ctypes.c_int64(com.shape[0]),
                           _ptr(raw), ctypes.c_int64(raw.shape[0]), _ptr(cls), ctypes.c_int(K), _ptr(tab),
-                          ctypes.c_int(1 if non_human_sample else 0), _ptr(ccs), _ptr(ref), log)
+                          ctypes.c_int(1 if non_human_sample else 0), ctypes.byref(ph) if ph is not None else None,
+                          _ptr(ccs), _ptr(ref), log)
     if rc:
         raise OracleError(rc)
     d_ccs, d_ref = tri_dicts(chars, ccs, ref)

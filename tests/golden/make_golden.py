@@ -135,7 +135,7 @@ def worker_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, phase_bl
 
 
 def norm_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, overrides=None, md_threshold=None,
-              qlen_limits=None, mutate_ref=None, non_human_sample=False):
+              qlen_limits=None, mutate_ref=None, non_human_sample=False, phase_block=0):
     """normcounts.get_callable_tricounts (non-phased) on a synthetic contig + its reference sequence."""
     ref = H.load_reference()
     s = synth.generate(cfg, want_ref=True)
@@ -167,9 +167,19 @@ def norm_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, overrides=
         synth.write_pon_vcf(pon, s, seed=cfg.seed, extra_sites=hits[::5])
         exp["common_set"] = sorted([list(t) for t in ref.vcflib.load_common_snp(b.name, common)])
         exp["pon_set"] = sorted([list(t) for t in ref.vcflib.load_pon(b.name, pon)])
+    phase_sets = None
+    if phase_block:
+        pv = os.path.join(tmpdir, case + ".phased.vcf")
+        synth.write_phased_vcf(pv, s, block=phase_block)
+        hb, hp, hs, c2c = ref.vcflib.load_phased_hetsnps(pv, [b.name], sizes)
+        phase_sets = (dict(hb[b.name]), dict(hp[b.name]), dict(hs[b.name]))
+        chunks = [(s_, e_) for (_, s_, e_) in c2c[b.name]]
+        exp["chunks"] = chunks
+        exp["phase_sets"] = {"hbit": phase_sets[0], "hpos": phase_sets[1],
+                             "hetsnp": {k: [list(t) for t in v] for k, v in phase_sets[2].items()}}
     ccs, rf, log, order = H.run_reference_normcounts(bam, b.name, seq, chunks, ql, qu, md, common_snps=common,
                                                      panel_of_normals=pon, non_human_sample=non_human_sample,
-                                                     **(overrides or {}))
+                                                     phase_sets=phase_sets, **(overrides or {}))
     exp["ccs_tri2count"] = {k: int(v) for k, v in ccs.items()}
     exp["ref_tri2count"] = {k: int(v) for k, v in rf.items()}
     exp["log"] = [int(x) for x in log]
@@ -456,6 +466,9 @@ def main():
                   with_sets=True, md_threshold=60,
                   overrides=dict(min_bq=40, min_gq=70, max_mismatch_count=2, mismatch_window_size=15, min_ref_count=5,
                                  min_alt_count=2, min_sequence_identity=0.95))
+    if want("norm_phase"):
+        norm_case("norm_phase", small_cfg(205, contig_len=40000, snp_rate=3e-3, som_rate=3e-4, name="chr5"),
+                  md_threshold=52, phase_block=12, with_sets=True)
     if want("norm_softmask"):
         # lower-case (soft-masked) and N stretches in the reference: skipped positions, odd trinucleotide keys
         def mask(seq):

@@ -183,7 +183,7 @@ def run_reference_worker(bam_path, chrom, chunks, qlen_lower, qlen_upper, md_thr
 
 
 def run_reference_normcounts(bam_path, chrom, seq, chunks, qlen_lower, qlen_upper, md_threshold, common_snps=None,
-                             panel_of_normals=None, non_human_sample=False, **overrides):
+                             panel_of_normals=None, non_human_sample=False, phase_sets=None, **overrides):
     """Calls the reference's normcounts worker (normcounts.py:206) without phasing.  Returns
     (ccs_tri2count, ref_tri2count, log, alt_order): alt_order[ref] = list(base_set.difference(ref)) as THIS
     interpreter orders it -- the worker's PoN/common precedence and its tie rule depend on it."""
@@ -192,11 +192,12 @@ def run_reference_normcounts(bam_path, chrom, seq, chunks, qlen_lower, qlen_uppe
     p = dict(CALL_DEFAULTS)
     p.update(overrides)
     ccs, rf, log = {}, {}, {}
+    hbit, hpos, hetsnp = phase_sets if phase_sets is not None else ({}, {}, {})
     N.get_callable_tricounts(
-        chrom, seq, bam_path, common_snps, panel_of_normals, [(chrom, s, e) for (s, e) in chunks], {}, {}, {},
+        chrom, seq, bam_path, common_snps, panel_of_normals, [(chrom, s, e) for (s, e) in chunks], hbit, hpos, hetsnp,
         p["min_qv"], p["min_mapq"], p["min_trim"], qlen_lower, qlen_upper, p["min_sequence_identity"], p["min_gq"],
         p["min_bq"], p["mismatch_window_size"], p["max_mismatch_count"], p["min_ref_count"], p["min_alt_count"],
         p["min_hap_count"], md_threshold, p["somatic_snv_prior"], p["germline_snv_prior"], p["germline_indel_prior"],
-        False, non_human_sample, ccs, rf, log)
+        phase_sets is not None, non_human_sample, ccs, rf, log)
     order = {b: list(ref.util.base_set.difference(b)) for b in "ATGC"}
     return ccs[chrom], rf[chrom], log[chrom], order

@@ -58,7 +58,7 @@ def test_cs_tuples():
                 assert (o[3], o[4]) == (t[1], t[2])
 
 
-NORM_CASES = ["norm_basic", "norm_sets", "norm_dense", "norm_softmask"]
+NORM_CASES = ["norm_basic", "norm_sets", "norm_dense", "norm_softmask", "norm_phase"]
 
 
 def load_norm_case(case):
@@ -82,7 +82,8 @@ def test_normcounts_oracle_matches_reference(case):
     from oracle import oracle as O
     batch, exp, p, refseq, pon, com = load_norm_case(case)
     ccs, rf, log = O.normcounts(batch, util.chunks_of(exp), p, refseq, p["germline_snv_prior"], pon, com,
-                                alt_order=exp["alt_order"], non_human_sample=exp["non_human_sample"])
+                                alt_order=exp["alt_order"], non_human_sample=exp["non_human_sample"],
+                                phase=util.phase_of(exp))
     assert log == exp["log"]
     assert {k: v for k, v in ccs.items() if v or k in O.TRI_LST} == \
         {k: v for k, v in exp["ccs_tri2count"].items() if v or k in O.TRI_LST}
