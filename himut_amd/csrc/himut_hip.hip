@@ -792,7 +792,10 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     if (!c->have_lut) return fail(c, HIMUT_ERR_ARG, "himut_set_gt_lut has not been called");
     if (!c->have_reads) return fail(c, HIMUT_ERR_ARG, "himut_push_reads has not been called");
     if (c->reflen <= 0) return fail(c, HIMUT_ERR_ARG, "himut_set_reference has not been called");
-    if (c->params.p.phase) return fail(c, HIMUT_ERR_ARG, "phased normcounts is not implemented");
+    const bool phase = c->params.p.phase != 0;
+    if (phase && !c->have_phase) return fail(c, HIMUT_ERR_ARG, "phase requested but himut_set_phase has not been called");
+    if (phase && (int64_t)c->h_phoff.size() != (int64_t)c->cstart.size() + 1)
+        return fail(c, HIMUT_ERR_ARG, "himut_set_phase chunk count differs from himut_set_chunks");
     for (size_t k = 0; k < c->cstart.size(); k++)
         if (c->cstart[k] > c->cend[k]) return fail(c, HIMUT_ERR_CHUNK, "ValueError: invalid coordinates: chunk start > end");
     for (int k = 0; k < 12; k++) if (alt_order[k] > 3) return fail(c, HIMUT_ERR_ARG, "alt_order holds alleles 0..3");
@@ -807,6 +810,8 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     Reads R = make_reads(c);
     Derived D = make_derived(c);
     Chunks C = make_chunks(c, T.n);
+    if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
+    Phase H = make_phase(c);
     Scalars* sc = c->d_scalars.as<Scalars>();
     const int K = c->ref_K;
     const size_t ntri = (size_t)K * K * K;
@@ -830,6 +835,11 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     if (c->n > 0 && T.n > 0) {
         hipLaunchKernelGGL(k_read_live, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, C, c->params,
                            c->d_live.as<uint8_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
+        if (phase && T.npairs > 0) {
+            hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
+            hipLaunchKernelGGL(k_pair_ccs, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, C, H, R, c->d_live.as<uint8_t>(),
+                               T.npairs, c->d_ccs.as<uint8_t>());
+        }
         hipLaunchKernelGGL(k_callable, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, c->d_live.as<uint8_t>(),
                            c->d_callable.as<uint32_t>());
         hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, R, nblk, c->d_winlo.as<int32_t>(),
@@ -857,7 +867,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     A.S.pon = c->d_pon.as<uint64_t>(); A.S.npon = c->npon; A.S.com = c->d_com.as<uint64_t>(); A.S.ncom = c->ncom;
     A.S.posbits = c->d_posbits.as<uint32_t>(); A.S.nposbits = c->nposbits;
     A.lut = c->d_lut.as<GtLut>();
-    A.R = R; A.C = C;
+    A.R = R; A.C = C; A.H = H;
     A.refseq = c->d_refseq.as<uint8_t>(); A.reflen = c->reflen;
     memcpy(A.cls, c->ref_cls, 256);
     A.K = K; A.cA = c->ref_cls['A']; A.cC = c->ref_cls['C']; A.cG = c->ref_cls['G']; A.cT = c->ref_cls['T'];

@@ -1,5 +1,5 @@
 // Device code of the normcounts sweep: himut's `normcounts.get_callable_tricounts`
-// (src/himut/normcounts.py:206-421, non-phased) on the machinery of the call path.
+// (src/himut/normcounts.py:206-421, with or without --phase) on the machinery of the call path.
 //
 // Every reference position of the chunks is a "candidate": the position bitmap is all
 // ones inside the chunks, k_stream_capture<true> transposes every (read, position) cell into
@@ -21,6 +21,16 @@ namespace himut {
 constexpr int64_t NORM_PASS = (int64_t)8 << 20;   // reference positions per pass (multiple of 256)
 
 // ---------------------------------------------------------------------------------------
+// phased runs: a read counts in a chunk only if it carries haplotype 0 or 1 there (normcounts.py:293-298)
+__global__ void __launch_bounds__(256) k_pair_ccs(Chunks C, Phase H, Reads R, const uint8_t* live, int64_t npairs,
+                                                  uint8_t* ccs_flag) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= npairs) return;
+    const int64_t c = upper_bound(C.pairoff, (int64_t)0, C.n + 1, k) - 1;
+    const int64_t r = C.rlo[c] + (k - C.pairoff[c]);
+    if (live[r] && H.hap[k] != HAP_NONE) ccs_flag[R.qid[r]] = 1;
+}
+
 __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C, Params P, uint8_t* live, uint8_t* ccs_flag,
                                                    int* err) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,7 +62,7 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
             while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (C.rec[m].start < M.tend) lo = m + 1; else hi = m; }
             ok = lo > 0 && C.rec[lo - 1].pmaxend > M.tstart;
         }
-        if (ok) { lv = 1; ccs_flag[R.qid[r]] = 1; }
+        if (ok) { lv = 1; if (!P.p.phase) ccs_flag[R.qid[r]] = 1; }
     }
     live[r] = lv;
 }
@@ -239,6 +249,7 @@ struct NormArgs {
     const GtLut* lut;
     Reads R;
     Chunks C;
+    Phase H;
     PosIndex X;
     const uint16_t* colstore;
     const uint8_t* refseq;       // the contig as the FASTA holds it
@@ -287,8 +298,10 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
         double S[3][4];
 #pragma unroll
         for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
-        uint32_t tri_sum = 0;
+        uint32_t tri_sum = 0, h0 = 0, h1 = 0;
         bool bq0 = false;
+        const bool phase = A.P.p.phase != 0;
+        const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
         // sixteen slots of the column are in flight at a time (their addresses do not depend on each other)
         for (uint32_t i0 = 0; i0 < n; i0 += 16) {
             uint32_t vv[16];
@@ -314,12 +327,22 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
                             S[2][b] = S[2][b] + ve;
                         }
                     }
-                    tri_sum += (v >> 4) & 1u;
+                    uint32_t counts_here = (v >> 4) & 1u;
+                    if (phase) {       // rpos2hap2count over match and substitution bases; only phased reads are callable
+                        const uint32_t hp = A.H.hap[pairbase + lo + (int32_t)(i0 + k)];
+                        if (hp == HAP_0) h0++; else if (hp == HAP_1) h1++; else counts_here = 0;
+                    }
+                    tri_sum += counts_here;
                 } else if (cell == CELL_DEL) cnt[5]++;
                 else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;           // normcounts.py:126
             }
         }
         if (ref < 0 || tri_sum == 0) continue;                                  // normcounts.py:318-321
+        if (phase && !((int64_t)h0 >= A.P.p.min_hap_count && (int64_t)h1 >= A.P.p.min_hap_count)) {
+            atomicAdd(&s_log[1], tri_sum);                                      // is_rpos_phased (normcounts.py:198-205,324-328)
+            atomicAdd(&s_log[2], tri_sum);
+            continue;
+        }
         if (bq0) { bad |= 1 << HIMUT_ERR_BQ0; continue; }
         int slot = 1;   // which counter takes tri_sum besides num_bases; 13 = callable
         // get_germ_gt (gtlib.py:72-135)

@@ -1,5 +1,5 @@
 """Host side of the normcounts sweep: mirror of ``himut.normcounts.get_callable_tricounts``
-(src/himut/normcounts.py:206-421, non-phased) in front of libhimut_hip.so.
+(src/himut/normcounts.py:206-421) in front of libhimut_hip.so.
 
 The device returns two histograms over class triples and 14 counters; this module builds
 the byte -> class table from the contig's reference string, supplies the order python gives
@@ -50,14 +50,19 @@ def tri_dicts(chars, ccs, ref):
     return d_ccs, d_ref
 
 
-def norm_contig(worker, batch, chunks, refseq, pon_keys=None, common_keys=None, non_human_sample=False, alt_order=None):
-    """Runs the sweep on one contig through a configured caller.Worker; returns (ccs dict, ref dict, log[14])."""
+def norm_contig(worker, batch, chunks, refseq, pon_keys=None, common_keys=None, non_human_sample=False, alt_order=None,
+                phase_sets=None):
+    """Runs the sweep on one contig through a configured caller.Worker; returns (ccs dict, ref dict, log[14]).
+    phase_sets = (hbit, hpos, hetsnp) dicts of the contig when the worker was configured with phase=True."""
+    from .caller import pack_phase_sets
     ctx = worker.ctx
     chars, cls = tri_classes(refseq)
     ctx.set_chunks(chunks)
     ctx.set_site_set(0, pon_keys if pon_keys is not None else np.zeros(0, np.uint64))
     ctx.set_site_set(1, common_keys if common_keys is not None else np.zeros(0, np.uint64))
     ctx.set_reference(refseq, cls, len(chars))
+    if phase_sets is not None:
+        ctx.set_phase(*pack_phase_sets(chunks, *phase_sets))
     ctx.push_reads(batch)
     ctx.run_normcounts(alt_order_table(alt_order), non_human_sample)
     ccs, ref, log = ctx.normcounts()
@@ -73,10 +78,8 @@ def get_callable_tricounts(
     chrom2ccs_callable_tri2count, chrom2ref_callable_tri2count, chrom2norm_log, device=0, read_batch=None,
 ):
     """Drop-in for himut.normcounts.get_callable_tricounts (normcounts.py:206): same arguments, same three
-    assignments.  ``phase=True`` is not implemented on the device yet."""
+    assignments."""
     from . import vcflib
-    if phase:
-        raise NotImplementedError("phased normcounts is not part of the accelerated path yet")
     pon_keys = com_keys = None
     if common_snps is not None and common_snps.endswith(".vcf"):              # normcounts.py:251-253
         com_keys = site_keys(vcflib.load_common_snp(chrom, common_snps))
@@ -88,9 +91,10 @@ def get_callable_tricounts(
     w = _worker_for(device)
     w.configure(min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
                 max_mismatch_count, mismatch_window, md_threshold, min_ref_count, min_alt_count, min_hap_count,
-                germline_snv_prior, False)
+                germline_snv_prior, phase)
     chunks = [(int(s), int(e)) for (_c, s, e) in chunkloci_lst]
-    ccs, ref, log = norm_contig(w, read_batch, chunks, seq, pon_keys, com_keys, non_human_sample)
+    phase_sets = (phase_set2hbit_lst, phase_set2hpos_lst, phase_set2hetsnp_lst) if phase else None
+    ccs, ref, log = norm_contig(w, read_batch, chunks, seq, pon_keys, com_keys, non_human_sample, phase_sets=phase_sets)
     chrom2ccs_callable_tri2count[chrom] = ccs
     chrom2ref_callable_tri2count[chrom] = ref
     chrom2norm_log[chrom] = log

@@ -181,9 +181,9 @@ int himut_get_stats(himut_ctx* ctx, himut_run_stats* out);
 int himut_records_device(himut_ctx* ctx, const void** dev_ptr, int64_t* n);
 int himut_copy_records_to_device(himut_ctx* ctx, void* dst_device, int64_t capacity_records);
 
-/* ---- next row: normcounts.get_callable_tricounts, non-phased ------------------
+/* ---- next row: normcounts.get_callable_tricounts ---------------------------------
  * The worker's arguments (normcounts.py:206-241) map onto the same calls as the call path
- * (params, LUT, chunks, site sets, reads) plus the contig's reference string:
+ * (params, LUT, chunks, site sets, phase sets, reads) plus the contig's reference string:
  *   seq (str(refseq[chrom]), normcounts.py:504)          himut_set_reference
  *   the body of the worker (normcounts.py:243-402)       himut_run_normcounts
  *   chrom2{ccs,ref}_callable_tri2count, chrom2norm_log   himut_get_normcounts
