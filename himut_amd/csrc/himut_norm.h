@@ -298,17 +298,19 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
         double S[3][4];
 #pragma unroll
         for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
+        double R0 = 0.0, R1 = 0.0, R2 = 0.0;     // the three sums of the reference allele
+        uint32_t nref = 0;
         uint32_t tri_sum = 0, h0 = 0, h1 = 0;
         bool bq0 = false;
         const bool phase = A.P.p.phase != 0;
         const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
-        // sixteen slots of the column are in flight at a time (their addresses do not depend on each other)
-        for (uint32_t i0 = 0; i0 < n; i0 += 16) {
-            uint32_t vv[16];
+        // eight slots of the column are in flight at a time (their addresses do not depend on each other)
+        for (uint32_t i0 = 0; i0 < n; i0 += 8) {
+            uint32_t vv[8];
 #pragma unroll
-            for (int k = 0; k < 16; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
+            for (int k = 0; k < 8; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < 8; k++) {
                 const uint32_t v = vv[k];
                 const uint32_t cell = v & 7u;
                 if ((v & 15u) == CELL_EMPTY) continue;
@@ -318,13 +320,18 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
                     const uint32_t q = v >> 8;
                     if (q == 0) bq0 = true;
                     const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q];
+                    if ((int)cell == ref) {            // nearly every cell: the reference allele has registers of its own
+                        nref++;
+                        R0 = R0 + vh; R1 = R1 + vt; R2 = R2 + ve;
+                    } else {
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        if ((int)cell == b) {
-                            cnt[b]++;
-                            S[0][b] = S[0][b] + vh;
-                            S[1][b] = S[1][b] + vt;
-                            S[2][b] = S[2][b] + ve;
+                        for (int b = 0; b < 4; b++) {
+                            if ((int)cell == b) {
+                                cnt[b]++;
+                                S[0][b] = S[0][b] + vh;
+                                S[1][b] = S[1][b] + vt;
+                                S[2][b] = S[2][b] + ve;
+                            }
                         }
                     }
                     uint32_t counts_here = (v >> 4) & 1u;
@@ -338,6 +345,8 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
             }
         }
         if (ref < 0 || tri_sum == 0) continue;                                  // normcounts.py:318-321
+#pragma unroll
+        for (int b = 0; b < 4; b++) if (b == ref) { cnt[b] = nref; S[0][b] = R0; S[1][b] = R1; S[2][b] = R2; }
         if (phase && !((int64_t)h0 >= A.P.p.min_hap_count && (int64_t)h1 >= A.P.p.min_hap_count)) {
             atomicAdd(&s_log[1], tri_sum);                                      // is_rpos_phased (normcounts.py:198-205,324-328)
             atomicAdd(&s_log[2], tri_sum);
