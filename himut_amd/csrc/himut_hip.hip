@@ -58,7 +58,7 @@ void upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
 template <class T>
 void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) { upload(b, v.data(), v.size(), st); }
 
-enum { EV_START = 0, EV_FORK, EV_BQ0, EV_BQ1, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
+enum { EV_START = 0, EV_FORK, EV_BQ0, EV_BQ1, EV_SIDE, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
 
 }  // namespace
 
@@ -309,7 +309,9 @@ int check_device_err(himut_ctx* c, int bits) {
     return fail(c, HIMUT_ERR_ARG, "device error");
 }
 
-void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {
+// side_work: more work for the second stream, done behind the quality sum while the cs decode still runs
+template <class F>
+void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, F side_work) {
     hipStream_t st = c->stream;
     // the quality stream (HBM bound) overlaps the cs decode (VALU bound)
     HCHECK(hipEventRecord(c->ev[EV_FORK], st));
@@ -317,11 +319,16 @@ void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc
     HCHECK(hipEventRecord(c->ev[EV_BQ0], c->side));
     hipLaunchKernelGGL(k_bq_sum, dim3(blocks_for(c->n, 4)), dim3(256), 0, c->side, R, D.bqsum);
     HCHECK(hipEventRecord(c->ev[EV_BQ1], c->side));
+    side_work(c->side);
+    HCHECK(hipEventRecord(c->ev[EV_SIDE], c->side));
     hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
     if (c->any_longcs)
         hipLaunchKernelGGL(k_check_longcs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, &sc->err);
-    HCHECK(hipStreamWaitEvent(st, c->ev[EV_BQ1], 0));
+    HCHECK(hipStreamWaitEvent(st, c->ev[EV_SIDE], 0));
     HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+}
+void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {
+    run_parse_stage(c, R, D, sc, [](hipStream_t) {});
 }
 
 void alloc_derived(himut_ctx* c) {
@@ -377,10 +384,24 @@ int do_run(himut_ctx* c) {
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
-    HCHECK(hipMemsetAsync(c->d_mask.p, 0, mask_bytes, st));
     HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
-    if (c->n > 0) run_parse_stage(c, R, D, sc);
-    else HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+    // window index for the column kernel, and the empty mask: neither needs the cs decode, so both
+    // run behind the quality sum on the second stream
+    int32_t maxend = 0;
+    for (int32_t e : c->cend) maxend = std::max(maxend, e);
+    const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
+    c->d_winlo.reserve((size_t)nblk * 4 + 64);
+    c->d_winhi.reserve((size_t)nblk * 4 + 64);
+    if (c->n > 0)
+        run_parse_stage(c, R, D, sc, [&](hipStream_t side) {
+            HCHECK(hipMemsetAsync(c->d_mask.p, 0, mask_bytes, side));
+            hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, side, R, nblk,
+                               c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>());
+        });
+    else {
+        HCHECK(hipMemsetAsync(c->d_mask.p, 0, mask_bytes, st));
+        HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+    }
     if (phase && T.npairs > 0)
         hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
     HCHECK(hipEventRecord(c->ev[EV_HAP], st));
@@ -400,15 +421,6 @@ int do_run(himut_ctx* c) {
         HCHECK(hipMemcpyAsync(&last_tcnt, c->d_tilecnt.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
         HCHECK(hipMemcpyAsync(&last_toff, c->d_tileoff2.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
     }
-    // window index for the column kernel
-    int32_t maxend = 0;
-    for (int32_t e : c->cend) maxend = std::max(maxend, e);
-    const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
-    c->d_winlo.reserve((size_t)nblk * 4 + 64);
-    c->d_winhi.reserve((size_t)nblk * 4 + 64);
-    if (c->n > 0)
-        hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, R, nblk, c->d_winlo.as<int32_t>(),
-                           c->d_winhi.as<int32_t>());
     HCHECK(hipEventRecord(c->ev[EV_EMIT], st));
 
     // exact number of candidate evaluations -> record capacity
