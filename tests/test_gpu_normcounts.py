@@ -84,3 +84,37 @@ def test_normcounts_phase_oracle_parity(worker, tmp_path):
     assert log == o_log
     assert ccs == o_ccs and rf == o_ref
     assert log[2] > 0 and log[13] > 0
+
+
+def test_normcounts_full_size_properties_and_prefix_parity(worker):
+    """BASELINE configs[1] size (chr20-sized contig, 30x): the counters must add up (every counted base lands in
+    exactly one class) and the first chunks must match the oracle run on the reads under them."""
+    from oracle import oracle as O
+    from himut_amd import bamlib, normcounts, synth, util as hutil
+    from himut_amd.readbatch import ReadBatch
+    L = 64_444_167
+    s = synth.generate(synth.SynthConfig(seed=2, contig_len=L, name="chr20"), want_ref=True)
+    b = s.batch
+    refseq = bytes(s.ref)
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((b.name, 0, b.length))]
+    ql, qu, md = bamlib.get_thresholds({b.name: b}, [b.name], {b.name: b.length})
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=ql, qlen_upper_limit=qu, md_threshold=md)
+    _configure(worker, p)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+    ccs, rf, log = normcounts.norm_contig(worker, b, chunks, refseq, alt_order=order)
+    assert log[1] == log[2] + log[3] + log[4] + log[5] + log[6]
+    assert log[6] == sum(log[7:14])
+    assert sum(ccs.values()) == log[13] and log[13] > 1_000_000_000
+    assert sorted(ccs) == sorted(O.TRI_LST) and all(v > 0 for v in rf.values())
+    # prefix parity: 12 chunks (2.4 Mb); the counters and dicts of a prefix are those of the oracle on the reads under it
+    nch = 12
+    end = chunks[nch - 1][1]
+    n = int(np.searchsorted(b.tstart, end, side="left"))
+    tot = int(b.qoff[n - 1] + ((int(b.qlen[n - 1]) + 31) & ~31))
+    sub = ReadBatch(name=b.name, length=b.length, tstart=b.tstart[:n], tend=b.tend[:n], qstart=b.qstart[:n],
+                    qlen=b.qlen[:n], mapq=b.mapq[:n], flag=b.flag[:n], qid=b.qid[:n], qoff=b.qoff[:n],
+                    cs_off=b.cs_off[:n + 1], seq=b.seq[:tot // 2], bq=b.bq[:tot], cs=b.cs[:int(b.cs_off[n])], tp=b.tp[:n])
+    o_ccs, o_ref, o_log = O.normcounts(sub, chunks[:nch], p, refseq, p["germline_snv_prior"], alt_order=order)
+    h_ccs, h_ref, h_log = normcounts.norm_contig(worker, sub, chunks[:nch], refseq, alt_order=order)
+    assert h_log == o_log and h_ccs == o_ccs and h_ref == o_ref
