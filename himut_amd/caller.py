@@ -142,8 +142,12 @@ def get_somatic_substitutions(
     human = not non_human_sample and not create_panel_of_normals
     if common_snps is not None and human and common_snps.endswith(".vcf"):          # caller.py:248-254
         com_keys = site_keys(vcflib.load_common_snp(chrom, common_snps))
+    elif common_snps is not None and human and common_snps.endswith(".bgz"):        # caller.py:269-278
+        com_keys = site_keys(vcflib.load_bgz_common_snp(chrom, common_snps))
     if panel_of_normals is not None and human and panel_of_normals.endswith(".vcf"):  # caller.py:256-262
         pon_keys = site_keys(vcflib.load_pon(chrom, panel_of_normals))
+    elif panel_of_normals is not None and human and panel_of_normals.endswith(".bgz"):  # caller.py:280-289
+        pon_keys = site_keys(vcflib.load_bgz_pon(chrom, panel_of_normals))
     if read_batch is None:
         from . import bamio
         read_batch = bamio.read_contig(bam_file, chrom)

@@ -83,8 +83,12 @@ def get_callable_tricounts(
     pon_keys = com_keys = None
     if common_snps is not None and common_snps.endswith(".vcf"):              # normcounts.py:251-253
         com_keys = site_keys(vcflib.load_common_snp(chrom, common_snps))
+    elif common_snps is not None and common_snps.endswith(".bgz"):            # normcounts.py:262-271
+        com_keys = site_keys(vcflib.load_bgz_common_snp(chrom, common_snps))
     if panel_of_normals is not None and panel_of_normals.endswith(".vcf"):    # normcounts.py:255-257
         pon_keys = site_keys(vcflib.load_pon(chrom, panel_of_normals))
+    elif panel_of_normals is not None and panel_of_normals.endswith(".bgz"):  # normcounts.py:273-282
+        pon_keys = site_keys(vcflib.load_bgz_pon(chrom, panel_of_normals))
     if read_batch is None:
         from . import bamio
         read_batch = bamio.read_contig(bam_file, chrom)

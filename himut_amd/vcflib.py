@@ -61,6 +61,42 @@ def load_pon(chrom, vcf_file):
     return out
 
 
+def _bgz_lines(path, chrom):
+    """Data lines of a bgzip-compressed VCF on ``chrom``.  A BGZF file is a series of gzip members, so python's
+    gzip reads it; the reference goes through a tabix index (vcflib.py:381,417,449), which only selects the same
+    lines faster.  The region arguments of the reference's per-chunk queries (chunk +- qlen_upper_limit,
+    caller.py:269-289) always contain the chunk, so one pass per contig gives the same membership answers."""
+    import gzip
+    with gzip.open(path, "rt") as fh:
+        for line in fh:
+            if line.startswith("#"):
+                continue
+            if line.split("\t", 1)[0] == chrom:
+                yield line
+
+
+def load_bgz_pon(chrom, vcf_file):
+    """.bgz panel of normals on ``chrom`` (vcflib.py:412-423)."""
+    out = set()
+    for line in _bgz_lines(vcf_file, chrom):
+        v = VcfRecord(line)
+        if v.is_snp and v.is_pass:
+            out.add((v.pos, v.ref, v.alt))
+    return out
+
+
+def load_bgz_common_snp(chrom, vcf_file):
+    """.bgz common SNPs on ``chrom`` -- the tabix variant queries the RIGHT contig, unlike load_common_snp
+    (vcflib.py:443-459)."""
+    out = set()
+    for line in _bgz_lines(vcf_file, chrom):
+        f = line.strip().split("\t")
+        alts = f[4].split(",")
+        if f[6] == "PASS" and len(alts) == 1 and len(f[3]) == 1 and len(alts[0]) == 1:
+            out.add((int(f[1]), f[3], alts[0]))
+    return out
+
+
 def load_common_snp(chrom, vcf_file):
     """(pos, ref, alt) of PASS bi-allelic SNVs -- from the OTHER contigs
     (vcflib.py:426-440: ``if chrom != arr[0] and ...``)."""

@@ -110,3 +110,38 @@ def test_thresholds_match_reference():
         b = synth.generate(cfg).batch
         got = bamlib.get_thresholds({"chr9": b}, ["chr9"], {"chr9": cfg.contig_len})
         assert got == (c["qlen_lower_limit"], c["qlen_upper_limit"], c["md_threshold"])
+
+
+def test_bgz_side_vcf_loaders(tmp_path):
+    """.bgz side files (BGZF = a series of gzip members): the loaders read them without a tabix index and, as the
+    reference's tabix variants do, on the contig itself -- so the common-SNP set differs from the plain .vcf one."""
+    import gzip
+    from himut_amd import vcflib
+    exp = util.load_json("worker_sets")
+    common = tmp_path / "c.vcf"
+    pon = tmp_path / "p.vcf"
+    common.write_text(exp["common_vcf"])
+    pon.write_text(exp["pon_vcf"])
+
+    def bgz(src, dst):
+        # two gzip members, like two BGZF blocks
+        data = open(src, "rb").read()
+        half = data.rfind(b"\n", 0, len(data) // 2) + 1
+        with open(dst, "wb") as o:
+            o.write(gzip.compress(data[:half]))
+            o.write(gzip.compress(data[half:]))
+
+    bgz(common, tmp_path / "c.vcf.bgz")
+    bgz(pon, tmp_path / "p.vcf.bgz")
+    chrom = exp["contig"]
+    assert vcflib.load_bgz_pon(chrom, str(tmp_path / "p.vcf.bgz")) == vcflib.load_pon(chrom, str(pon))
+    got = vcflib.load_bgz_common_snp(chrom, str(tmp_path / "c.vcf.bgz"))
+    # same filter as the plain loader, but on this contig instead of on every other one
+    want = set()
+    for line in exp["common_vcf"].splitlines():
+        if line.startswith("#"):
+            continue
+        f = line.split()
+        if f[0] == chrom and f[6] == "PASS" and "," not in f[4] and len(f[3]) == 1 and len(f[4]) == 1:
+            want.add((int(f[1]), f[3], f[4]))
+    assert got == want and len(got) > 0
