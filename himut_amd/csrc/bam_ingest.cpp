@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <future>
 #include <thread>
 
@@ -222,6 +223,30 @@ struct Bgzf {
     }
 };
 
+// growable byte buffer that does not zero what it grows by
+struct RawBuf {
+    uint8_t* p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf&) = delete;
+    RawBuf& operator=(const RawBuf&) = delete;
+    RawBuf(RawBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ~RawBuf() { free(p); }
+    bool grow(size_t want) {
+        if (want > cap) {
+            size_t nc = cap ? cap : 4096;
+            while (nc < want) nc += nc / 2 + 4096;
+            uint8_t* q = (uint8_t*)realloc(p, nc);
+            if (!q) return false;
+            p = q; cap = nc;
+        }
+        n = want;
+        return true;
+    }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+};
+
 struct Contig {
     std::string name;
     int64_t length = 0;
@@ -229,9 +254,9 @@ struct Contig {
     std::vector<uint8_t> mapq, tp;
     std::vector<uint16_t> flag;
     std::vector<int64_t> qoff, cs_off;
-    std::vector<uint8_t> seq, bq, cs;
+    RawBuf seq, bq, cs;
     std::unordered_map<std::string, int32_t> first_by_name;
-    int64_t bases_padded = 0;
+    int64_t bases_padded = 0, cs_n = 0;
 };
 
 struct Bam {
@@ -354,25 +379,33 @@ void* bam_load_threads(const char* path, int threads) {
         B->contigs[i].name = nm;
         B->contigs[i].length = le32(b4);
     }
-    std::vector<uint8_t> scratch;
-    for (;;) {
-        if (!z.read(b4, 4)) { if (z.eof && z.err.empty()) break; return fail(z.err); }
-        const uint32_t bs = le32(b4);
-        if (bs < 32) return fail("BAM record too short");
-        const uint8_t* rec = z.view(bs, scratch);
-        if (!rec) return fail(z.err.empty() ? "truncated BAM record" : z.err);
-        const int32_t ref_id = (int32_t)le32(&rec[0]);
-        const int32_t pos = (int32_t)le32(&rec[4]);
-        const uint8_t l_read_name = rec[8];
-        const uint8_t mapq = rec[9];
+    // Records are parsed a window at a time: the record boundaries of the window are found by hopping from
+    // length field to length field, the records are decoded by the pool (CIGAR walk, tag scan), a short
+    // sequential pass assigns every kept record its place in its contig's arrays, and the pool copies the bytes.
+    struct RecInfo {
+        const uint8_t* rec; uint32_t bs;
+        int32_t ref_id, pos, lead_clip; int64_t ref_len;
+        uint32_t l_seq, cs_len; uint16_t flag; uint8_t mapq, tp, l_qname, status;   // status: 0 keep, 1 unmapped, 2 no cs
+        const uint8_t *seq, *qual, *cs; const char* qname;
+        int64_t dst_bases, dst_cs; Contig* C;
+    };
+    std::string perr;
+    auto decode = [&](RecInfo& I) -> bool {
+        const uint8_t* rec = I.rec;
+        const uint32_t bs = I.bs;
+        I.ref_id = (int32_t)le32(&rec[0]);
+        I.pos = (int32_t)le32(&rec[4]);
+        I.l_qname = rec[8];
+        I.mapq = rec[9];
         const uint16_t n_cigar = le16(&rec[12]);
-        const uint16_t flag = le16(&rec[14]);
-        const uint32_t l_seq = le32(&rec[16]);
-        if (ref_id < 0 || (uint32_t)ref_id >= n_ref || (flag & 4)) { B->n_unmapped++; continue; }
+        I.flag = le16(&rec[14]);
+        I.l_seq = le32(&rec[16]);
+        I.status = 0;
+        if (I.ref_id < 0 || (uint32_t)I.ref_id >= n_ref || (I.flag & 4)) { I.status = 1; return true; }
         size_t o = 32;
-        if (o + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq > bs) return fail("BAM record fields exceed block");
-        const char* qname = (const char*)&rec[o];
-        o += l_read_name;
+        if (o + I.l_qname + 4ull * n_cigar + (I.l_seq + 1) / 2 + I.l_seq > bs) return false;
+        I.qname = (const char*)&rec[o];
+        o += I.l_qname;
         int64_t ref_len = 0;
         int32_t lead_clip = 0;
         bool seen_query = false;
@@ -383,38 +416,107 @@ void* bam_load_threads(const char* path, int threads) {
             if (op == 4 && !seen_query) lead_clip += (int32_t)ln;                   // leading S
             if (op == 0 || op == 1 || op == 7 || op == 8) seen_query = true;        // M I = X
         }
+        I.ref_len = ref_len; I.lead_clip = lead_clip;
         o += 4ull * n_cigar;
-        const uint8_t* seq = &rec[o];
-        o += (l_seq + 1) / 2;
-        const uint8_t* qual = &rec[o];
-        o += l_seq;
-        const uint8_t* cs; size_t cs_len; uint8_t tp;
-        if (!scan_tags(&rec[o], rec + bs, &cs, &cs_len, &tp)) return fail("malformed auxiliary data");
-        if (!cs) { B->n_missing_cs++; continue; }
-        Contig& C = B->contigs[(size_t)ref_id];
-        if (!C.tstart.empty() && pos < C.tstart.back()) B->n_unsorted++;
+        I.seq = &rec[o];
+        o += (I.l_seq + 1) / 2;
+        I.qual = &rec[o];
+        o += I.l_seq;
+        size_t cs_len = 0;
+        if (!scan_tags(&rec[o], rec + bs, &I.cs, &cs_len, &I.tp)) return false;
+        I.cs_len = (uint32_t)cs_len;
+        if (!I.cs) I.status = 2;
+        return true;
+    };
+    auto place = [&](RecInfo& I) {          // sequential: order matters
+        if (I.status == 1) { B->n_unmapped++; return; }
+        if (I.status == 2) { B->n_missing_cs++; return; }
+        Contig& C = B->contigs[(size_t)I.ref_id];
+        if (!C.tstart.empty() && I.pos < C.tstart.back()) B->n_unsorted++;
         const int32_t idx = (int32_t)C.tstart.size();
-        C.tstart.push_back(pos);
-        C.tend.push_back((int32_t)(pos + ref_len));
-        C.qstart.push_back(lead_clip);
-        C.qlen.push_back((int32_t)l_seq);
-        C.mapq.push_back(mapq);
-        C.flag.push_back(flag);
-        C.tp.push_back(tp);
-        auto it = C.first_by_name.emplace(std::string(qname), idx);
+        C.tstart.push_back(I.pos);
+        C.tend.push_back((int32_t)(I.pos + I.ref_len));
+        C.qstart.push_back(I.lead_clip);
+        C.qlen.push_back((int32_t)I.l_seq);
+        C.mapq.push_back(I.mapq);
+        C.flag.push_back(I.flag);
+        C.tp.push_back(I.tp);
+        auto it = C.first_by_name.emplace(std::string(I.qname), idx);
         C.qid.push_back(it.first->second);
         C.qoff.push_back(C.bases_padded);
-        const int64_t padded = ((int64_t)l_seq + 31) & ~(int64_t)31;
-        C.seq.insert(C.seq.end(), seq, seq + (l_seq + 1) / 2);
-        if (l_seq & 1) C.seq.back() &= 0xf0;
-        C.seq.resize((size_t)((C.bases_padded + padded) / 2), 0);     // pad to the 32-base boundary
-        C.bq.insert(C.bq.end(), qual, qual + l_seq);
-        C.bq.resize((size_t)(C.bases_padded + padded), 0);
-        C.bases_padded += padded;
-        C.cs_off.push_back((int64_t)C.cs.size());
-        C.cs.insert(C.cs.end(), cs, cs + cs_len);
+        I.C = &C; I.dst_bases = C.bases_padded; I.dst_cs = C.cs_n;
+        C.bases_padded += ((int64_t)I.l_seq + 31) & ~(int64_t)31;
+        C.cs_off.push_back(C.cs_n);
+        C.cs_n += I.cs_len;
+    };
+    auto copy_bytes = [&](const RecInfo& I) {
+        if (I.status) return;
+        Contig& C = *I.C;
+        const int64_t padded = ((int64_t)I.l_seq + 31) & ~(int64_t)31;
+        uint8_t* sq = C.seq.p + I.dst_bases / 2;
+        const size_t nsq = (I.l_seq + 1) / 2;
+        memcpy(sq, I.seq, nsq);
+        if (I.l_seq & 1) sq[nsq - 1] &= 0xf0;
+        memset(sq + nsq, 0, (size_t)(padded / 2) - nsq);               // pad to the 32-base boundary
+        uint8_t* bq = C.bq.p + I.dst_bases;
+        memcpy(bq, I.qual, I.l_seq);
+        memset(bq + I.l_seq, 0, (size_t)padded - I.l_seq);
+        if (I.cs_len) memcpy(C.cs.p + I.dst_cs, I.cs, I.cs_len);
+    };
+    auto run_pool = [&](size_t count, const std::function<void(size_t)>& f) {
+        const int nt = (int)std::min<size_t>((size_t)z.threads, count / 64 + 1);
+        if (nt <= 1) { for (size_t k = 0; k < count; k++) f(k); return; }
+        std::atomic<size_t> next(0);
+        auto work = [&]() { for (;;) { const size_t k0 = next.fetch_add(64); if (k0 >= count) break; for (size_t k = k0; k < std::min(count, k0 + 64); k++) f(k); } };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    };
+    auto finish_batch = [&](std::vector<RecInfo>& recs) -> bool {
+        std::atomic<int> bad(0);
+        run_pool(recs.size(), [&](size_t k) { if (!decode(recs[k])) bad = 1; });
+        if (bad) { perr = "malformed BAM record"; return false; }
+        for (auto& I : recs) place(I);
+        for (auto& C : B->contigs)
+            if (!C.seq.grow((size_t)(C.bases_padded / 2)) || !C.bq.grow((size_t)C.bases_padded) || !C.cs.grow((size_t)C.cs_n)) {
+                perr = "out of memory"; return false;
+            }
+        run_pool(recs.size(), [&](size_t k) { copy_bytes(recs[k]); });
+        recs.clear();
+        return true;
+    };
+    std::vector<uint8_t> scratch;
+    std::vector<RecInfo> recs;
+    for (;;) {
+        // whole records inside the current window
+        if (z.pos == z.len && !z.next_window()) { if (z.eof && z.err.empty()) break; return fail(z.err); }
+        const uint8_t* wbuf = z.buf[z.cur & 1].data();
+        while (z.pos + 4 <= z.len) {
+            const uint32_t bs = le32(wbuf + z.pos);
+            if (bs < 32) return fail("BAM record too short");
+            if (z.pos + 4 + (size_t)bs > z.len) break;
+            RecInfo I;
+            memset(&I, 0, sizeof(I));
+            I.rec = wbuf + z.pos + 4; I.bs = bs;
+            recs.push_back(I);
+            z.pos += 4 + (size_t)bs;
+        }
+        if (!finish_batch(recs)) return fail(perr);
+        if (z.pos == z.len) continue;
+        // a record that runs into the next window: assembled in scratch, handled on its own
+        if (!z.read(b4, 4)) { if (z.eof && z.err.empty()) break; return fail(z.err); }
+        const uint32_t bs = le32(b4);
+        if (bs < 32) return fail("BAM record too short");
+        const uint8_t* rec = z.view(bs, scratch);
+        if (!rec) return fail(z.err.empty() ? "truncated BAM record" : z.err);
+        RecInfo I;
+        memset(&I, 0, sizeof(I));
+        I.rec = rec; I.bs = bs;
+        recs.push_back(I);
+        if (!finish_batch(recs)) return fail(perr);
     }
-    for (auto& C : B->contigs) { C.cs_off.push_back((int64_t)C.cs.size()); C.first_by_name.clear(); }
+    for (auto& C : B->contigs) { C.cs_off.push_back(C.cs_n); C.first_by_name.clear(); }
     z.close();
     return B;
 }
