@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""``python -m himut_amd call ...`` -- the `himut call` entry point (reference:
-src/himut/__main__.py:15-49)."""
+"""``python -m himut_amd call ...`` / ``normcounts ...`` -- the `himut call` and `himut normcounts` entry
+points (reference: src/himut/__main__.py:15-49,115-146)."""
 __version__ = "1.0.4+mi355x"
 
 from himut_amd.parse_args import parse_args
@@ -18,6 +18,16 @@ def main(arguments=None):
             options.germline_snv_prior, options.germline_indel_prior, options.threads, options.phase,
             options.non_human_sample, options.reference_sample, options.create_panel_of_normal, __version__,
             options.output, devices=[int(d) for d in options.devices.split(",") if d != ""])
+    elif options.sub == "normcounts":
+        from himut_amd import normcounts
+        normcounts.get_normcounts(
+            options.bam, options.ref, options.sbs, options.vcf, options.phased_vcf, options.common_snps,
+            options.panel_of_normals, options.region, options.region_list, options.min_qv, options.min_mapq,
+            options.min_sequence_identity, options.min_gq, options.min_bq, options.min_trim, options.mismatch_window,
+            options.max_mismatch_count, options.min_ref_count, options.min_alt_count, options.min_hap_count,
+            options.somatic_snv_prior, options.germline_snv_prior, options.germline_indel_prior, options.threads,
+            options.phase, options.non_human_sample, options.reference_sample, options.output,
+            devices=[int(d) for d in options.devices.split(",") if d != ""])
     else:
         parser.print_help()
 

@@ -102,3 +102,228 @@ def get_callable_tricounts(
     chrom2ccs_callable_tri2count[chrom] = ccs
     chrom2ref_callable_tri2count[chrom] = ref
     chrom2norm_log[chrom] = log
+
+
+# ---------------------------------------------------------------------------------------------
+# The rest of `himut normcounts` (host side): inputs around the worker and the output table.
+# Mirrors, in order of use: vcflib.get_thresholds (vcflib.py:666-700), mutlib.load_sbs96_counts /
+# get_sbs96 (mutlib.py:1998-2102), reflib.get_chrom_tricount / get_genome_tricounts (reflib.py:11-61),
+# mutlib.get_normcounts_cmdline (:2396-2479), dump_normcounts (:2482-2539), dump_norm_log (:2605-2640).
+
+SUB_LST = ["C>A", "C>G", "C>T", "T>A", "T>C", "T>G"]                                    # mutlib.py:14
+SBS96_LST = ["{}[{}]{}".format(f, sub, l) for f in "ACGT" for sub in SUB_LST for l in "ACGT"]   # mutlib.py:52-149
+PURINE = set("AG")
+PUR2PYR = {"A": "T", "T": "A", "G": "C", "C": "G", "N": "N"}                            # mutlib.py:15
+NORM_LOG_ROWS = ["num_ccs", "num_bases", "num_unphased_bases", "num_het_bases", "num_hetalt_bases",
+                 "num_homalt_bases", "num_homref_bases", "num_uncallable_bases", "num_md_filtered_bases",
+                 "num_ab_filtered_bases", "num_low_gq_bases", "num_pon_filtered_bases", "num_pop_filtered_bases",
+                 "num_callable_bases"]
+
+
+def read_fasta(path):
+    """name -> sequence exactly as the file spells it (pyfastx keeps the case; so does the worker)."""
+    seqs, name, parts = {}, None, []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith(">"):
+                if name is not None:
+                    seqs[name] = "".join(parts)
+                name, parts = line[1:].split()[0], []
+            else:
+                parts.append(line.strip())
+    if name is not None:
+        seqs[name] = "".join(parts)
+    return seqs
+
+
+def get_thresholds(sbs_file):
+    """qlen_lower_limit, qlen_upper_limit, md_threshold from the header `himut call` wrote."""
+    if not sbs_file.endswith(".vcf"):
+        raise ValueError("only plain .vcf SBS files are supported")
+    opts, md = {}, None
+    for line in open(sbs_file):
+        if line.startswith("##FILTER=<ID=HighDepth"):
+            md = line.strip().split()[-1].replace('">', "")
+        elif line.startswith("##himut_command"):
+            arr = line.strip().replace("##himut_command=himut call", "").split()
+            key = None
+            for i, tok in enumerate(arr):       # alternating option / value, flags have no value
+                if i % 2 == 0:
+                    key = tok
+                elif not tok.startswith("--"):
+                    opts[key] = tok
+        elif line.startswith("#CHROM"):
+            break
+    return int(opts["--qlen_lower_limit"]), int(opts["--qlen_upper_limit"]), float(md)
+
+
+def get_sbs96(chrom, pos, ref, alt, refseq):
+    """pos 0-based; purine references are reported on the other strand."""
+    seq = refseq[chrom]
+    if ref in PURINE:
+        return "{}[{}>{}]{}".format(PUR2PYR.get(seq[pos + 1], "N"), PUR2PYR.get(ref, "N"), PUR2PYR.get(alt, "N"),
+                                    PUR2PYR.get(seq[pos - 1], "N"))
+    return "{}[{}>{}]{}".format(seq[pos - 1], ref, alt, seq[pos + 1])
+
+
+def load_sbs96_counts(vcf_file, refseq, chrom_lst):
+    """SBS96 counts of the PASS bi-allelic SNVs of ``chrom_lst``; classes that contain an N are dropped."""
+    from .vcflib import VcfRecord
+    if not vcf_file.endswith(".vcf"):
+        raise ValueError("only plain .vcf SBS files are supported")
+    per_chrom = {}
+    contigs = []
+    for line in open(vcf_file):
+        if line.startswith("##"):
+            if line.startswith("##contig"):
+                contigs.append(line.strip().replace("##contig=<ID=", "").split(",")[0])
+            continue
+        if line.startswith("#CHROM"):
+            per_chrom = {t: {} for t in contigs}
+            continue
+        v = VcfRecord(line)
+        if v.is_snp and v.is_pass:
+            k = get_sbs96(v.chrom, v.pos - 1, v.ref, v.alt, refseq)
+            d = per_chrom[v.chrom]                  # KeyError for a contig the header does not list, as the reference
+            d[k] = d.get(k, 0) + 1
+    counts = {k: 0 for k in SBS96_LST}
+    for chrom in chrom_lst:
+        for k, c in per_chrom[chrom].items():
+            if k.count("N") == 0:
+                counts[k] += c                       # KeyError for a class outside the 96, as the reference
+    return counts
+
+
+def get_chrom_tricount(seq):
+    """Trinucleotide counts of one contig (reflib.py:11-33): triplets whose FIRST base is N are skipped, purine
+    centres are reverse-complemented.  Only the 32 pyrimidine-centred ACGT keys are kept (all the callers read)."""
+    raw = np.frombuffer(seq.encode("ascii") if isinstance(seq, str) else bytes(seq), np.uint8)
+    code = np.full(256, 4, np.int64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    c = code[raw]
+    if c.shape[0] < 3:
+        return {t: 0 for t in TRI_LST}
+    a, b, d = c[:-2], c[1:-1], c[2:]
+    ok = (a < 4) & (b < 4) & (d < 4)            # a key with any other letter is not in tri_lst
+    a, b, d = a[ok], b[ok], d[ok]
+    pur = (b == 0) | (b == 2)                    # A or G in the middle: read the other strand
+    f = np.where(pur, 3 - d, a)
+    m = np.where(pur, 3 - b, b)
+    l = np.where(pur, 3 - a, d)
+    hist = np.bincount(f * 16 + m * 4 + l, minlength=64)
+    return {t: int(hist["ACGT".index(t[0]) * 16 + "ACGT".index(t[1]) * 4 + "ACGT".index(t[2])]) for t in TRI_LST}
+
+
+def get_genome_tricounts(refseq, chrom_lst):
+    tot = {t: 0 for t in TRI_LST}
+    for chrom in chrom_lst:
+        for t, c in get_chrom_tricount(refseq[chrom]).items():
+            tot[t] += c
+    return tot
+
+
+def get_normcounts_cmdline(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, min_qv, min_mapq,
+                           min_sequence_identity, min_gq, min_bq, min_trim, mismatch_window, max_mismatch_count,
+                           min_ref_count, min_alt_count, min_hap_count, common_snps, panel_of_normals,
+                           somatic_snv_prior, germline_snv_prior, germline_indel_prior, threads, phase,
+                           non_human_sample, reference_sample, out_file):
+    param = ("--min_qv {} --min_mapq {} --min_sequence_identity {} --min_gq {} --min_bq {} --min_ref_count {} "
+             "--min_alt_count {} --min_hap_count {} --min_trim {} --mismatch_window {} --max_mismatch_count {} "
+             "--somatic_snv_prior {} --germline_snv_prior {} --germline_indel_prior {} --threads {} -o {}").format(
+        min_qv, min_mapq, min_sequence_identity, min_gq, min_bq, min_ref_count, min_alt_count, min_hap_count, min_trim,
+        mismatch_window, max_mismatch_count, somatic_snv_prior, germline_snv_prior, germline_indel_prior, threads,
+        out_file)
+    head = "##himut_command=himut normcounts -i {} --ref {} --sbs {}".format(bam_file, ref_file, sbs_file)
+    if non_human_sample:
+        tail = " --vcf {}{} {}{} --non_human_sample{}".format(
+            vcf_file, " --phased_vcf {}".format(phased_vcf_file) if phase else "", param, " --phase" if phase else "",
+            " --reference_sample" if reference_sample else "")
+        return head + tail
+    if reference_sample:
+        return None          # the reference has no branch for --reference_sample without --non_human_sample
+    if phase:
+        return head + " --phased_vcf {} {} --common_snps {} --panel_of_normals {} --phase".format(
+            phased_vcf_file, param, common_snps, panel_of_normals)
+    return head + " {} --common_snps {} --panel_of_normals {}".format(param, common_snps, panel_of_normals)
+
+
+def _trifreq(d):
+    tot = sum(d.values())
+    return {k: (0 if tot == 0 else v / float(tot)) for k, v in d.items()}
+
+
+def _ratio(num, den):
+    fn, fd = _trifreq(num), _trifreq(den)
+    return {t: (0 if fd[t] == 0 else fn[t] / float(fd[t])) for t in TRI_LST}
+
+
+def dump_normcounts(sbs96_counts, ref_tri2count, chrom2ref_callable_tri2count, chrom2ccs_callable_tri2count, cmdline,
+                    out_file):
+    ref_call = {t: sum(d[t] for d in chrom2ref_callable_tri2count.values()) for t in TRI_LST}
+    ccs_call = {t: sum(d[t] for d in chrom2ccs_callable_tri2count.values()) for t in TRI_LST}
+    r_ref = _ratio(ref_call, ref_tri2count)
+    r_call = _ratio(ref_call, ccs_call)
+    with open(out_file, "w") as o:
+        o.write("{}\n".format(cmdline))
+        o.write("\t".join(["sub", "tri", "sbs96", "counts", "normcounts", "ref_tri_ratio", "ref_ccs_tri_ratio",
+                           "ref_tri_count", "ref_callable_tri_count", "ccs_callable_tri_count"]) + "\n")
+        for k in SBS96_LST:
+            sub, tri = k[2:5], k[0] + k[2] + k[6]
+            count = sbs96_counts[k]
+            norm = count * r_ref[tri] * r_call[tri]
+            o.write("{}\t{}\t{}\t{}\t{}\t{}\t{}\t{}\t{}\t{}\n".format(sub, tri, k, count, norm, r_ref[tri], r_call[tri],
+                                                                      ref_tri2count[tri], ref_call[tri], ccs_call[tri]))
+
+
+def dump_norm_log(chrom_lst, chrom2norm_log, path="norm.log"):
+    dt = np.zeros((len(NORM_LOG_ROWS), len(chrom_lst)))
+    for i, chrom in enumerate(chrom_lst):
+        for j, count in enumerate(chrom2norm_log[chrom]):
+            dt[j][i] = count
+    with open(path, "w") as o:
+        o.write("{:30}{}\n".format("", "\t".join(list(chrom_lst) + ["total"])))
+        for k, row in enumerate(NORM_LOG_ROWS):
+            cells = [str(int(r)) for r in dt[k].tolist()] + [str(int(np.sum(dt[k])))]
+            o.write("{:30}{}\n".format(row, "\t".join(cells)))
+
+
+def get_normcounts(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, common_snps, panel_of_normals, region,
+                   region_list, min_qv, min_mapq, min_sequence_identity, min_gq, min_bq, min_trim, mismatch_window,
+                   max_mismatch_count, min_ref_count, min_alt_count, min_hap_count, somatic_snv_prior,
+                   germline_snv_prior, germline_indel_prior, threads, phase, non_human_sample, reference_sample,
+                   out_file, devices=(0,), log_path="norm.log"):
+    """Driver of `himut normcounts` (normcounts.py:424-592): same arguments, the same table and norm.log; the PDF
+    plot is left out.  Contigs go to the GPUs of ``devices`` round-robin."""
+    from . import bamio, util, vcflib
+    if non_human_sample:
+        raise NotImplementedError("--non_human_sample needs germline priors from a FASTA/VCF pair "
+                                  "(vcflib.get_germline_priors); not part of the accelerated path")
+    bam = bamio.read_bam(bam_file)
+    tname2tsize = bam.tname2tsize
+    chrom_lst, chrom2chunkloci_lst = util.load_loci(region, region_list, tname2tsize)
+    ps2hbit, ps2hpos, ps2hetsnp = {}, {}, {}
+    if phase:
+        ps2hbit, ps2hpos, ps2hetsnp, chrom2chunkloci_lst = vcflib.load_phased_hetsnps(phased_vcf_file, chrom_lst,
+                                                                                      tname2tsize)
+    qlen_lower_limit, qlen_upper_limit, md_threshold = get_thresholds(sbs_file)
+    refseq = read_fasta(ref_file)
+    ccs, ref, log = {}, {}, {}
+    for k, chrom in enumerate(chrom_lst):
+        get_callable_tricounts(
+            chrom, refseq[chrom], bam_file, common_snps, panel_of_normals, chrom2chunkloci_lst[chrom],
+            ps2hbit.get(chrom, {}), ps2hpos.get(chrom, {}), ps2hetsnp.get(chrom, {}), min_qv, min_mapq, min_trim,
+            qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, mismatch_window,
+            max_mismatch_count, min_ref_count, min_alt_count, min_hap_count, md_threshold, somatic_snv_prior,
+            germline_snv_prior, germline_indel_prior, phase, non_human_sample, ccs, ref, log,
+            device=devices[k % len(devices)], read_batch=bam.batches[chrom])
+    cmdline = get_normcounts_cmdline(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, min_qv, min_mapq,
+                                     min_sequence_identity, min_gq, min_bq, min_trim, mismatch_window,
+                                     max_mismatch_count, min_ref_count, min_alt_count, min_hap_count, common_snps,
+                                     panel_of_normals, somatic_snv_prior, germline_snv_prior, germline_indel_prior,
+                                     threads, phase, non_human_sample, reference_sample, out_file)
+    sbs2count = load_sbs96_counts(sbs_file, refseq, chrom_lst)
+    ref_tri2count = get_genome_tricounts(refseq, chrom_lst)
+    dump_normcounts(sbs2count, ref_tri2count, ref, ccs, cmdline, out_file)
+    dump_norm_log(chrom_lst, log, log_path)
+    return ccs, ref, log

@@ -1,5 +1,5 @@
-"""Command line of ``himut call`` (reference: src/himut/parse_args.py:37-227): same flag
-names, types and defaults, plus ``--devices`` for the GPUs to use."""
+"""Command lines of ``himut call`` and ``himut normcounts`` (reference: src/himut/parse_args.py:37-227,
+502-692): same flag names, types and defaults, plus ``--devices`` for the GPUs to use."""
 import argparse
 import sys
 
@@ -44,6 +44,39 @@ def build_parser(program_version):
                    help="call substitutions with relaxed parameters for panel of normal preparation")
     p.add_argument("-o", "--output", type=str, required=True, help="VCF file to write the substitutions")
     p.add_argument("--devices", type=str, default="0", help="comma separated GPU ids (contigs are spread over them)")
+    # himut normcounts (reference: parse_args.py:502-692)
+    n = sub.add_parser("normcounts", help="normalises SBS96 mutation counts based on genome and read trinucleotide "
+                                          "context counts", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    n.add_argument("-i", "--bam", type=str, required=True,
+                   help="minimap2 (parameters: -ax map-hifi --cs=short) aligned BAM file")
+    n.add_argument("--ref", type=str, required=True, help="reference FASTA file")
+    n.add_argument("--sbs", type=str, required=True, help="himut VCF file to read somatic single base substitutions")
+    n.add_argument("--vcf", type=str, required=False, help="VCF file with germline mutations")
+    n.add_argument("--phased_vcf", type=str, required=False, help="phased germline VCF file")
+    n.add_argument("--common_snps", type=str, required=False, help="common SNPs VCF file")
+    n.add_argument("--panel_of_normals", type=str, required=False, help="panel of normal VCF file")
+    n.add_argument("--region", type=str, required=False, help="target chromosome")
+    n.add_argument("--region_list", type=str, required=False, help="list of target chromosomes, one per line")
+    n.add_argument("--min_qv", type=int, default=30, help="minimum read accuracy score")
+    n.add_argument("--min_mapq", type=int, default=60, help="minimum mapping quality score")
+    n.add_argument("--min_sequence_identity", type=float, default=0.99, help="minimum sequence identity")
+    n.add_argument("--min_gq", type=int, default=20, help="minimum germline genotype quality score")
+    n.add_argument("--min_bq", type=int, default=93, help="minimum base quality score")
+    n.add_argument("--min_ref_count", type=int, default=3, help="minimum reference allele depth")
+    n.add_argument("--min_alt_count", type=int, default=1, help="minimum alternative allele depth")
+    n.add_argument("--min_hap_count", type=int, default=3, help="minimum h0 and h1 haplotype count")
+    n.add_argument("--min_trim", type=float, default=0.01, help="proportion of the read ends to ignore")
+    n.add_argument("--mismatch_window", type=int, default=20, help="mismatch window size")
+    n.add_argument("--max_mismatch_count", type=int, default=0, help="maximum mismatches within the window")
+    n.add_argument("--somatic_snv_prior", type=float, default=1 / (10 ** 6), help="somatic SNV prior")
+    n.add_argument("--germline_snv_prior", type=float, default=1 / (10 ** 3), help="germline SNV prior")
+    n.add_argument("--germline_indel_prior", type=float, default=1 / (10 ** 4), help="germline indel prior")
+    n.add_argument("-t", "--threads", type=int, default=1, help="kept for the command line record; GPUs do the work")
+    n.add_argument("--phase", required=False, action="store_true", help="use phased reads only")
+    n.add_argument("--non_human_sample", required=False, action="store_true", help="human (default) or non-human sample")
+    n.add_argument("--reference_sample", required=False, action="store_true", help="reads from the reference sample")
+    n.add_argument("-o", "--output", type=str, required=True, help="file to write the normalised SBS96 counts")
+    n.add_argument("--devices", type=str, default="0", help="comma separated GPU ids (contigs are spread over them)")
     return parser
 
 

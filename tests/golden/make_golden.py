@@ -390,6 +390,76 @@ def header_case():
     save("vcf_header", {"header": hdr, "header_phase": hdr_phase})
 
 
+def norm_host_case(tmpdir="/tmp"):
+    """The host side of `himut normcounts` around the worker: thresholds from the SBS file's header, SBS96 counts,
+    genome trinucleotide counts, the output table and norm.log, the command line."""
+    ref = H.load_reference()
+    NH = H.load_reference_norm_host()
+    cfg = small_cfg(301, contig_len=30000, name="chr9", som_rate=4e-4)
+    s = synth.generate(cfg, want_ref=True)
+    b = s.batch
+    seq = list(bytes(s.ref).decode())
+    seq[100:140] = ["N"] * 40
+    seq[5000:5020] = [c.lower() for c in seq[5000:5020]]
+    seq = "".join(seq)
+    fa = os.path.join(tmpdir, "norm_host.fa")
+    with open(fa, "w") as o:
+        o.write(">chr9 test\n")
+        for i in range(0, len(seq), 60):
+            o.write(seq[i:i + 60] + "\n")
+    bam = "/fake/norm_host.bam"
+    H.register_bam(bam, {b.name: b})
+    sizes = {b.name: b.length}
+    ql, qu, md = thresholds_of(ref, bam, [b.name], sizes)
+    _, c2c = ref.util.load_loci(None, None, sizes)
+    chunks = [(s_, e_) for (_, s_, e_) in c2c[b.name]]
+    recs, _ = H.run_reference_worker(bam, b.name, chunks, ql, qu, md)
+    args = dict(H.CALL_DEFAULTS)
+    header = ref.vcflib.get_himut_vcf_header(
+        bam, None, None, None, None, sizes, "common.vcf", "pon.vcf", args["min_qv"], args["min_mapq"], ql, qu,
+        args["min_sequence_identity"], args["min_gq"], args["min_bq"], args["min_trim"], args["max_mismatch_count"],
+        args["mismatch_window_size"], md, args["min_ref_count"], args["min_alt_count"], args["min_hap_count"], 1,
+        args["somatic_snv_prior"], args["germline_snv_prior"], args["germline_indel_prior"], False, False, False, False,
+        "1.0.4", os.path.join(tmpdir, "norm_host.vcf"))
+    sbs = os.path.join(tmpdir, "norm_host.vcf")
+    cwd = os.getcwd()
+    os.chdir(tmpdir)
+    try:
+        ref.vcflib.dump_sbs(sbs, header, [b.name], {b.name: recs})
+        exp = {"contig": b.name, "fasta_text": open(fa).read(), "sbs_vcf_text": open(sbs).read()}
+        exp["thresholds"] = list(NH.vcflib.get_thresholds(sbs))
+        exp["sbs96_counts"] = NH.mutlib.load_sbs96_counts(sbs, fa, [b.name])
+        d = {}
+        NH.reflib.get_chrom_tricount(b.name, seq, d)
+        exp["chrom_tricount"] = {k: int(v) for k, v in d[b.name].items() if k in NH.mutlib.tri_lst}
+        ccs, rf, log, order = H.run_reference_normcounts(bam, b.name, seq, chunks, ql, qu, md)
+        ref_tri2count = {t: d[b.name][t] for t in NH.mutlib.tri_lst}
+        out = os.path.join(tmpdir, "norm_host.tsv")
+        cmd = NH.mutlib.get_normcounts_cmdline(bam, fa, sbs, None, None, 30, 60, 0.99, 20, 93, 0.01, 20, 0, 3, 1, 3,
+                                               "common.vcf", "pon.vcf", 1e-6, 1e-3, 1e-4, 4, False, False, False, out)
+        NH.mutlib.dump_normcounts(exp["sbs96_counts"], ref_tri2count, {b.name: rf}, {b.name: ccs}, cmd, out)
+        NH.mutlib.dump_norm_log([b.name], {b.name: log})
+        exp["cmdline"] = cmd
+        exp["cmdline_phase"] = NH.mutlib.get_normcounts_cmdline(bam, fa, sbs, "g.vcf", "p.vcf", 30, 60, 0.99, 20, 93,
+                                                                0.01, 20, 0, 3, 1, 3, "c.vcf", "n.vcf", 1e-6, 1e-3,
+                                                                1e-4, 2, True, False, False, out)
+        exp["cmdline_nonhuman"] = NH.mutlib.get_normcounts_cmdline(bam, fa, sbs, "g.vcf", "p.vcf", 30, 60, 0.99, 20,
+                                                                   93, 0.01, 20, 0, 3, 1, 3, None, None, 1e-6, 1e-3,
+                                                                   1e-4, 2, True, True, True, out)
+        exp["normcounts_tsv"] = open(out).read()
+        exp["norm_log_text"] = open("norm.log").read()
+        exp["ccs_tri2count"] = {k: int(v) for k, v in ccs.items()}
+        exp["ref_tri2count"] = {k: int(v) for k, v in rf.items()}
+        exp["log"] = [int(x) for x in log]
+        exp["bam"] = bam
+        exp["out"] = out
+        exp["fa"] = fa
+        exp["sbs"] = sbs
+    finally:
+        os.chdir(cwd)
+    save("norm_host", exp)
+
+
 def main():
     only = set(sys.argv[1:])
 
@@ -454,6 +524,8 @@ def main():
         worker_case("worker_pon_params", small_cfg(109, contig_len=20000, name="chrN", som_rate=2e-4), md_threshold=52,
                     overrides=dict(min_bq=20, min_gq=10, min_qv=20, min_trim=0, min_mapq=30, min_hap_count=0,
                                    min_sequence_identity=0.8), create_pon=True)
+    if want("norm_host"):
+        norm_host_case()
     if want("norm_basic"):
         norm_case("norm_basic", small_cfg(201, contig_len=40000, name="chrA"), md_threshold=52)
     if want("norm_sets"):

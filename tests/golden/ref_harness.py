@@ -201,3 +201,33 @@ def run_reference_normcounts(bam_path, chrom, seq, chunks, qlen_lower, qlen_uppe
         phase_sets is not None, non_human_sample, ccs, rf, log)
     order = {b: list(ref.util.base_set.difference(b)) for b in "ATGC"}
     return ccs[chrom], rf[chrom], log[chrom], order
+
+
+class FakeFasta:
+    """pyfastx.Fasta stand-in: fasta[chrom] behaves like the sequence string (indexing, slicing, str())."""
+
+    def __init__(self, path, **kw):
+        self._seqs = {}
+        name, parts = None, []
+        for line in open(path):
+            if line.startswith(">"):
+                if name is not None:
+                    self._seqs[name] = "".join(parts)
+                name, parts = line[1:].split()[0], []
+            else:
+                parts.append(line.strip())
+        if name is not None:
+            self._seqs[name] = "".join(parts)
+
+    def __getitem__(self, chrom):
+        return self._seqs[chrom]
+
+
+def load_reference_norm_host():
+    """mutlib / reflib / vcflib of the reference with pyfastx.Fasta served by FakeFasta."""
+    load_reference()
+    sys.modules["pyfastx"].Fasta = FakeFasta
+    import himut.mutlib
+    import himut.reflib
+    import himut.vcflib
+    return types.SimpleNamespace(mutlib=himut.mutlib, reflib=himut.reflib, vcflib=himut.vcflib)

@@ -56,3 +56,66 @@ def test_call_two_contigs_with_side_vcfs(tmp_path):
     assert open(tmp_path / "himut.log").read() == open(tmp_path / "exp.log").read()
     assert "##himut_command=himut call -i {}".format(bam) in header
     assert sum(len(v) for v in want.values()) > 500
+
+
+def test_call_then_normcounts_end_to_end(tmp_path):
+    """`himut call` followed by `himut normcounts` on its output, two contigs: the table and norm.log equal what the
+    golden-pinned host functions print from the ORACLE's per-contig results on the same inputs."""
+    import numpy as np
+    from himut_amd import __main__ as cli
+    from himut_amd import bamio, normcounts as N, synth, util as hutil
+    from oracle import oracle as O
+    s1 = synth.generate(synth.SynthConfig(seed=61, contig_len=230_000, read_len_mean=6000, read_len_sd=1200,
+                                          read_len_min=2000, read_len_max=12000, som_rate=2e-4, name="chr3"), want_ref=True)
+    s2 = synth.generate(synth.SynthConfig(seed=62, contig_len=80_000, read_len_mean=6000, read_len_sd=1200,
+                                          read_len_min=2000, read_len_max=12000, som_rate=2e-4, name="chr11"), want_ref=True)
+    bam = str(tmp_path / "in.bam")
+    bamio.write_bam(bam, [s1.batch, s2.batch], sample="SMP")
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "w") as o:
+        for s in (s1, s2):
+            seq = bytes(s.ref).decode()
+            o.write(">{}\n".format(s.batch.name))
+            for i in range(0, len(seq), 70):
+                o.write(seq[i:i + 70] + "\n")
+    com = str(tmp_path / "common.vcf")
+    pon = str(tmp_path / "pon.vcf")
+    synth.write_common_snps_vcf(com, s1, seed=1, other_contig="chr11")
+    synth.write_pon_vcf(pon, s1, seed=1, rate=2e-3)
+    sbs = str(tmp_path / "calls.vcf")
+    out = str(tmp_path / "norm.tsv")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        cli.main(["call", "-i", bam, "--common_snps", com, "--panel_of_normals", pon, "-o", sbs])
+        cli.main(["normcounts", "-i", bam, "--ref", fa, "--sbs", sbs, "--common_snps", com, "--panel_of_normals", pon,
+                  "-o", out])
+    finally:
+        os.chdir(cwd)
+    # expected, from the oracle
+    from himut_amd import vcflib
+    refseq = N.read_fasta(fa)
+    sizes = {"chr3": 230_000, "chr11": 80_000}
+    chrom_lst, c2c = hutil.load_loci(None, None, sizes)
+    ql, qu, md = N.get_thresholds(sbs)
+    assert md == int(md)          # the header prints ceil(...) with one decimal (vcflib.py:183)
+    p = dict(min_qv=30, min_mapq=60, qlen_lower_limit=ql, qlen_upper_limit=qu, min_sequence_identity=0.99, min_gq=20,
+             min_bq=93, min_trim=0.01, max_mismatch_count=0, mismatch_window_size=20, md_threshold=int(md),
+             min_ref_count=3, min_alt_count=1, min_hap_count=3)
+    batches = {"chr3": s1.batch, "chr11": s2.batch}
+    ccs, ref, log = {}, {}, {}
+    for c in chrom_lst:
+        chunks = [(x[1], x[2]) for x in c2c[c]]
+        ccs[c], ref[c], log[c] = O.normcounts(batches[c], chunks, p, refseq[c], 1 / (10 ** 3),
+                                              O.site_keys(vcflib.load_pon(c, pon)),
+                                              O.site_keys(vcflib.load_common_snp(c, com)),
+                                              alt_order={b: list(N.BASE_SET.difference(b)) for b in "ATGC"})
+    exp_out = str(tmp_path / "exp.tsv")
+    cmd = open(out).readline().rstrip("\n")
+    N.dump_normcounts(N.load_sbs96_counts(sbs, refseq, chrom_lst), N.get_genome_tricounts(refseq, chrom_lst), ref, ccs,
+                      cmd, exp_out)
+    assert open(out).read() == open(exp_out).read()
+    N.dump_norm_log(chrom_lst, log, str(tmp_path / "exp.log"))
+    assert open(tmp_path / "norm.log").read() == open(tmp_path / "exp.log").read()
+    assert cmd.startswith("##himut_command=himut normcounts -i {} --ref {} --sbs {}".format(bam, fa, sbs))
+    assert sum(log[c][13] for c in chrom_lst) > 1_000_000
