@@ -111,7 +111,9 @@ def _make_batch(seed, contig_len, n_reads, kinds):
     recs.sort(key=lambda r: r["tstart"])
     for i, r in enumerate(recs):
         r["qname"] = "m/{}/ccs".format(i)
-    return batch_from_records("chrE", contig_len, recs)
+    batch = batch_from_records("chrE", contig_len, recs)
+    batch.refseq = ref          # the contig the reads were cut from (normcounts needs it)
+    return batch
 
 
 def _params(**kw):
@@ -161,3 +163,35 @@ def test_edge_reads_default_filters():
     chunks = [(1, 45_000), (45_000, L - 2)]
     p = _params(max_mismatch_count=0, mismatch_window_size=20, min_sequence_identity=0.9)
     _check(batch, chunks, p)
+
+
+@pytest.mark.parametrize("seed,kinds", [
+    (41, ["plain", "clip", "short", "trailins"]),
+    (42, ["bigindel", "plain", "mixed"]),
+    (43, ["noisy", "dense", "plain"]),
+])
+def test_edge_reads_normcounts_against_oracle(seed, kinds):
+    """The same hand-built alignments through the dense normcounts sweep."""
+    from oracle import oracle as O
+    from himut_amd import normcounts
+    from himut_amd.caller import Worker
+    L = 100_000
+    batch = _make_batch(seed, L, 240, kinds)
+    refseq = batch.refseq.encode("ascii")
+    chunks = [(1, 30_000), (30_000, 30_700), (45_000, L - 2)]
+    p = _params(min_bq=30, min_gq=5, max_mismatch_count=3, mismatch_window_size=12, min_ref_count=2, md_threshold=60,
+                min_sequence_identity=0.9)
+    order = {"A": ["C", "T", "G"], "T": ["G", "C", "A"], "G": ["T", "A", "C"], "C": ["A", "G", "T"]}
+    o_ccs, o_ref, o_log = O.normcounts(batch, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+    w = Worker(0)
+    try:
+        w.configure(p["min_qv"], p["min_mapq"], p["qlen_lower_limit"], p["qlen_upper_limit"], p["min_sequence_identity"],
+                    p["min_gq"], p["min_bq"], p["min_trim"], p["max_mismatch_count"], p["mismatch_window_size"],
+                    p["md_threshold"], p["min_ref_count"], p["min_alt_count"], p["min_hap_count"],
+                    p["germline_snv_prior"], False)
+        ccs, rf, log = normcounts.norm_contig(w, batch, chunks, refseq, alt_order=order)
+    finally:
+        w.close()
+    assert log == o_log
+    assert ccs == o_ccs and rf == o_ref
+    assert log[13] > 10_000
