@@ -899,6 +899,7 @@ __global__ void __launch_bounds__(256) k_block_slots(const uint32_t* rank, int64
     if (b < nblk) {
         const int64_t w0 = min(b * 8, nwords), w1 = min(b * 8 + 8, nwords);
         s = (unsigned long long)(rank[w1] - rank[w0]) * (unsigned long long)(uint32_t)(winhi[b] - winlo[b]);
+        s = (s + 15ULL) & ~15ULL;      // every block starts on a 32-byte boundary of the column store
         out[b] = (uint32_t)s;
     }
     if (total) {     // the sum in 64 bits: tells the host when the 32-bit offsets have wrapped
@@ -958,6 +959,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     __shared__ __align__(16) uint32_t s_bt[4][64];        // 16 block-table entries
     __shared__ uint32_t s_cb[4][NORM ? 64 : 1];            // normcounts: the window's callable bits
     __shared__ uint32_t s_wb[4][NORM ? 128 : 1];           // normcounts: the bitmap words under the window
+    __shared__ __align__(16) uint16_t s_out[4][NORM ? 1024 : 8];   // normcounts: the cells of 1024 positions, one 32-byte row per lane
     __shared__ uint2 s_list[4][CLQ];
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const Reads& R = A.R;
@@ -1133,21 +1135,98 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
             wb[lane] = mylo; wb[64 + lane] = myhi;
             __builtin_amdgcn_wave_barrier();
             const int64_t wbase = tA >> 5;
-            for (int32_t pg = tA; pg < tB; pg += 64) {
-                const int32_t p = pg + lane;
-                bool bit = false;
-                if (p < tB) {
-                    const int64_t wi = ((int64_t)p >> 5) - wbase;
-                    uint32_t word;
-                    if (wi < 128) word = wb[wi];
-                    else { word = X.bits[min((int64_t)p >> 5, X.nwords - 1)]; asm volatile("" : "+v"(word)); }   // long deletions
-                    bit = (word >> (p & 31)) & 1u;
+            // generic form: lane = position, 64 at a time, rank from a running count
+            auto generic = [&](const int32_t x0, const int32_t x1) {
+                for (int32_t pg = x0; pg < x1; pg += 64) {
+                    const int32_t p = pg + lane;
+                    bool bit = false;
+                    if (p < x1) {
+                        const int64_t wi = ((int64_t)p >> 5) - wbase;
+                        uint32_t word;
+                        if (wi < 128) word = wb[wi];
+                        else { word = X.bits[min((int64_t)p >> 5, X.nwords - 1)]; asm volatile("" : "+v"(word)); }   // long deletions
+                        bit = (word >> (p & 31)) & 1u;
+                    }
+                    const unsigned long long m = __ballot(bit);
+                    if (!m) continue;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    batch(bit, (uint32_t)p, ubase + below, pg + 63 - (int)__builtin_clzll(m));
+                    ubase += (uint32_t)__popcll(m);
                 }
-                const unsigned long long m = __ballot(bit);
-                if (!m) continue;
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                batch(bit, (uint32_t)p, ubase + below, pg + 63 - (int)__builtin_clzll(m));
-                ubase += (uint32_t)__popcll(m);
+            };
+            // Pieces of 1024 positions, aligned to 16: lane l owns positions P + 16 l .. + 15, which lie in one
+            // 256-position block.  Where every block under the piece is full (all 256 positions are candidates),
+            // a position's column index is its offset in the block, the lane's 16 cells are 32 contiguous,
+            // 32-byte aligned bytes of the column store, and the piece goes out as two 16-byte stores per lane.
+            uint16_t* ob = s_out[wv];
+            for (int32_t P = tA & ~15; P < tB; P += 1024) {
+                const int32_t x0 = max(P, tA), x1 = min(P + 1024, tB);
+                const int32_t p = P + 16 * lane;
+                const bool valid = p < x1 && p + 16 > x0;
+                uint4 bt = make_uint4(0, 256u << 22, 0, 0);
+                if (valid) {
+                    const int64_t bi = (int64_t)(p >> 8) - btb;
+                    if (bi >= 0 && bi < 16) bt = *reinterpret_cast<const uint4*>(lbt + 4 * bi);
+                    else { bt = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)(p >> 8), X.nblk - 1)); CAP_LANDED4(bt); }
+                }
+                if (__ballot(valid && (bt.y >> 22) != 256u)) { generic(x0, x1); continue; }   // a block at a chunk edge
+                {
+                    const uint4 e = make_uint4(0x00070007u, 0x00070007u, 0x00070007u, 0x00070007u);   // CELL_EMPTY
+                    reinterpret_cast<uint4*>(ob)[2 * lane] = e;
+                    reinterpret_cast<uint4*>(ob)[2 * lane + 1] = e;
+                }
+                __builtin_amdgcn_wave_barrier();
+                int j = jcur;
+                while (j < ns) {
+                    if (j < jb || j >= jb + nw) {        // lists longer than the LDS window: reload it from j
+                        jb = j; nw = min(ns - jb, CSG);
+                        __builtin_amdgcn_wave_barrier();
+                        CAP_SEGWIN();
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    const int4 sv = lseg[j - jb];
+                    const int32_t t0 = uni(sv.x), q0 = uni(sv.y), len = uni(sv.z);
+                    const uint32_t fl = (uint32_t)uni(sv.w);
+                    if (t0 >= x1) break;
+                    const int32_t span = len > 0 ? len : ((fl & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
+                    if (t0 + span > x0) {
+                        const int32_t a = max(max(p, x0), t0), b = min(min(p + 16, x1), t0 + span);
+                        if (fl & SEG_DEL) {
+                            for (int32_t i = a; i < b; i++) ob[i - P] = (uint16_t)(CELL_DEL | ((i == t0 && (fl & SEG_INS)) ? CELL_INS : 0u));
+                        } else if (len == 0) {
+                            if (a < b) ob[t0 - P] = (uint16_t)(CELL_EMPTY | CELL_INS);
+                        } else {
+                            for (int32_t i = a; i < b; i++) {
+                                const int32_t q = q0 + (i - t0);
+                                const int32_t o = (q - cq) & (CWQ - 1);             // inside the window by construction
+                                const uint32_t qv = wbq[o], sb = wsq[o >> 1];
+                                const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
+                                uint32_t val = (uint32_t)nib2allele(nib) | (qv << 8) | (((wcb[o >> 5] >> (o & 31)) & 1u) << 4);
+                                if (i == t0 && (fl & SEG_INS)) val |= CELL_INS;
+                                ob[i - P] = (uint16_t)val;
+                            }
+                        }
+                    }
+                    j++;
+                }
+                jcur = max(j - 1, jcur);
+                __builtin_amdgcn_wave_barrier();
+                if (valid) {
+                    // BlockTab: x = lo, y = n | cnt << 22, z = boff (a multiple of 16), w = ufirst
+                    const int64_t slot = (int64_t)bt.z + (int64_t)(r - (int32_t)bt.x) * 256 + (p & 255);
+                    if (p >= x0 && p + 16 <= x1) {
+                        if (slot + 16 <= A.nslots) {
+                            uint4* dst = reinterpret_cast<uint4*>(A.colstore + slot);
+                            dst[0] = reinterpret_cast<const uint4*>(ob)[2 * lane];
+                            dst[1] = reinterpret_cast<const uint4*>(ob)[2 * lane + 1];
+                        }
+                    } else {
+                        for (int32_t i = max(p, x0); i < min(p + 16, x1); i++)
+                            if (slot + (i - p) < A.nslots) A.colstore[slot + (i - p)] = ob[i - P];
+                    }
+                }
+                ubase += (uint32_t)(x1 - x0);
+                __builtin_amdgcn_wave_barrier();
             }
         } else {
         // ---- candidate bits of [tA, tB): lane l takes the CPL positions from tA + CPL * l
