@@ -144,27 +144,33 @@ def main():
     ctx.push_reads(batch)                     # inputs resident in HBM before the timed region
     t_h2d = time.perf_counter() - t_h2d
 
-    def step(materialize=False):
-        ctx.run()
-        if world > 1:
-            # final gather of the per-contig record buffers + counters to rank 0 (RCCL over xGMI)
-            _, n = ctx.records_device()
-            if backend == "nccl":
-                return hdist.gather_contig_results({batch.name: (None, ctx.log())}, names, rank, world,
-                                                   device_buffers={batch.name: (ctx, n)}, materialize=materialize)
-            return hdist.gather_contig_results({batch.name: (ctx.records(), ctx.log())}, names, rank, world,
-                                               materialize=materialize)
-        return None
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = None
+    # N > 1: the final exchange of every step (record buffers of the step's contigs -> rank 0, RCCL over xGMI)
+    # is pipelined: it runs while the next step scans.  All K exchanges complete inside the timed region.
+    ex = None
+    if world > 1:
+        ctx.run()                                           # untimed: sizes the exchange buffers
+        cap = hdist.RecordExchange.plan(ctx.records_device()[1])
+        ex = hdist.RecordExchange(rank, world, cap, depth=2)
+
+    def step():
+        ctx.run()
+        if world > 1:
+            _, n = ctx.records_device()
+            if backend == "nccl":
+                ex.submit(n, ctx.log(), ctx=ctx)
+            else:
+                ex.submit(n, ctx.log(), records=ctx.records())
 
     for _ in range(a.warmup):
         step()
+    if ex is not None:
+        ex.drain()
+        ex.meta = []
     stage_ms = {}
     barrier()
     t0 = time.perf_counter()
@@ -174,9 +180,11 @@ def main():
         for k in ("ms_total", "ms_parse", "ms_bqsum", "ms_hap", "ms_emit", "ms_index", "ms_capture", "ms_eval",
                   "ms_finalize"):
             stage_ms.setdefault(k, []).append(st[k])
+    gathered = ex.drain() if ex is not None else None
     barrier()
     elapsed = time.perf_counter() - t0
-    gathered = step(materialize=True) if world > 1 else None   # untimed: host copy of the gathered records
+    if gathered is not None:                                # untimed: host copy of the last step's gathered records
+        gathered = (gathered[0], ex.last_records(gathered[0]))
     red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -192,9 +200,11 @@ def main():
     positions, cand_sites, read_bases, n_records = [float(x) for x in totals.tolist()]
 
     if rank == 0:
-        if world > 1:   # the gathered result must hold every rank's contig
-            assert gathered is not None and sorted(gathered) == sorted(names)
-            assert sum(len(v[0]) for v in gathered.values()) == int(n_records)
+        if world > 1:   # every step's exchange delivered every rank's records
+            counts, last = gathered
+            assert len(counts) == world and all(len(c) == a.steps for c in counts)
+            assert sum(int(c[-1][0]) for c in counts) == int(n_records)
+            assert sum(len(v) for v in last.values()) == int(n_records)
         ms_per_step = elapsed / a.steps * 1e3
         mbp_s = positions / 1e6 / (elapsed / a.steps)
         avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}

@@ -52,6 +52,9 @@ def gather_contig_results(local, contig_names, rank, world, device_buffers=None,
     cap = max(max(per_rank), 1)
     # 2. one fixed-size send per rank: its contigs' records back to back, in natural order
     send = torch.zeros(cap * REC, dtype=torch.uint8, device=dev)
+    if dev.type == "cuda":
+        # the library copies into `send` on its own stream: the zero fill (torch's stream) must be done first
+        torch.cuda.current_stream().synchronize()
     off = 0
     for c in names:
         if c not in local:
@@ -82,3 +85,91 @@ def gather_contig_results(local, contig_names, rank, world, device_buffers=None,
         cursor[owner] += n
         out[c] = (recs, [int(x) for x in tab[i, 2:17]])
     return out
+
+
+class RecordExchange:
+    """The same final exchange, pipelined: the gather of one contig's records to rank 0 runs while the next
+    contig is scanned.  Every rank sends a fixed-size buffer per submit (``cap_records`` records, agreed once
+    with ``plan``), `depth` of them in flight; the record counts and the 15 counters travel in one small
+    all-gather when the exchange is drained."""
+
+    def __init__(self, rank, world, cap_records, depth=2):
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world, self.cap, self.depth = rank, world, int(cap_records), depth
+        backend = dist.get_backend()
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        self.send = [torch.zeros(self.cap * REC, dtype=torch.uint8, device=self.dev) for _ in range(depth)]
+        self.recv = [[torch.empty_like(self.send[0]) for _ in range(world)] for _ in range(depth)] if rank == 0 else None
+        if self.dev.type == "cuda":
+            torch.cuda.current_stream().synchronize()     # the zero fills are done before the library writes
+        self.handles = [None] * depth
+        self.meta = []          # per submit: [n, log[15]]
+        self.k = 0
+        # one untimed gather brings the point-to-point channels up (RCCL sets them up on first use)
+        dist.gather(self.send[0], self.recv[0] if rank == 0 else None, dst=0)
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    @staticmethod
+    def plan(n_local):
+        """Collective: the capacity every rank must use = the largest record count of any rank (+25 %)."""
+        import torch
+        import torch.distributed as dist
+        backend = dist.get_backend()
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item()) * 5 // 4 + 64
+
+    def submit(self, n, log, ctx=None, records=None):
+        """Records of one finished contig: from the context's device buffer (ctx) or from a host array."""
+        import torch
+        import torch.distributed as dist
+        if n > self.cap:
+            raise ValueError("RecordExchange: {} records exceed the planned capacity {}".format(n, self.cap))
+        slot = self.k % self.depth
+        if self.handles[slot] is not None:
+            self.handles[slot].wait()
+        if n:
+            if ctx is not None:
+                ctx.copy_records_to_device(self.send[slot].data_ptr(), self.cap)
+            else:
+                raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+                self.send[slot][:n * REC] = torch.from_numpy(raw.copy()).to(self.dev)
+        self.handles[slot] = dist.gather(self.send[slot], self.recv[slot] if self.rank == 0 else None, dst=0,
+                                         async_op=True)
+        self.meta.append([int(n)] + [int(x) for x in log])
+        self.k += 1
+
+    def drain(self, materialize_last=False):
+        """Waits for every gather in flight and exchanges the per-submit counts.  Rank 0 gets
+        (counts[world][submits][16], last) where ``last`` is {rank: records array} of the last submit when
+        ``materialize_last``; other ranks get None."""
+        import torch
+        import torch.distributed as dist
+        for h in self.handles:
+            if h is not None:
+                h.wait()
+        self.handles = [None] * self.depth
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+        m = torch.tensor(self.meta if self.meta else [[0] * 16], dtype=torch.int64, device=self.dev)
+        allm = [torch.empty_like(m) for _ in range(self.world)]
+        dist.all_gather(allm, m)
+        if self.rank != 0:
+            return None
+        counts = [t.cpu().numpy() for t in allm]
+        last = self.last_records(counts) if materialize_last else None
+        return counts, last
+
+    def last_records(self, counts):
+        """Rank 0: {rank: records array} of the last submit (host copy)."""
+        if self.rank != 0 or self.k == 0:
+            return None
+        slot = (self.k - 1) % self.depth
+        last = {}
+        for r in range(self.world):
+            n = int(counts[r][-1][0])
+            last[r] = self.recv[slot][r][:n * REC].cpu().numpy().view(RECORD_DTYPE).copy()
+        return last

@@ -38,6 +38,19 @@ if rank == 0:
         assert np.array_equal(recs, want), c
         assert log == wlog, c
     print("GATHER_OK", json.dumps(assign))
+# the pipelined exchange: three "contigs" per rank, two gathers in flight
+mine = [fake(c) for c in (["chr1", "chr10", "chrX"] if rank == 0 else ["chr2", "chrM", "chr10"])]
+cap = hdist.RecordExchange.plan(max(len(r) for r, _ in mine))
+ex = hdist.RecordExchange(rank, world, cap, depth=2)
+for recs, log in mine:
+    ex.submit(len(recs), log, records=recs)
+out = ex.drain(materialize_last=True)
+if rank == 0:
+    counts, last = out
+    assert [int(x[0]) for x in counts[0]] == [9, 4, 3] and [int(x[0]) for x in counts[1]] == [5, 0, 4]
+    assert [int(v) for v in counts[1][0][1:]] == fake("chr2")[1]
+    assert np.array_equal(last[0], fake("chrX")[0]) and np.array_equal(last[1], fake("chr10")[0])
+    print("EXCHANGE_OK")
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -65,4 +78,4 @@ def test_gather_world_size_2_gloo(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    assert "GATHER_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "EXCHANGE_OK" in outs[0]
