@@ -47,7 +47,7 @@ EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_err
            "himut_set_gt_lut", "himut_set_chunks", "himut_set_site_set", "himut_set_phase", "himut_push_reads",
            "himut_run", "himut_get_records", "himut_get_log", "himut_get_stats", "himut_records_device",
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
-           "himut_get_normcounts"]
+           "himut_get_normcounts", "himut_ref_tricounts"]
 
 _lib = None
 
@@ -106,6 +106,7 @@ def lib():
     L.himut_set_reference.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
     L.himut_run_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.himut_get_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.himut_ref_tricounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     for name in EXPORTS:
         if name not in ("himut_destroy", "himut_last_error"):
             getattr(L, name).restype = ctypes.c_int
@@ -238,6 +239,11 @@ class Context:
         log = np.zeros(14, np.int64)
         self._check(self._L.himut_get_normcounts(self._h, _ptr(ccs), _ptr(ref), _ptr(log)))
         return ccs, ref, [int(x) for x in log]
+
+    def ref_tricounts(self):
+        out = np.zeros(64, np.int64)
+        self._check(self._L.himut_ref_tricounts(self._h, _ptr(out)))
+        return out
 
     def pile_counts(self, p0, p1):
         counts = np.zeros((p1 - p0, 6), np.uint32)

@@ -978,6 +978,23 @@ int himut_set_reference(himut_ctx* c, const uint8_t* seq, int64_t len, const uin
     });
 }
 
+int himut_ref_tricounts(himut_ctx* c, int64_t out[64]) {
+    if (!c || !out) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int {
+        if (c->reflen <= 0) return fail(c, HIMUT_ERR_ARG, "himut_set_reference has not been called");
+        HCHECK(hipSetDevice(c->device));
+        c->d_tmp2.reserve(64 * 8 + 256);
+        unsigned long long* d = c->d_tmp2.as<unsigned long long>();
+        HCHECK(hipMemsetAsync(d, 0, 64 * 8, c->stream));
+        hipLaunchKernelGGL(k_ref_tricounts, dim3(2048), dim3(256), 0, c->stream, c->d_refseq.as<uint8_t>(), c->reflen, d);
+        unsigned long long h[64];
+        HCHECK(hipMemcpyAsync(h, d, 64 * 8, hipMemcpyDeviceToHost, c->stream));
+        HCHECK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 64; k++) out[k] = (int64_t)h[k];
+        return HIMUT_OK;
+    });
+}
+
 int himut_run_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human_sample) {
     if (!c || !alt_order) return HIMUT_ERR_ARG;
     return guarded(c, [&]() -> int { return do_normcounts(c, alt_order, non_human_sample); });

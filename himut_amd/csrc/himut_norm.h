@@ -486,4 +486,24 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
     if (bad) atomicOr(A.err, bad);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_ref_tricounts: reflib.get_chrom_tricount (reflib.py:11-33) over the resident reference string: every
+// triplet whose three letters are upper-case A/C/G/T, purine centres read on the other strand; 64 bins
+// indexed first * 16 + centre * 4 + last with A0 C1 G2 T3 (only the 32 pyrimidine-centred ones fill).
+__global__ void __launch_bounds__(256) k_ref_tricounts(const uint8_t* seq, int64_t len, unsigned long long* out) {
+    __shared__ unsigned int s_h[64];
+    if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    auto code = [](int c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 2 < len; i += (int64_t)gridDim.x * blockDim.x) {
+        const int a = code(seq[i]), b = code(seq[i + 1]), d = code(seq[i + 2]);
+        if (a > 3 || b > 3 || d > 3) continue;
+        const bool pur = b == 0 || b == 2;
+        const int f = pur ? 3 - d : a, m = pur ? 3 - b : b, l = pur ? 3 - a : d;
+        atomicAdd(&s_h[f * 16 + m * 4 + l], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+}
+
 }  // namespace himut

@@ -215,6 +215,14 @@ def get_chrom_tricount(seq):
     return {t: int(hist["ACGT".index(t[0]) * 16 + "ACGT".index(t[1]) * 4 + "ACGT".index(t[2])]) for t in TRI_LST}
 
 
+def get_chrom_tricount_device(ctx, seq):
+    """The same counts from the device (the contig string goes to HBM for the sweep anyway)."""
+    chars, cls = tri_classes(seq)
+    ctx.set_reference(seq, cls, len(chars))
+    h = ctx.ref_tricounts()
+    return {t: int(h["ACGT".index(t[0]) * 16 + "ACGT".index(t[1]) * 4 + "ACGT".index(t[2])]) for t in TRI_LST}
+
+
 def get_genome_tricounts(refseq, chrom_lst):
     tot = {t: 0 for t in TRI_LST}
     for chrom in chrom_lst:

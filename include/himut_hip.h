@@ -197,6 +197,9 @@ int himut_copy_records_to_device(himut_ctx* ctx, void* dst_device, int64_t capac
 int himut_set_reference(himut_ctx* ctx, const uint8_t* seq, int64_t len, const uint8_t cls[256], int n_classes);
 int himut_run_normcounts(himut_ctx* ctx, const uint8_t alt_order[12], int non_human_sample);
 int himut_get_normcounts(himut_ctx* ctx, int64_t* ccs_tri, int64_t* ref_tri, int64_t log[14]);
+/* reflib.get_chrom_tricount (reflib.py:11-33) of the string given to himut_set_reference: out[first * 16 + centre * 4 +
+ * last], letters A0 C1 G2 T3, purine centres already turned to the other strand (so 32 of the 64 bins fill). */
+int himut_ref_tricounts(himut_ctx* ctx, int64_t out[64]);
 
 /* Dense pile of [p0, p1) over ALL pushed reads (no chunk restriction):
  * counts[(p - p0) * 6 + a], bqsum[(p - p0) * 4 + b]  (caller.py:44-72). */

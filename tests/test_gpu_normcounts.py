@@ -118,3 +118,15 @@ def test_normcounts_full_size_properties_and_prefix_parity(worker):
     o_ccs, o_ref, o_log = O.normcounts(sub, chunks[:nch], p, refseq, p["germline_snv_prior"], alt_order=order)
     h_ccs, h_ref, h_log = normcounts.norm_contig(worker, sub, chunks[:nch], refseq, alt_order=order)
     assert h_log == o_log and h_ccs == o_ccs and h_ref == o_ref
+
+
+def test_ref_tricounts_match_reference_golden(worker):
+    """reflib.get_chrom_tricount on the device against the reference's own counts (norm_host golden: N and
+    lower-case stretches) and against the numpy host version on a large random string."""
+    from himut_amd import normcounts as N
+    exp = util.load_json("norm_host")
+    seq = "".join(l.strip() for l in exp["fasta_text"].splitlines() if not l.startswith(">"))
+    assert N.get_chrom_tricount_device(worker.ctx, seq) == exp["chrom_tricount"]
+    rs = np.random.RandomState(7)
+    big = bytes(rs.choice(np.frombuffer(b"ACGTACGTACGTNacgt", np.uint8), 5_000_000))
+    assert N.get_chrom_tricount_device(worker.ctx, big) == N.get_chrom_tricount(big)
