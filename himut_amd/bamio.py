@@ -44,6 +44,9 @@ def _load():
         L.bam_count.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.bam_ref_copy.restype = None
         L.bam_ref_copy.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 13
+        L.vcf_format_records.restype = ctypes.c_int64
+        L.vcf_format_records.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_int64]
         L.bam_free.restype = None
         L.bam_free.argtypes = [ctypes.c_void_p]
         L.bam_write.restype = ctypes.c_int
@@ -135,3 +138,17 @@ def write_bam(path, batches, sample="syn"):
     rc = L.bam_write(path.encode(), sample.encode(), arr, len(batches))
     if rc:
         raise IOError("bam_write failed ({})".format(rc))
+
+
+def format_records(recs, chrom, phased=False, single_molecule_file=False):
+    """VCF body lines (bytes) of a records array, printed by the host library exactly as
+    caller.records_to_tuples + vcflib._body_line would."""
+    L = _load()
+    recs = np.ascontiguousarray(recs)
+    cap = int(recs.shape[0]) * 256 + 1024
+    out = np.empty(cap, np.uint8)
+    n = L.vcf_format_records(_p(recs), int(recs.shape[0]), chrom.encode(), 1 if phased else 0,
+                             1 if single_molecule_file else 0, _p(out), cap)
+    if n < 0:
+        raise RuntimeError("vcf_format_records: buffer too small")
+    return out[:n].tobytes()

@@ -129,14 +129,15 @@ def get_somatic_substitutions(
     phase_set2hetsnp_lst, min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq,
     min_trim, max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
     somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample, create_panel_of_normals,
-    chrom2tsbs_lst, chrom2tsbs_log, device=0, read_batch=None,
+    chrom2tsbs_lst, chrom2tsbs_log, device=0, read_batch=None, chrom2records=None,
 ):
     """Drop-in for himut.caller.get_somatic_substitutions (caller.py:208).
 
     ``bam_file`` is read with the package's own BAM reader unless a prebuilt
     ``read_batch`` is given.  ``somatic_snv_prior`` and ``germline_indel_prior``
     are accepted and unused, as in the reference.  Assigns
-    chrom2tsbs_lst[chrom] / chrom2tsbs_log[chrom] exactly like caller.py:622-641."""
+    chrom2tsbs_lst[chrom] / chrom2tsbs_log[chrom] exactly like caller.py:622-641 (with ``chrom2records`` the
+    integer records are kept instead of the tuples: the driver's fast printer works from those)."""
     from . import vcflib
     pon_keys = com_keys = None
     human = not non_human_sample and not create_panel_of_normals
@@ -158,7 +159,10 @@ def get_somatic_substitutions(
     chunks = [(int(s), int(e)) for (_c, s, e) in chunkloci_lst]
     phase_sets = (phase_set2hbit_lst, phase_set2hpos_lst, phase_set2hetsnp_lst) if phase else None
     recs, log = w.call_contig(read_batch, chunks, pon_keys, com_keys, phase_sets)
-    chrom2tsbs_lst[chrom] = records_to_tuples(chrom, recs)
+    if chrom2records is not None:       # the driver prints from the integer records (vcflib.dump_records)
+        chrom2records[chrom] = recs
+    else:
+        chrom2tsbs_lst[chrom] = records_to_tuples(chrom, recs)
     chrom2tsbs_log[chrom] = log
 
 
@@ -201,7 +205,7 @@ def call_somatic_substitutions(
         max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count, threads,
         somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample, reference_sample,
         create_panel_of_normals, version, out_file, bam.sample())
-    chrom2tsbs_lst, chrom2tsbs_log = {}, {}
+    chrom2tsbs_lst, chrom2tsbs_log, chrom2records = {}, {}, {}
     devices = list(devices) or [0]
     plan = dist.lpt_assign({c: tname2tsize[c] for c in chrom_lst}, len(devices))
     for dev, contigs in zip(devices, plan):
@@ -212,11 +216,9 @@ def call_somatic_substitutions(
                 qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
                 max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
                 somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample,
-                create_panel_of_normals, chrom2tsbs_lst, chrom2tsbs_log, device=dev, read_batch=bam.batches[chrom])
+                create_panel_of_normals, chrom2tsbs_lst, chrom2tsbs_log, device=dev, read_batch=bam.batches[chrom],
+                chrom2records=chrom2records)
     vcflib.dump_call_log(chrom_lst, chrom2tsbs_log, path=log_path)                         # caller.py:812-817
-    if phase:
-        vcflib.dump_phased_sbs(out_file, vcf_header, chrom_lst, chrom2tsbs_lst)
-    else:
-        vcflib.dump_sbs(out_file, vcf_header, chrom_lst, chrom2tsbs_lst)
+    vcflib.dump_records(out_file, vcf_header, chrom_lst, chrom2records, bool(phase))       # = dump_sbs / dump_phased_sbs
     print("himut single molecule somatic mutation detection took {} minutes".format((time.time() - t0) / 60))
-    return chrom2tsbs_lst, chrom2tsbs_log
+    return chrom2records, chrom2tsbs_log

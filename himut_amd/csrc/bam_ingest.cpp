@@ -551,6 +551,62 @@ void bam_ref_copy(void* h, int64_t i, int32_t* tstart, int32_t* tend, int32_t* q
 
 void bam_free(void* h) { delete (Bam*)h; }
 
+// ---- VCF body text from the device's integer records ---------------------------------------
+// What caller.records_to_tuples + vcflib._body_line print (reference: bamlib.py:181-219, caller.py:174-192,
+// vcflib.py:820-1021), in C: the divisions are the same IEEE doubles and "%.1f" / "%.0f" / "%.2f" round
+// like python's format (both print the correctly rounded decimal).  One 64-byte himut_record per entry
+// (include/himut_hip.h).  sm_file = 1 writes only the rows of the single_molecule_mutations file.
+// Returns the number of bytes written, or -1 if `cap` is too small.
+struct VcfRec {
+    int32_t tpos, chunk, phase_set, gq;
+    uint8_t ref, alt, gt0, gt1, status, gt_state, flags, pad;
+    uint32_t counts[6], bqsum[4];
+};
+
+int64_t vcf_format_records(const void* records, int64_t n, const char* chrom, int phased, int sm_file, char* out, int64_t cap) {
+    static const char* STATUS[] = {"PASS", "LowBQ", "LowGQ", "IndelSite", "HetSite", "HetAltSite", "HomAltSite", "ComSnp",
+                                   "PanelOfNormal", "LowDepth", "HighDepth", "Unphased"};
+    auto idx = [](int ch) { return ch == 'A' ? 0 : ch == 'T' ? 1 : ch == 'G' ? 2 : 3; };
+    const VcfRec* R = (const VcfRec*)records;
+    int64_t w = 0;
+    for (int64_t k = 0; k < n; k++) {
+        const VcfRec& r = R[k];
+        if (cap - w < 512) return -1;
+        const uint32_t* c = r.counts;
+        const double depth = (double)(c[0] + c[1] + c[2] + c[3] + c[5]);
+        const double ref_count = (double)c[idx(r.ref)];
+        const bool hetalt = r.status == 5;
+        char ps[16];
+        if (r.phase_set >= 0) snprintf(ps, sizeof(ps), "%d", r.phase_set); else snprintf(ps, sizeof(ps), ".");
+        char line[512];
+        int m;
+        if (hetalt) {
+            const int pi = idx(r.gt0), qi = idx(r.gt1);
+            const double pc = (double)c[pi], qc = (double)c[qi];
+            if ((int64_t)ref_count != 1 && sm_file) continue;
+            const char* fmt = (phased && sm_file) ? "GT:GQ:BQ:DP:AD:VAF:PS" : "GT:GQ:BQ:DP:AD:VAF";
+            m = snprintf(line, sizeof(line), "%s\t%d\t.\t%c\t%c,%c\t.\t%s\t.\t%s\t./.:%d:%.1f,%.1f:%.0f:%.0f,%.0f,%.0f:%.2f,%.2f",
+                         chrom, r.tpos, r.ref, r.gt0, r.gt1, STATUS[r.status], fmt, r.gq, (double)r.bqsum[pi] / pc,
+                         (double)r.bqsum[qi] / qc, depth, ref_count, pc, qc, pc / depth, qc / depth);
+        } else {
+            const int ai = idx(r.alt);
+            const double alt_count = (double)c[ai];
+            if ((int64_t)alt_count != 1 && sm_file) continue;
+            const double alt_bq = alt_count != 0 ? (double)r.bqsum[ai] / alt_count : 0.0;
+            const char* fmt = phased ? "GT:GQ:BQ:DP:AD:VAF:PS" : "GT:GQ:BQ:DP:AD:VAF";
+            m = snprintf(line, sizeof(line), "%s\t%d\t.\t%c\t%c\t.\t%s\t.\t%s\t./.:%d:%.1f:%.0f:%.0f,%.0f:%.2f", chrom, r.tpos,
+                         r.ref, r.alt, r.status < 12 ? STATUS[r.status] : "?", fmt, r.gq, alt_bq, depth, ref_count, alt_count,
+                         alt_count / depth);
+        }
+        if (m < 0 || m >= (int)sizeof(line) - 24) return -1;
+        memcpy(out + w, line, (size_t)m);
+        w += m;
+        if (phased) { out[w++] = ':'; const size_t l = strlen(ps); memcpy(out + w, ps, l); w += (int64_t)l; }
+        out[w++] = '\n';
+    }
+    return w;
+}
+
 // ---- writer: one call per file; contigs given as parallel arrays of batches -------------
 struct BamWriteContig {
     const char* name;

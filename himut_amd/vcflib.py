@@ -259,6 +259,20 @@ def _dump(vcf_file, vcf_header, chrom_lst, chrom2tsbs_lst, phased):
                     sm.write(_body_line(rec, phased, True))
 
 
+def dump_records(vcf_file, vcf_header, chrom_lst, chrom2recs, phased):
+    """The same two files straight from the integer records (numpy arrays of RECORD_DTYPE), formatted by the host
+    library: what dump_sbs / dump_phased_sbs write for caller.records_to_tuples(chrom, recs)."""
+    from . import bamio
+    if not vcf_file.endswith(".vcf"):
+        raise ValueError("VCF file must have .vcf suffix")
+    with open(vcf_file, "wb") as main, open(vcf_file.replace(".vcf", ".single_molecule_mutations.vcf"), "wb") as sm:
+        main.write("{}\n".format(vcf_header).encode())
+        sm.write("{}\n".format(vcf_header).encode())
+        for chrom in chrom_lst:
+            main.write(bamio.format_records(chrom2recs[chrom], chrom, phased, False))
+            sm.write(bamio.format_records(chrom2recs[chrom], chrom, phased, True))
+
+
 def dump_sbs(vcf_file, vcf_header, chrom_lst, chrom2tsbs_lst):
     _dump(vcf_file, vcf_header, chrom_lst, chrom2tsbs_lst, False)
 

@@ -178,3 +178,26 @@ def test_normcounts_host_side_matches_reference(tmp_path):
     log = tmp_path / "norm.log"
     N.dump_norm_log([chrom], {chrom: exp["log"]}, str(log))
     assert log.read_text() == exp["norm_log_text"]
+
+
+def test_record_formatter_matches_reference_vcf_text(tmp_path):
+    """The host library's VCF body printer against the text the REFERENCE's writer produced for the golden cases
+    (records come from the oracle, which the other tests pin to the reference's tuples)."""
+    from oracle import oracle as O
+    from himut_amd import caller
+    for case in ["worker_basic", "worker_dense_sets", "worker_flags", "worker_phase", "worker_phase_dense"]:
+        batch, exp = util.load_case(case)
+        p = util.params_of(exp)
+        pon = O.site_keys([tuple(t) for t in exp["pon_set"]]) if "pon_set" in exp else None
+        com = O.site_keys([tuple(t) for t in exp["common_set"]]) if "common_set" in exp else None
+        recs, _ = O.call(batch, util.chunks_of(exp), p, p["germline_snv_prior"], pon, com, util.phase_of(exp))
+        phased = util.phase_of(exp) is not None
+        out = tmp_path / (case + ".vcf")
+        vcflib.dump_records(str(out), "#HEADER", [exp["contig"]], {exp["contig"]: recs}, phased)
+        assert out.read_text() == exp["vcf_text"], case
+        assert (tmp_path / (case + ".single_molecule_mutations.vcf")).read_text() == exp["sm_vcf_text"], case
+        # and the python printer agrees line by line
+        ref_out = tmp_path / (case + ".py.vcf")
+        (vcflib.dump_phased_sbs if phased else vcflib.dump_sbs)(str(ref_out), "#HEADER", [exp["contig"]],
+                                                                  {exp["contig"]: caller.records_to_tuples(exp["contig"], recs)})
+        assert ref_out.read_text() == out.read_text()
