@@ -47,6 +47,8 @@ def _load():
         L.vcf_format_records.restype = ctypes.c_int64
         L.vcf_format_records.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_int64]
+        L.bam_ref_bytes.restype = ctypes.c_void_p
+        L.bam_ref_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
         L.bam_free.restype = None
         L.bam_free.argtypes = [ctypes.c_void_p]
         L.bam_write.restype = ctypes.c_int
@@ -68,35 +70,55 @@ class BamFile:
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         h = L.bam_load_threads(path.encode(), int(threads))
+        self._h = h            # the big arrays of the batches are views into the library's memory
+        self._L = L
+        err = L.bam_error(h).decode()
+        if err:
+            raise ValueError("{}: {}".format(path, err))
+        if L.bam_count(h, 0):
+            # the reference does line.get_tag("cs") on every record (bamlib.py:32)
+            raise KeyError("tag 'cs' not present in {} records of {}".format(L.bam_count(h, 0), path))
+        if L.bam_count(h, 2):
+            raise ValueError("{} is not coordinate sorted".format(path))
+        self.header_text = L.bam_header_text(h).decode("utf-8", "replace")
+        self.tname2tsize = {}
+        self.batches = {}
+
+        def view(i, which, n):
+            if n == 0:
+                return np.zeros(0, np.uint8)
+            buf = (ctypes.c_uint8 * n).from_address(L.bam_ref_bytes(h, i, which))
+            a = np.frombuffer(buf, dtype=np.uint8)
+            a.flags.writeable = True
+            return a
+
+        for i in range(L.bam_n_ref(h)):
+            name = L.bam_ref_name(h, i).decode()
+            length = L.bam_ref_len(h, i)
+            self.tname2tsize[name] = length
+            n = L.bam_ref_nreads(h, i)
+            tot = L.bam_ref_bases_padded(h, i)
+            csb = L.bam_ref_cs_bytes(h, i)
+            a = dict(tstart=np.zeros(n, np.int32), tend=np.zeros(n, np.int32), qstart=np.zeros(n, np.int32),
+                     qlen=np.zeros(n, np.int32), mapq=np.zeros(n, np.uint8), flag=np.zeros(n, np.uint16),
+                     qid=np.zeros(n, np.int32), qoff=np.zeros(n, np.int64), cs_off=np.zeros(n + 1, np.int64),
+                     tp=np.zeros(n, np.uint8))
+            L.bam_ref_copy(h, i, _p(a["tstart"]), _p(a["tend"]), _p(a["qstart"]), _p(a["qlen"]), _p(a["mapq"]),
+                           _p(a["flag"]), _p(a["qid"]), _p(a["qoff"]), _p(a["cs_off"]), None, None, None, _p(a["tp"]))
+            a["seq"] = view(i, 0, tot // 2)
+            a["bq"] = view(i, 1, tot)
+            a["cs"] = view(i, 2, csb)
+            b = ReadBatch(name=name, length=length, **a)
+            b._owner = self        # keeps the library's memory alive as long as the batch is
+            self.batches[name] = b
+
+    def __del__(self):
         try:
-            err = L.bam_error(h).decode()
-            if err:
-                raise ValueError("{}: {}".format(path, err))
-            if L.bam_count(h, 0):
-                # the reference does line.get_tag("cs") on every record (bamlib.py:32)
-                raise KeyError("tag 'cs' not present in {} records of {}".format(L.bam_count(h, 0), path))
-            if L.bam_count(h, 2):
-                raise ValueError("{} is not coordinate sorted".format(path))
-            self.header_text = L.bam_header_text(h).decode("utf-8", "replace")
-            self.tname2tsize = {}
-            self.batches = {}
-            for i in range(L.bam_n_ref(h)):
-                name = L.bam_ref_name(h, i).decode()
-                length = L.bam_ref_len(h, i)
-                self.tname2tsize[name] = length
-                n = L.bam_ref_nreads(h, i)
-                tot = L.bam_ref_bases_padded(h, i)
-                csb = L.bam_ref_cs_bytes(h, i)
-                a = dict(tstart=np.zeros(n, np.int32), tend=np.zeros(n, np.int32), qstart=np.zeros(n, np.int32),
-                         qlen=np.zeros(n, np.int32), mapq=np.zeros(n, np.uint8), flag=np.zeros(n, np.uint16),
-                         qid=np.zeros(n, np.int32), qoff=np.zeros(n, np.int64), cs_off=np.zeros(n + 1, np.int64),
-                         seq=np.zeros(tot // 2, np.uint8), bq=np.zeros(tot, np.uint8), cs=np.zeros(csb, np.uint8),
-                         tp=np.zeros(n, np.uint8))
-                L.bam_ref_copy(h, i, *[_p(a[k]) for k in ("tstart", "tend", "qstart", "qlen", "mapq", "flag", "qid",
-                                                           "qoff", "cs_off", "seq", "bq", "cs", "tp")])
-                self.batches[name] = ReadBatch(name=name, length=length, **a)
-        finally:
-            L.bam_free(h)
+            if getattr(self, "_h", None):
+                self._L.bam_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def sample(self):
         """SM of the first @RG line (bamlib.get_sample, bamlib.py:89-106)."""

@@ -545,8 +545,16 @@ void bam_ref_copy(void* h, int64_t i, int32_t* tstart, int32_t* tend, int32_t* q
     cp(tstart, C.tstart.data(), n * 4); cp(tend, C.tend.data(), n * 4); cp(qstart, C.qstart.data(), n * 4);
     cp(qlen, C.qlen.data(), n * 4); cp(mapq, C.mapq.data(), n); cp(flag, C.flag.data(), n * 2);
     cp(qid, C.qid.data(), n * 4); cp(qoff, C.qoff.data(), n * 8); cp(cs_off, C.cs_off.data(), (n + 1) * 8);
-    cp(seq, C.seq.data(), C.seq.size()); cp(bq, C.bq.data(), C.bq.size()); cp(cs, C.cs.data(), C.cs.size());
+    if (seq) cp(seq, C.seq.data(), C.seq.size());
+    if (bq) cp(bq, C.bq.data(), C.bq.size());
+    if (cs) cp(cs, C.cs.data(), C.cs.size());
     cp(tp, C.tp.data(), n);
+}
+
+// the three big arrays of a contig in place (valid until bam_free): 0 seq, 1 bq, 2 cs
+const uint8_t* bam_ref_bytes(void* h, int64_t i, int which) {
+    const Contig& C = ((Bam*)h)->contigs[(size_t)i];
+    return which == 0 ? C.seq.data() : which == 1 ? C.bq.data() : C.cs.data();
 }
 
 void bam_free(void* h) { delete (Bam*)h; }
