@@ -952,6 +952,63 @@ done:
     return rc;
 }
 
+/* ---------------- phaselib.get_edges ---------------- */
+
+/* For every primary read with mapq >= min_mapq: the hetSNPs with tstart < pos <= tend (phaselib.py:38-44), the
+ * read's base and quality at each (cs2tpos2qbase, cslib.py:153-170: a deleted position has quality 0), and for every
+ * ordered pair with both qualities >= min_bq one count in cis1 / cis2 / trans1 / trans2 (phaselib.py:48-67).
+ * counts[(i * band + (j - i - 1)) * 4 + k] for the pair (i, j), i < j < i + 1 + band; returns ORC_ERR_CAPACITY if a
+ * read sees hetSNPs further apart in the list than the band. */
+int orc_edges(const orc_reads* R, int min_bq, int min_mapq, int64_t nhet, const int32_t* hpos, const uint8_t* href,
+              int64_t band, uint32_t* counts) {
+    int rc = ORC_OK;
+    for (int64_t r = 0; r < R->n && !rc; r++) {
+        if (R->flag[r] & 0x100) continue;            /* bamlib.py:17, phaselib.py:30 */
+        if (R->mapq[r] < min_mapq) continue;
+        int64_t idx = bisect_right32(hpos, nhet, R->tstart[r]);
+        int64_t jdx = bisect_right32(hpos, nhet, R->tend[r]);
+        if (jdx - idx < 2) continue;
+        orc_oplist ol;
+        rc = parse_cs(R, r, &ol);
+        if (rc) break;
+        orc_oplist* OL = (orc_oplist*)calloc((size_t)(r + 1), sizeof(orc_oplist)); /* base_at indexes by read */
+        if (!OL) { free(ol.ops); return ORC_ERR_NOMEM; }
+        OL[r] = ol;
+        int64_t k = jdx - idx;
+        int* state = (int*)malloc(sizeof(int) * (size_t)k);
+        int* ok = (int*)malloc(sizeof(int) * (size_t)k);
+        for (int64_t a = 0; a < k && !rc; a++) {
+            const int32_t pos = hpos[idx + a];
+            int qb = base_at(R, OL, r, pos);
+            if (qb == 0) { rc = ORC_ERR_COVER; break; }
+            int bq = 0;
+            if (qb != '-') { /* quality of the base: walk again for the query offset */
+                int64_t tpos = R->tstart[r], qpos = R->qstart[r];
+                for (int32_t o = 0; o < ol.nops; o++) {
+                    const orc_op* op = &ol.ops[o];
+                    if ((op->state == 1 || op->state == 2) && pos >= tpos + 1 && pos <= tpos + op->ref_len)
+                        bq = R->bq[R->qoff[r] + qpos + (pos - tpos - 1)];
+                    tpos += op->ref_len;
+                    qpos += op->alt_len;
+                }
+            }
+            ok[a] = bq >= min_bq;
+            state[a] = (qb == href[idx + a]) ? 0 : 1;
+        }
+        for (int64_t a = 0; a < k && !rc; a++) {
+            if (!ok[a]) continue;
+            for (int64_t b = a + 1; b < k; b++) {
+                if (!ok[b]) continue;
+                if (b - a - 1 >= band) { rc = ORC_ERR_CAPACITY; break; }
+                int kk = (!state[a] && !state[b]) ? 0 : (state[a] && state[b]) ? 1 : (!state[a] && state[b]) ? 2 : 3;
+                counts[((idx + a) * band + (b - a - 1)) * 4 + kk]++;
+            }
+        }
+        free(state); free(ok); free(ol.ops); free(OL);
+    }
+    return rc;
+}
+
 /* ---------------- leaf entry points used by the golden-vector tests ---------------- */
 
 /* cs2tuple of read r: fills state/ref_len/alt_len/ref/alt per op; returns nops or -err */

@@ -315,3 +315,38 @@ def normcounts(batch, chunks, params, refseq, germline_snv_prior=1 / (10 ** 3), 
         raise OracleError(rc)
     d_ccs, d_ref = tri_dicts(chars, ccs, ref)
     return d_ccs, d_ref, [int(x) for x in log]
+
+
+def edge_band(batch, hpos):
+    """Largest number of hetSNPs one read spans, minus one: the band the edge table needs."""
+    hp = np.asarray(hpos, np.int64)
+    k = np.searchsorted(hp, batch.tend, side="right") - np.searchsorted(hp, batch.tstart, side="right")
+    return max(1, int(k.max()) - 1 if k.shape[0] else 1)
+
+
+def edges_from_table(counts, band, hidx=None):
+    """Band table -> (edge_lst, edge2counts) as phaselib.get_edges returns them (keys that got a count, in natural order)."""
+    nz = np.flatnonzero(counts.reshape(-1, 4).sum(1))
+    edge2counts = {}
+    for e in nz:
+        i, d = int(e) // band, int(e) % band
+        j = i + 1 + d
+        key = (hidx[i], hidx[j]) if hidx is not None else (i, j)
+        edge2counts[key] = [float(x) for x in counts.reshape(-1, 4)[e]]
+    return sorted(edge2counts), edge2counts
+
+
+def edges(batch, hetsnp_lst, min_bq, min_mapq):
+    """Restated phaselib.get_edges.  hetsnp_lst: [(pos1, ref, alt)] sorted by position."""
+    L = lib()
+    L.orc_edges.restype = ctypes.c_int
+    hpos = np.array([h[0] for h in hetsnp_lst], np.int32)
+    href = np.array([ord(h[1]) for h in hetsnp_lst], np.uint8)
+    band = edge_band(batch, hpos)
+    counts = np.zeros(max(1, hpos.shape[0]) * band * 4, np.uint32)
+    R = _reads_struct(batch)
+    rc = L.orc_edges(ctypes.byref(R), ctypes.c_int(min_bq), ctypes.c_int(min_mapq), ctypes.c_int64(hpos.shape[0]), _ptr(hpos),
+                     _ptr(href), ctypes.c_int64(band), _ptr(counts))
+    if rc:
+        raise OracleError(rc)
+    return edges_from_table(counts, band)

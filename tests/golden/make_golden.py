@@ -390,6 +390,24 @@ def header_case():
     save("vcf_header", {"header": hdr, "header_phase": hdr_phase})
 
 
+def edges_case(case, cfg, min_bq=20, min_mapq=20, mutate=None):
+    """phaselib.get_edges on a synthetic contig and its heterozygous SNPs."""
+    s = synth.generate(cfg)
+    b = s.batch
+    if mutate is not None:
+        mutate(b)
+    bam = "/fake/{}.bam".format(case)
+    H.register_bam(bam, {b.name: b})
+    het = s.snp_gt == 1 if hasattr(s, "snp_gt") else None
+    hets = [(int(p) + 1, chr(r), chr(a)) for p, r, a, g in zip(s.snp_pos, s.snp_ref, s.snp_alt, s.snp_gt) if g in (1, 2)]
+    hets = sorted(set(hets))
+    edge_lst, e2c = H.run_reference_edges(bam, b.name, hets, min_bq, min_mapq)
+    exp = {"contig": b.name, "hetsnps": [list(h) for h in hets], "min_bq": min_bq, "min_mapq": min_mapq,
+           "edge_lst": edge_lst, "edge2counts": e2c}
+    print("   ", case, len(hets), "hetSNPs", len(edge_lst), "edges")
+    save(case, exp, batch=b)
+
+
 def norm_host_case(tmpdir="/tmp"):
     """The host side of `himut normcounts` around the worker: thresholds from the SBS file's header, SBS96 counts,
     genome trinucleotide counts, the output table and norm.log, the command line."""
@@ -524,6 +542,13 @@ def main():
         worker_case("worker_pon_params", small_cfg(109, contig_len=20000, name="chrN", som_rate=2e-4), md_threshold=52,
                     overrides=dict(min_bq=20, min_gq=10, min_qv=20, min_trim=0, min_mapq=30, min_hap_count=0,
                                    min_sequence_identity=0.8), create_pon=True)
+    if want("edges_basic"):
+        edges_case("edges_basic", small_cfg(401, contig_len=40000, snp_rate=4e-3, name="chr6"))
+    if want("edges_lowq"):
+        def lowmapq(b):
+            b.mapq[::5] = 10
+        edges_case("edges_lowq", small_cfg(402, contig_len=30000, snp_rate=6e-3, name="chr8", del_rate=2e-3, ins_rate=1e-3),
+                   min_bq=93, min_mapq=60, mutate=lowmapq)
     if want("norm_host"):
         norm_host_case()
     if want("norm_basic"):

@@ -231,3 +231,16 @@ def load_reference_norm_host():
     import himut.reflib
     import himut.vcflib
     return types.SimpleNamespace(mutlib=himut.mutlib, reflib=himut.reflib, vcflib=himut.vcflib)
+
+
+def run_reference_edges(bam_path, chrom, hetsnp_lst, min_bq, min_mapq):
+    """phaselib.get_edges of the reference (phaselib.py:16-67).  Returns (edge_lst, {edge: [4 counts]})."""
+    load_reference()
+    import scipy.stats
+    if not hasattr(scipy.stats, "binom_test"):      # removed from scipy >= 1.12; phaselib imports it by name (get_edges never calls it)
+        scipy.stats.binom_test = lambda x, n, p=0.5, alternative="two-sided": scipy.stats.binomtest(int(x), int(n), p, alternative).pvalue
+    import himut.phaselib as PL
+    hpos = [h[0] for h in hetsnp_lst]
+    hidx = {h: i for i, h in enumerate(hetsnp_lst)}
+    edge_lst, edge2counts = PL.get_edges(chrom, bam_path, min_bq, min_mapq, hpos, hetsnp_lst, hidx)
+    return [list(e) for e in edge_lst], {"{},{}".format(*k): [float(x) for x in v] for k, v in edge2counts.items()}

@@ -89,3 +89,16 @@ def test_normcounts_oracle_matches_reference(case):
         {k: v for k, v in exp["ccs_tri2count"].items() if v or k in O.TRI_LST}
     assert {k: v for k, v in rf.items() if v or k in O.TRI_LST} == \
         {k: v for k, v in exp["ref_tri2count"].items() if v or k in O.TRI_LST}
+
+
+EDGE_CASES = ["edges_basic", "edges_lowq"]
+
+
+@pytest.mark.parametrize("case", EDGE_CASES)
+def test_edges_oracle_matches_reference(case):
+    """phaselib.get_edges: the same edges in the same order with the same four counts."""
+    batch, exp = util.load_case(case)
+    hets = [tuple(h) for h in exp["hetsnps"]]
+    edge_lst, e2c = O.edges(batch, hets, exp["min_bq"], exp["min_mapq"])
+    assert [list(e) for e in edge_lst] == exp["edge_lst"]
+    assert {"{},{}".format(*k): v for k, v in e2c.items()} == exp["edge2counts"]
