@@ -47,7 +47,7 @@ EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_err
            "himut_set_gt_lut", "himut_set_chunks", "himut_set_site_set", "himut_set_phase", "himut_push_reads",
            "himut_run", "himut_get_records", "himut_get_log", "himut_get_stats", "himut_records_device",
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
-           "himut_get_normcounts", "himut_ref_tricounts"]
+           "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges"]
 
 _lib = None
 
@@ -107,6 +107,8 @@ def lib():
     L.himut_run_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.himut_get_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.himut_ref_tricounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.himut_run_edges.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int64, ctypes.c_void_p]
     for name in EXPORTS:
         if name not in ("himut_destroy", "himut_last_error"):
             getattr(L, name).restype = ctypes.c_int
@@ -239,6 +241,14 @@ class Context:
         log = np.zeros(14, np.int64)
         self._check(self._L.himut_get_normcounts(self._h, _ptr(ccs), _ptr(ref), _ptr(log)))
         return ccs, ref, [int(x) for x in log]
+
+    def run_edges(self, hpos, href, min_bq, min_mapq, band):
+        hpos = np.ascontiguousarray(hpos, np.int32)
+        href = np.ascontiguousarray(href, np.uint8)
+        counts = np.zeros(max(1, hpos.shape[0]) * int(band) * 4, np.uint32)
+        self._check(self._L.himut_run_edges(self._h, _ptr(hpos), _ptr(href), int(hpos.shape[0]), int(min_bq), int(min_mapq),
+                                            int(band), _ptr(counts)))
+        return counts
 
     def ref_tricounts(self):
         out = np.zeros(64, np.int64)

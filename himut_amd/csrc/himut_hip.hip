@@ -978,6 +978,47 @@ int himut_set_reference(himut_ctx* c, const uint8_t* seq, int64_t len, const uin
     });
 }
 
+int himut_run_edges(himut_ctx* c, const int32_t* hpos, const uint8_t* href, int64_t n_het, int min_bq, int min_mapq,
+                    int64_t band, uint32_t* counts) {
+    if (!c || !counts || band < 1 || n_het < 0 || (n_het && (!hpos || !href))) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int {
+        if (!c->have_reads) return fail(c, HIMUT_ERR_ARG, "himut_push_reads has not been called");
+        if (!c->have_params) return fail(c, HIMUT_ERR_ARG, "himut_set_params has not been called");   // the cs decode reads them
+        HCHECK(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        alloc_derived(c);
+        Reads R = make_reads(c);
+        Derived D = make_derived(c);
+        Scalars* sc = c->d_scalars.as<Scalars>();
+        const size_t nc = (size_t)std::max<int64_t>(n_het, 1) * (size_t)band * 4;
+        c->d_tmp.reserve(nc * 4 + 256);
+        upload(c->d_hpos, hpos, (size_t)n_het, st);
+        upload(c->d_href, href, (size_t)n_het, st);
+        HCHECK(hipEventRecord(c->ev[EV_START], st));
+        HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+        HCHECK(hipMemsetAsync(c->d_tmp.p, 0, nc * 4, st));
+        if (c->n > 0) {
+            run_parse_stage(c, R, D, sc);
+            if (n_het >= 2)
+                hipLaunchKernelGGL(k_edges, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->d_hpos.as<int32_t>(),
+                                   c->d_href.as<uint8_t>(), n_het, min_bq, min_mapq, band, c->d_tmp.as<uint32_t>(), &sc->err);
+        }
+        HCHECK(hipEventRecord(c->ev[EV_FINAL], st));
+        Scalars hs;
+        HCHECK(hipMemcpyAsync(counts, c->d_tmp.p, nc * 4, hipMemcpyDeviceToHost, st));
+        HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+        HCHECK(hipStreamSynchronize(st));
+        c->have_phase = false;        // d_hpos / d_href were reused
+        float f = 0;
+        (void)hipEventElapsedTime(&f, c->ev[EV_START], c->ev[EV_FINAL]);
+        memset(&c->stats, 0, sizeof(c->stats));
+        c->stats.ms_total = (double)f;
+        c->stats.n_reads = c->n; c->stats.read_bases = c->read_bases;
+        if (hs.err) return check_device_err(c, hs.err);
+        return HIMUT_OK;
+    });
+}
+
 int himut_ref_tricounts(himut_ctx* c, int64_t out[64]) {
     if (!c || !out) return HIMUT_ERR_ARG;
     return guarded(c, [&]() -> int {

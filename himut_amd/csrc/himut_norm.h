@@ -506,4 +506,67 @@ __global__ void __launch_bounds__(256) k_ref_tricounts(const uint8_t* seq, int64
     if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_edges: phaselib.get_edges (phaselib.py:16-67).  One wave per read, lanes = the heterozygous SNPs the read
+// spans (tstart < pos <= tend).  Every lane finds its SNP's segment by binary search over the read's segment
+// list and reads the base and its quality (a deleted position has quality 0, cslib.py:153-170); every ordered
+// pair of lanes whose qualities reach min_bq adds one to cis1 / cis2 / trans1 / trans2 of its edge.  The edge
+// table is banded: counts[(i * band + (j - i - 1)) * 4 + k].
+__global__ void __launch_bounds__(256) k_edges(Reads R, Derived D, const int32_t* hpos, const uint8_t* href, int64_t nhet,
+                                               int min_bq, int min_mapq, int64_t band, uint32_t* counts, int* err) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + uni((int)(threadIdx.x >> 6));
+    if (r >= R.n) return;
+    const ReadMeta Mv = D.meta[r];
+    const int mapq = uni((int)R.mapq[r]);
+    if ((uni(Mv.flags) & RF_SECONDARY) || mapq < min_mapq) return;
+    const int32_t tstart = uni(Mv.tstart), tend = uni(Mv.tend);
+    const int ns = uni(Mv.nseg);
+    const Seg* segs = D.segs + uni(Mv.segbase);
+    const int64_t qo = uni(Mv.qoff);
+    const int64_t idx = upper_bound(hpos, (int64_t)0, nhet, tstart), jdx = upper_bound(hpos, (int64_t)0, nhet, tend);
+    const int64_t k = jdx - idx;
+    if (k < 2) return;
+    for (int64_t a0 = 0; a0 < k; a0 += 64) {                   // lanes = SNPs a0 .. a0 + 63 as the first of a pair
+        const int64_t a = a0 + lane;
+        int st_a = 0;
+        bool ok_a = false;
+        auto look = [&](int64_t g, int& st, bool& ok) {          // state and usability of hetSNP g for this read
+            const int32_t rpos = hpos[g] - 1;
+            int lo = 0, hi = ns;                                // last segment that starts at or before rpos
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (segs[mid].t0 <= rpos) lo = mid; else hi = mid; }
+            const Seg sg = segs[lo];
+            int qb = 0, bq = 0;
+            if (rpos >= sg.t0 && rpos < sg.t0 + sg.len) {
+                if (sg.flags & SEG_DEL) qb = '-';
+                else {
+                    const int32_t q = sg.q0 + (rpos - sg.t0);
+                    qb = nib2char(nib_at(R.seq, qo + q));
+                    bq = R.bq[qo + q];
+                }
+            } else set_err(err, HIMUT_ERR_COVER);                // KeyError in tpos2qbase
+            ok = bq >= min_bq;
+            st = (qb == (int)href[g]) ? 0 : 1;
+        };
+        if (a < k) look(idx + a, st_a, ok_a);
+        // second of the pair: the SNPs behind a, a block of 64 at a time (one look-up per lane, then broadcast)
+        for (int64_t b0 = a0; b0 < k; b0 += 64) {
+            int st_bb = st_a;
+            bool ok_bb = ok_a;
+            if (b0 != a0) { st_bb = 0; ok_bb = false; if (b0 + lane < k) look(idx + b0 + lane, st_bb, ok_bb); }
+            const int nb = (int)min((int64_t)64, k - b0);
+            for (int t = 0; t < nb; t++) {
+                const int64_t b = b0 + t;
+                const int st_b = lane_val(st_bb, t);
+                if (!lane_val((int)ok_bb, t)) continue;
+                if (a < k && a < b && ok_a) {
+                    if (b - a - 1 >= band) { set_err(err, HIMUT_ERR_ARG); continue; }
+                    const int kk = (!st_a && !st_b) ? 0 : (st_a && st_b) ? 1 : (!st_a && st_b) ? 2 : 3;
+                    atomicAdd(&counts[((idx + a) * band + (b - a - 1)) * 4 + kk], 1u);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace himut

@@ -201,6 +201,15 @@ int himut_get_normcounts(himut_ctx* ctx, int64_t* ccs_tri, int64_t* ref_tri, int
  * last], letters A0 C1 G2 T3, purine centres already turned to the other strand (so 32 of the 64 bins fill). */
 int himut_ref_tricounts(himut_ctx* ctx, int64_t out[64]);
 
+/* ---- next row: phaselib.get_edges (phaselib.py:16-67) --------------------------------
+ * hpos / href: the contig's heterozygous SNPs (1-based position ascending, ASCII reference base), as
+ * vcflib.load_hetsnps lists them.  For every primary read with mapq >= min_mapq and every ordered pair (i, j) of
+ * the hetSNPs it spans whose base qualities are >= min_bq:  counts[(i * band + (j - i - 1)) * 4 + k] += 1 with
+ * k = 0 cis1 (ref, ref), 1 cis2 (other, other), 2 trans1 (ref, other), 3 trans2 (other, ref).  band must be at least the
+ * largest number of hetSNPs one read spans minus one (HIMUT_ERR_ARG otherwise). */
+int himut_run_edges(himut_ctx* ctx, const int32_t* hpos, const uint8_t* href, int64_t n_het, int min_bq, int min_mapq,
+                    int64_t band, uint32_t* counts);
+
 /* Dense pile of [p0, p1) over ALL pushed reads (no chunk restriction):
  * counts[(p - p0) * 6 + a], bqsum[(p - p0) * 4 + b]  (caller.py:44-72). */
 int himut_pile_counts(himut_ctx* ctx, int32_t p0, int32_t p1, uint32_t* counts, uint32_t* bqsum);
