@@ -152,14 +152,19 @@ def main():
     # N > 1: the final exchange of every step (record buffers of the step's contigs -> rank 0, RCCL over xGMI)
     # is pipelined: it runs while the next step scans.  All K exchanges complete inside the timed region.
     ex = None
-    if world > 1:
+    use_ex = world > 1 or os.environ.get("HIMUT_BENCH_FORCE_EXCHANGE") == "1"   # rehearsal of the N > 1 path on one rank
+    if use_ex:
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend, rank=0, world_size=1)
         ctx.run()                                           # untimed: sizes the exchange buffers
         cap = hdist.RecordExchange.plan(ctx.records_device()[1])
         ex = hdist.RecordExchange(rank, world, cap, depth=2)
 
     def step():
         ctx.run()
-        if world > 1:
+        if use_ex:
             _, n = ctx.records_device()
             if backend == "nccl":
                 ex.submit(n, ctx.log(), ctx=ctx)
@@ -186,7 +191,7 @@ def main():
     if gathered is not None:                                # untimed: host copy of the last step's gathered records
         gathered = (gathered[0], ex.last_records(gathered[0]))
     red_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    if use_ex:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -195,12 +200,12 @@ def main():
     log = ctx.log()
     totals = torch.tensor([st["positions"], log[1], st["read_bases"], st["n_records"]], dtype=torch.float64,
                           device=red_dev)
-    if world > 1:
+    if use_ex:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     positions, cand_sites, read_bases, n_records = [float(x) for x in totals.tolist()]
 
     if rank == 0:
-        if world > 1:   # every step's exchange delivered every rank's records
+        if gathered is not None:   # every step's exchange delivered every rank's records
             counts, last = gathered
             assert len(counts) == world and all(len(c) == a.steps for c in counts)
             assert sum(int(c[-1][0]) for c in counts) == int(n_records)
@@ -246,7 +251,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch, chunks, params, pon, com, a.cpu_sample_mb)
         print(json.dumps(out), flush=True)
     w.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
