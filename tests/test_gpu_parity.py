@@ -99,6 +99,17 @@ def test_oracle_parity_1mb_config1(worker):
     assert n > 1000 and log[1] >= n
 
 
+def test_config1_full_size_matches_reference(worker):
+    """BASELINE.json configs[0] at full size against the records the reference itself produced
+    for the same seeded input (tests/golden/config1_reference.json)."""
+    from himut_amd import caller
+    b, exp = util.load_config1_reference()
+    recs, log = _run_hip(worker, b, util.chunks_of(exp), util.params_of(exp))
+    got, want = caller.records_to_tuples(exp["contig"], recs), util.expected_tuples(exp)
+    assert got == want, _diff(got, want)
+    assert log == exp["log"]
+
+
 def test_oracle_parity_sets_and_boundaries(worker):
     from himut_amd.synth import SynthConfig
     cfg = SynthConfig(seed=2, contig_len=450_000, read_len_mean=6000, read_len_sd=1500, read_len_min=1500,

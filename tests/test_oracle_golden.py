@@ -102,3 +102,12 @@ def test_edges_oracle_matches_reference(case):
     edge_lst, e2c = O.edges(batch, hets, exp["min_bq"], exp["min_mapq"])
     assert [list(e) for e in edge_lst] == exp["edge_lst"]
     assert {"{},{}".format(*k): v for k, v in e2c.items()} == exp["edge2counts"]
+
+
+def test_config1_full_size_matches_reference():
+    """BASELINE.json configs[0] at full size: the oracle against the reference's own records."""
+    from himut_amd import caller
+    b, exp = util.load_config1_reference()
+    recs, log = O.call(b, util.chunks_of(exp), util.params_of(exp), util.CALL_DEFAULTS["germline_snv_prior"], None, None, None)
+    assert caller.records_to_tuples(exp["contig"], recs) == util.expected_tuples(exp)
+    assert log == exp["log"]

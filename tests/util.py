@@ -54,3 +54,16 @@ def phase_of(exp):
 
 def expected_tuples(exp):
     return [tuple([exp["contig"]] + r) for r in exp["records"]]
+
+
+def load_config1_reference():
+    """BASELINE.json configs[0] as the reference itself scanned it (tests/golden/config1_reference.py):
+    regenerates the 1 Mb / 30x batch from its seed, verifies it byte for byte against the stored
+    checksums, and returns (batch, fixture)."""
+    import zlib
+    from himut_amd import synth
+    exp = load_json("config1_reference")
+    b = synth.generate(synth.SynthConfig(**exp["synth"])).batch
+    for k, v in exp["checksums"].items():
+        assert zlib.crc32(np.ascontiguousarray(getattr(b, k)).view(np.uint8)) == v, "generated batch differs: " + k
+    return b, exp
