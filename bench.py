@@ -22,18 +22,16 @@ if ROOT not in sys.path:
 CHR20_LEN = 64_444_167
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # algorithmic HBM bytes per unit of work, per kernel (DESIGN.md "Kernels and their rooflines")
-STAGE_KERNEL = {"ms_parse": "k_parse_cs", "ms_bqsum": "k_bq_sum", "ms_emit": "k_propose",
+STAGE_KERNEL = {"ms_parse": "k_parse_cs", "ms_emit": "k_propose",
                 "ms_capture": "k_stream_capture", "ms_eval": "k_eval_columns"}
 
 
 def algorithmic_bytes(stage, st, cs_bytes):
     rb, pos, cand, slots = st["read_bases"], st["positions"], st["n_candidates"], st["column_slots"]
-    if stage == "ms_bqsum":      # every quality byte once
-        return rb * 1.0
     if stage == "ms_capture":    # every quality byte + every packed base once, one 2-byte slot per pile cell kept
         return rb * 1.5 + slots * 2.0
-    if stage == "ms_parse":      # cs text in, ~16 B per cs operation out (segments + mismatch list)
-        return cs_bytes * 1.0 + cs_bytes / 4.0 * 16.0
+    if stage == "ms_parse":      # every quality byte once; cs text in, ~16 B per cs operation out (segments + mismatch list)
+        return rb * 1.0 + cs_bytes * 1.0 + cs_bytes / 4.0 * 16.0
     if stage == "ms_emit":       # mismatch list in, mask word + candidate out per candidate
         return cs_bytes / 4.0 * 8.0 + cand * 16.0
     if stage == "ms_eval":       # column slots in, one 64-byte record out
@@ -182,8 +180,7 @@ def main():
     for _ in range(a.steps):
         step()
         st = ctx.stats()
-        for k in ("ms_total", "ms_parse", "ms_bqsum", "ms_hap", "ms_emit", "ms_index", "ms_capture", "ms_eval",
-                  "ms_finalize"):
+        for k in ("ms_total", "ms_parse", "ms_hap", "ms_emit", "ms_index", "ms_capture", "ms_eval", "ms_finalize"):
             stage_ms.setdefault(k, []).append(st[k])
     gathered = ex.drain() if ex is not None else None
     barrier()

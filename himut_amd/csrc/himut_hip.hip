@@ -58,7 +58,7 @@ void upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
 template <class T>
 void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) { upload(b, v.data(), v.size(), st); }
 
-enum { EV_START = 0, EV_FORK, EV_BQ0, EV_BQ1, EV_SIDE, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
+enum { EV_START = 0, EV_FORK, EV_SIDE, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
 
 }  // namespace
 
@@ -66,7 +66,7 @@ struct himut_ctx {
     int device = 0;
     int n_cus = 256;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;   // the quality sum runs here, beside the cs decode
+    hipStream_t side = nullptr;   // work that needs nothing from the cs decode runs here, beside it
     hipEvent_t ev[EV_COUNT] = {};
     std::string err;
 
@@ -97,7 +97,7 @@ struct himut_ctx {
     // derived
     DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs, d_order;
     // run state
-    DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
+    DevBuf d_mask, d_any, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2;
     // normcounts
     DevBuf d_refseq, d_live, d_callable, d_tri;
@@ -107,6 +107,11 @@ struct himut_ctx {
     std::vector<unsigned long long> h_tri;   // ccs[K^3], ref[K^3], log[16]
     bool have_norm = false;
     DevBuf d_dense_counts, d_dense_bqsum, d_tiles, d_cands, d_cands2, d_winlo, d_winhi, d_blkslots, d_blkoff, d_blktab, d_colstore, d_posbits_c, d_posrank, d_poppc, d_tmp2;
+    // capacities the candidate / column buffers were last sized for: a run whose counts fit them goes
+    // through without a host round trip in the middle (0 = not known yet)
+    int64_t cap_cand = 0, cap_slots = 0;
+    bool mask_clean = false;                 // d_mask / d_any hold zeros only (k_mask_emit leaves them so)
+    void* h_scalars = nullptr;               // pinned landing zone of the scalars block
     std::vector<himut_record> h_recs;
     bool h_recs_valid = false;
     int64_t n_out = 0;
@@ -242,14 +247,13 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
     // no chunk starts before its predecessor's end (the reference's chunking shares only the edge)
     c->chunks_in_order = true;
     for (int64_t k = 1; k < n; k++) if (cs[k] < ce[k - 1]) c->chunks_in_order = false;
-    // mask tiles (2048 cells each): the chunk their first cell belongs to
-    const int64_t n4 = ((int64_t)T.positions * 2 + 15) / 16;
-    const int64_t ntile = std::max<int64_t>(1, (n4 + 255) / 256);
+    // mask tiles (MASK_TILE_CELLS cells each): the chunk their first cell belongs to
+    const int64_t ntile = std::max<int64_t>(1, ((int64_t)T.positions + MASK_TILE_CELLS - 1) / MASK_TILE_CELLS);
     std::vector<MaskTile> mtile((size_t)ntile);
     {
         int64_t ck = 0;
         for (int64_t b = 0; b < ntile; b++) {
-            const int64_t cell = b * 2048;
+            const int64_t cell = b * MASK_TILE_CELLS;
             while (ck + 1 < n && c->maskoff[ck + 1] <= cell) ck++;
             MaskTile& m = mtile[(size_t)b];
             m.ck0 = (int32_t)ck; m.start0 = n > 0 ? cs[ck] : 0;
@@ -309,19 +313,16 @@ int check_device_err(himut_ctx* c, int bits) {
     return fail(c, HIMUT_ERR_ARG, "device error");
 }
 
-// side_work: more work for the second stream, done behind the quality sum while the cs decode still runs
+// side_work: work for the second stream, done while the quality stream + cs decode run
 template <class F>
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, F side_work) {
     hipStream_t st = c->stream;
-    // the quality stream (HBM bound) overlaps the cs decode (VALU bound)
+    // the side stream takes the work that needs nothing from the decode
     HCHECK(hipEventRecord(c->ev[EV_FORK], st));
+    hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
     HCHECK(hipStreamWaitEvent(c->side, c->ev[EV_FORK], 0));
-    HCHECK(hipEventRecord(c->ev[EV_BQ0], c->side));
-    hipLaunchKernelGGL(k_bq_sum, dim3(blocks_for(c->n, 4)), dim3(256), 0, c->side, R, D.bqsum);
-    HCHECK(hipEventRecord(c->ev[EV_BQ1], c->side));
     side_work(c->side);
     HCHECK(hipEventRecord(c->ev[EV_SIDE], c->side));
-    hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
     if (c->any_longcs)
         hipLaunchKernelGGL(k_check_longcs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, &sc->err);
     HCHECK(hipStreamWaitEvent(st, c->ev[EV_SIDE], 0));
@@ -346,7 +347,13 @@ void alloc_derived(himut_ctx* c) {
     c->d_scalars.reserve(sizeof(Scalars));
 }
 
-int do_run(himut_ctx* c) {
+// One pass of the scan.  spec: the candidate and column-slot buffers keep the capacities of an earlier run
+// (cap_cand, cap_slots) and every kernel behind the candidate count takes the count from device memory, so
+// the host launches the whole run without waiting in the middle; *overflow is set if a count did not fit
+// (the caller runs again with exact sizes).  Otherwise the host waits for the counts where it needs them
+// and sizes the buffers with 25 % of headroom for the runs that follow.
+int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
+    *overflow = false;
     if (!c->have_params) return fail(c, HIMUT_ERR_ARG, "himut_set_params has not been called");
     if (!c->have_lut) return fail(c, HIMUT_ERR_ARG, "himut_set_gt_lut has not been called");
     if (!c->have_reads) return fail(c, HIMUT_ERR_ARG, "himut_push_reads has not been called");
@@ -367,11 +374,20 @@ int do_run(himut_ctx* c) {
     c->params.unique_qnames = c->unique_qnames ? 1 : 0;
 
     ChunkTables T = upload_chunks(c, c->cstart, c->cend);
+    // the sorted-chunk path writes the candidates in their final order straight from the mask: only that one
+    // has nothing between the count and its consumers that needs the count on the host
+    const bool spec = allow_spec && c->chunks_in_order && c->cap_cand > 0 && c->cap_slots > 0 && T.positions > 0 && c->n > 0;
     alloc_derived(c);
     const int64_t n4 = ((int64_t)T.positions * 2 + 15) / 16;     // the mask in 16-byte pieces (8 positions each)
     const size_t mask_bytes = (size_t)n4 * 16;
-    const unsigned mtiles = blocks_for(n4, 256);
+    const int64_t anyw = ((int64_t)T.positions + 31) / 32;        // summary bitmap: one bit per mask cell
+    const unsigned mtiles = blocks_for(anyw, 256);
+    const void* mask_was = c->d_mask.p; const void* any_was = c->d_any.p;
     c->d_mask.reserve(mask_bytes + 64);
+    c->d_any.reserve((size_t)anyw * 4 + 64);
+    // the emit sweep zeroes what the propose kernel set: a buffer that went through a whole run is clean
+    const bool clear_mask = !c->mask_clean || mask_was != c->d_mask.p || any_was != c->d_any.p;
+    c->mask_clean = false;
     c->d_tilecnt.reserve((size_t)mtiles * 4 + 64);
     c->d_tileoff2.reserve((size_t)mtiles * 4 + 64);
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
@@ -394,12 +410,18 @@ int do_run(himut_ctx* c) {
     c->d_winhi.reserve((size_t)nblk * 4 + 64);
     if (c->n > 0)
         run_parse_stage(c, R, D, sc, [&](hipStream_t side) {
-            HCHECK(hipMemsetAsync(c->d_mask.p, 0, mask_bytes, side));
+            if (clear_mask) {
+                HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, side));
+                HCHECK(hipMemsetAsync(c->d_any.p, 0, c->d_any.cap, side));
+            }
             hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, side, R, nblk,
                                c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>());
         });
     else {
-        HCHECK(hipMemsetAsync(c->d_mask.p, 0, mask_bytes, st));
+        if (clear_mask) {
+            HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, st));
+            HCHECK(hipMemsetAsync(c->d_any.p, 0, c->d_any.cap, st));
+        }
         HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
     }
     if (phase && T.npairs > 0)
@@ -407,52 +429,61 @@ int do_run(himut_ctx* c) {
     HCHECK(hipEventRecord(c->ev[EV_HAP], st));
     if (c->n > 0)
         hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, C, H, c->params,
-                           c->d_mask.as<uint32_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
+                           c->d_mask.as<uint32_t>(), c->d_any.as<uint32_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
     // the candidates = the set bits of the mask: bits per tile, then a scan
     size_t scan_tiles = 0;
     uint32_t last_tcnt = 0, last_toff = 0;
-    if (n4 > 0) {
-        hipLaunchKernelGGL(k_mask_count, dim3(mtiles), dim3(256), 0, st, c->d_mask.as<uint4>(), n4, c->d_tilecnt.as<uint32_t>());
+    if (anyw > 0) {
+        hipLaunchKernelGGL(k_mask_count, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
+                           c->d_tilecnt.as<uint32_t>());
         HCHECK(rocprim::exclusive_scan(nullptr, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
                                        (size_t)mtiles, rocprim::plus<uint32_t>(), st));
         c->d_tmp2.reserve(scan_tiles + 256);
         HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
                                        (size_t)mtiles, rocprim::plus<uint32_t>(), st));
-        HCHECK(hipMemcpyAsync(&last_tcnt, c->d_tilecnt.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
-        HCHECK(hipMemcpyAsync(&last_toff, c->d_tileoff2.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
+        if (!spec) {
+            HCHECK(hipMemcpyAsync(&last_tcnt, c->d_tilecnt.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
+            HCHECK(hipMemcpyAsync(&last_toff, c->d_tileoff2.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
+        }
     }
     HCHECK(hipEventRecord(c->ev[EV_EMIT], st));
 
-    // exact number of candidate evaluations -> record capacity
-    Scalars hs;
-    HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
-    HCHECK(hipStreamSynchronize(st));
-    if (hs.err) return check_device_err(c, hs.err);
-    const int64_t ncand = (int64_t)last_toff + last_tcnt;
-    c->d_recs.reserve((size_t)(ncand + 1) * sizeof(himut_record));
-    c->d_recs_out.reserve((size_t)(ncand + 1) * sizeof(himut_record));
+    // number of candidate evaluations -> record capacity
+    Scalars& hs = *reinterpret_cast<Scalars*>(c->h_scalars);
+    int64_t ncap = c->cap_cand, nreserve = c->cap_cand;       // grid / scan extent, buffer capacity (records)
+    if (!spec) {
+        HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+        HCHECK(hipStreamSynchronize(st));
+        if (hs.err) return check_device_err(c, hs.err);
+        ncap = (int64_t)last_toff + last_tcnt;
+        nreserve = ncap + ncap / 4 + 1024;
+    }
+    c->d_recs.reserve((size_t)(nreserve + 1) * sizeof(himut_record));
+    c->d_recs_out.reserve((size_t)(nreserve + 1) * sizeof(himut_record));
+    const unsigned long long* ncand_dev = &sc->ncand;
 
     size_t sort_tmp = 0, scan_tmp = 0;
-    if (ncand > 0) {
+    size_t slot_cap = 0;
+    if (ncap > 0) {
         // candidates in the order of the final records (tpos, chunk, ref, alt)
-        c->d_keys.reserve((size_t)ncand * 8); c->d_keys2.reserve((size_t)ncand * 8);
-        c->d_cands.reserve((size_t)ncand * sizeof(Cand) + 256);
-        c->d_cands2.reserve((size_t)ncand * sizeof(Cand) + 256);
-        c->d_emit.reserve((size_t)ncand * 4); c->d_pos.reserve((size_t)ncand * 4);
+        c->d_keys.reserve((size_t)nreserve * 8); c->d_keys2.reserve((size_t)nreserve * 8);
+        c->d_cands.reserve((size_t)nreserve * sizeof(Cand) + 256);
+        c->d_cands2.reserve((size_t)nreserve * sizeof(Cand) + 256);
+        c->d_emit.reserve((size_t)nreserve * 4); c->d_pos.reserve((size_t)nreserve * 4);
         HCHECK(rocprim::exclusive_scan(nullptr, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
-                                       (size_t)ncand, rocprim::plus<uint32_t>(), st));
+                                       (size_t)ncap, rocprim::plus<uint32_t>(), st));
         if (c->chunks_in_order) {
-            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_mask.as<uint4>(), n4, c->d_tileoff2.as<uint32_t>(),
-                               C, c->d_cands2.as<Cand>(), c->d_keys2.as<uint64_t>());
+            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
+                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands2.as<Cand>(), c->d_keys2.as<uint64_t>(), ncap, &sc->ncand);
             c->d_tmp.reserve(scan_tmp + 256);
         } else {
-            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_mask.as<uint4>(), n4, c->d_tileoff2.as<uint32_t>(),
-                               C, c->d_cands.as<Cand>(), c->d_keys.as<uint64_t>());
+            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
+                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(), c->d_keys.as<uint64_t>(), ncap, &sc->ncand);
             HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
-                                             c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
+                                             c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
             c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
             HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
-                                             c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncand, 0, 60, st));
+                                             c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
         }
         // bitmap of candidate positions + rank index + per unique position window / column offset
         // the bitmap is probed at every position a read covers, so it spans reads as well as chunks
@@ -465,7 +496,7 @@ int do_run(himut_ctx* c) {
         c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
         c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
         HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
-        hipLaunchKernelGGL(k_candpos_set, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand,
+        hipLaunchKernelGGL(k_candpos_set, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand_dev, ncap,
                            c->d_posbits_c.as<uint32_t>());
         // rank[w] for w = 0 .. nwords (the last entry is the number of unique candidate positions)
         hipLaunchKernelGGL(k_word_popc, dim3(blocks_for(nwords + 1, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
@@ -487,20 +518,24 @@ int do_run(himut_ctx* c) {
         hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
                            c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_blkoff.as<uint32_t>(), nblk,
                            c->d_blktab.as<BlockTab>());
-        uint32_t last_off = 0, last_n = 0;
-        HCHECK(hipMemcpyAsync(&last_off, c->d_blkoff.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
-        HCHECK(hipMemcpyAsync(&last_n, c->d_blkslots.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
-        HCHECK(hipStreamSynchronize(st));
-        const size_t nslots = (size_t)last_off + last_n;
-        c->d_colstore.reserve(nslots * 2 + 256);
-        c->stats.column_slots = (int64_t)nslots;
-        if (nslots) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, nslots, st));
+        size_t slot_reserve = (size_t)c->cap_slots;
+        slot_cap = (size_t)c->cap_slots;
+        if (!spec) {
+            uint32_t last_off = 0, last_n = 0;
+            HCHECK(hipMemcpyAsync(&last_off, c->d_blkoff.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
+            HCHECK(hipMemcpyAsync(&last_n, c->d_blkslots.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
+            HCHECK(hipStreamSynchronize(st));
+            slot_cap = (size_t)last_off + last_n;
+            slot_reserve = slot_cap + slot_cap / 4 + 4096;
+        }
+        c->d_colstore.reserve(slot_reserve * 2 + 256);
+        if (slot_cap) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, slot_cap, st));
         PosIndex X;
         X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
         X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
         CaptureArgs G;
-        G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)nslots;
-        G.r_begin = 0; G.r_end = c->n; G.callable = nullptr;
+        G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)slot_cap;
+        G.r_begin = 0; G.r_end = c->n; G.callable = nullptr; G.err = &sc->err;
         HCHECK(hipEventRecord(c->ev[EV_INDEX], st));
         hipLaunchKernelGGL(k_stream_capture<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
         HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
@@ -509,45 +544,50 @@ int do_run(himut_ctx* c) {
         A.S.pon = c->d_pon.as<uint64_t>(); A.S.npon = c->npon; A.S.com = c->d_com.as<uint64_t>(); A.S.ncom = c->ncom;
         A.S.posbits = c->d_posbits.as<uint32_t>(); A.S.nposbits = c->nposbits;
         A.lut = c->d_lut.as<GtLut>();
-        A.cands = c->d_cands2.as<Cand>(); A.ncand = ncand;
+        A.cands = c->d_cands2.as<Cand>(); A.ncand = ncap; A.ncand_dev = ncand_dev;
         A.R = R; A.D = D; A.C = C; A.H = H; A.X = X;
-        A.colstore = c->d_colstore.as<uint16_t>();
+        A.colstore = c->d_colstore.as<uint16_t>(); A.nslots = (int64_t)slot_cap;
         A.recs = c->d_recs.as<himut_record>();
         A.err = &sc->err;
-        if (phase) hipLaunchKernelGGL(k_eval_columns<true>, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, A);
-        else hipLaunchKernelGGL(k_eval_columns<false>, dim3(blocks_for(ncand, 256)), dim3(256), 0, st, A);
+        if (phase) hipLaunchKernelGGL(k_eval_columns<true>, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(k_eval_columns<false>, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, A);
     } else {
         HCHECK(hipEventRecord(c->ev[EV_INDEX], st));
         HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
     }
     HCHECK(hipEventRecord(c->ev[EV_SWEEP], st));
 
-    // ---- finalisation: order, cross-chunk som_seen, counters, compaction
-    int64_t nrec = ncand;  // every set mask bit yields exactly one evaluation
-    if (nrec > 0) {
-        const unsigned nb = blocks_for(nrec, 256);
+    // ---- finalisation: order, cross-chunk som_seen, counters, compaction (every set mask bit is one evaluation)
+    if (ncap > 0) {
+        const unsigned nb = blocks_for(ncap, 256);
         hipLaunchKernelGGL(k_resolve_seen, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
-                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, nrec);
+                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, ncand_dev, ncap);
         hipLaunchKernelGGL(k_finalize_flags, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
-                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, nrec, c->d_emit.as<uint32_t>(), sc->log);
+                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, ncand_dev, ncap, c->d_emit.as<uint32_t>(), sc->log);
         HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
-                                       (size_t)nrec, rocprim::plus<uint32_t>(), st));
+                                       (size_t)ncap, rocprim::plus<uint32_t>(), st));
         hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), (const uint32_t*)nullptr,
-                           c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), nrec, c->d_recs_out.as<himut_record>());
+                           c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), ncand_dev, ncap, c->d_recs_out.as<himut_record>());
+        hipLaunchKernelGGL(k_run_totals, dim3(1), dim3(64), 0, st, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), ncap,
+                           c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), nblk, &sc->nrec, &sc->reserved0);
     }
     if (c->n > 0)
         hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
     HCHECK(hipEventRecord(c->ev[EV_FINAL], st));
 
-    uint32_t last_emit = 0, last_pos = 0;
     HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
-    if (nrec > 0) {
-        HCHECK(hipMemcpyAsync(&last_emit, c->d_emit.as<uint32_t>() + (nrec - 1), 4, hipMemcpyDeviceToHost, st));
-        HCHECK(hipMemcpyAsync(&last_pos, c->d_pos.as<uint32_t>() + (nrec - 1), 4, hipMemcpyDeviceToHost, st));
-    }
     HCHECK(hipStreamSynchronize(st));
     if (hs.err) return check_device_err(c, hs.err);
-    c->n_out = nrec > 0 ? (int64_t)last_pos + last_emit : 0;
+    c->mask_clean = true;      // the emit sweep ran over every cell that was set (or nothing was set)
+    const int64_t ncand = ncap > 0 ? (int64_t)hs.ncand : 0;
+    const int64_t nslots = ncap > 0 ? (int64_t)hs.reserved0 : 0;
+    if (ncand > ncap || nslots > (int64_t)slot_cap) {   // only a run on kept capacities can get here
+        *overflow = true;
+        return HIMUT_OK;
+    }
+    if (!spec && c->chunks_in_order) { c->cap_cand = nreserve; c->cap_slots = (int64_t)(slot_cap + slot_cap / 4 + 4096); }
+    c->stats.column_slots = nslots;
+    c->n_out = ncap > 0 ? (int64_t)hs.nrec : 0;
     for (int k = 0; k < 15; k++) c->log[k] = (int64_t)hs.log[k];
     c->log[0] = (int64_t)hs.nccs;
 
@@ -555,7 +595,7 @@ int do_run(himut_ctx* c) {
     himut_run_stats& S = c->stats;
     S.ms_total = ms(EV_START, EV_FINAL);
     S.ms_parse = ms(EV_START, EV_PARSE);
-    S.ms_bqsum = c->n > 0 ? ms(EV_BQ0, EV_BQ1) : 0.0;
+    S.ms_bqsum = 0.0;
     S.ms_hap = ms(EV_PARSE, EV_HAP);
     S.ms_emit = ms(EV_HAP, EV_EMIT);
     S.ms_index = ms(EV_EMIT, EV_INDEX);
@@ -569,6 +609,16 @@ int do_run(himut_ctx* c) {
     S.n_candidates = ncand;
     S.n_records = c->n_out;
     return HIMUT_OK;
+}
+
+int do_run(himut_ctx* c) {
+    bool overflow = false;
+    int rc = do_run_once(c, true, &overflow);
+    if (rc == HIMUT_OK && overflow) {
+        c->cap_cand = c->cap_slots = 0;
+        rc = do_run_once(c, false, &overflow);
+    }
+    return rc;
 }
 
 }  // namespace
@@ -594,6 +644,7 @@ int himut_create(int device, himut_ctx** out) {
         HCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HCHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         for (auto& e : c->ev) HCHECK(hipEventCreate(&e));
+        HCHECK(hipHostMalloc(&c->h_scalars, sizeof(Scalars), hipHostMallocDefault));
         return HIMUT_OK;
     });
     if (rc) {
@@ -613,6 +664,7 @@ void himut_destroy(himut_ctx* c) {
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     delete c;
 }
 
@@ -934,7 +986,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
             X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
             CaptureArgs G;
             G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)nslots;
-            G.r_begin = rb; G.r_end = std::max(rb, re); G.callable = c->d_callable.as<uint32_t>();
+            G.r_begin = rb; G.r_end = std::max(rb, re); G.callable = c->d_callable.as<uint32_t>(); G.err = &sc->err;
             if (re > rb)
                 hipLaunchKernelGGL(k_stream_capture<true>, dim3(blocks_for(re - rb, 4)), dim3(256), 0, st, G);
             A.X = X; A.colstore = c->d_colstore.as<uint16_t>(); A.p_lo = p_lo; A.p_hi = p_hi;

@@ -2,10 +2,10 @@
 //
 // Pipeline for one contig (himut_run in himut_hip.hip launches them in order):
 //
-//   k_parse_cs         one wave per read, wave-parallel tokenizer: cs tag -> gapless segments +
-//                      mismatch list + identity (cslib.py:7-64, bamlib.py:47-63)
-//   k_bq_sum           one wave per read, 16-byte coalesced loads: sum of BQ over the whole
-//                      query (np.mean, bamlib.py:34-36); runs beside k_parse_cs on a second stream
+//   k_parse_cs         one wave per read: first the sum of BQ over the whole query with 16-byte
+//                      coalesced loads (np.mean, bamlib.py:34-36), then a wave-parallel tokenizer:
+//                      cs tag -> gapless segments + mismatch list + identity (cslib.py:7-64,
+//                      bamlib.py:47-63)
 //   k_read_hap         (--phase) one thread per (chunk, read): haplib.py:46-83
 //   k_propose          one wave per read: read filters of caller.py:310-317, cs vs SEQ check of
 //                      every substitution; lanes = mismatch entries: trim / mismatch-window
@@ -119,7 +119,7 @@ struct ChunkRec {
     int64_t pairbase;   // pairoff - rlo: + read index = the (chunk, read) pair
 };
 
-// what k_mask_emit needs about a mask tile (2048 cells): the chunk of its first cell
+// what k_mask_emit needs about a mask tile (MASK_TILE_CELLS cells): the chunk of its first cell
 struct MaskTile {
     int32_t ck0;      // chunk of the tile's first cell
     int32_t start0;   // its start
@@ -280,12 +280,17 @@ __device__ __forceinline__ uint32_t cs_pack4(uint32_t f) {                      
     return (g | (g >> 7) | (g >> 14) | (g >> 21)) & 15u;
 }
 
+__device__ __forceinline__ void bq_sum_read(const Reads& R, int64_t r, int lane, uint32_t* bqsum);
+
+// The wave first streams its read's qualities for the mean (bq_sum_read): waves in that phase are bound by
+// HBM, waves in the decode by VALU, and a CU holds both kinds at any time.
 __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
     __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
+    bq_sum_read(R, r, lane, D.bqsum);
     const int64_t cs0 = uni(R.cs_off[r]);
     const int64_t sb = (cs0 >> 1) + r;
     ReadMeta M;
@@ -535,13 +540,9 @@ __global__ void __launch_bounds__(256) k_check_longcs(Reads R, Derived D, int* e
 }
 
 // ---------------------------------------------------------------------------------------
-// k_bq_sum: one wave per read; streams the read's qualities with 16-byte coalesced loads
-// (np.mean of the whole query, bamlib.py:34-36).  Needs nothing from the cs decode, so it
-// runs on its own stream beside k_parse_cs: one is bound by HBM, the other by VALU.
-__global__ void __launch_bounds__(256) k_bq_sum(Reads R, uint32_t* bqsum) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + uni((int)(threadIdx.x >> 6));
-    if (r >= R.n) return;
+// bq_sum_read: the wave streams its read's qualities with 16-byte coalesced loads, four in flight
+// (np.mean of the whole query, bamlib.py:34-36).  First phase of k_parse_cs.
+__device__ __forceinline__ void bq_sum_read(const Reads& R, int64_t r, int lane, uint32_t* bqsum) {
     if (uni((int)R.flag[r]) & 0x100) return;
     const uint8_t* base = R.bq + uni(R.qoff[r]) + lane * 16;
     const int n = uni(R.qlen[r]);
@@ -630,7 +631,7 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
 // enumerated from the mask afterwards, so a wave never waits on its own stores.
 constexpr int EMIT_MAXC = 4;   // chunks of one read kept in registers
 
-__global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, Phase H, Params P, uint32_t* mask,
+__global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, Phase H, Params P, uint32_t* mask, uint32_t* anyb,
                                                  uint8_t* ccs_flag, int* err) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -740,6 +741,7 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
                     // 16 mask bits per position, two positions per 32-bit word
                     const int64_t cell = cmo[k] + (tp1 - cst[k]);
                     atomicOr(mask + (cell >> 1), (1u << bit) << ((cell & 1) ? 16 : 0));
+                    atomicOr(anyb + (cell >> 5), 1u << (cell & 31));
                 }
         } else {
             for (int64_t jj = hi - 1; jj >= 0 && C.rec[jj].pmaxend > ts; jj--) {
@@ -748,6 +750,7 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
                 if (phase && H.hap[qr.pairbase + r] == HAP_NONE) continue;
                 const int64_t cell = qr.maskoff + (tp1 - qr.start);
                 atomicOr(mask + (cell >> 1), (1u << bit) << ((cell & 1) ? 16 : 0));
+                atomicOr(anyb + (cell >> 5), 1u << (cell & 31));
             }
         }
     }
@@ -755,18 +758,22 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
 }
 
 // ---------------------------------------------------------------------------------------
-// The candidate list = the set bits of the mask.  Two sweeps over the mask (16 bytes = 8
-// positions per thread): bits per 2048-position tile, then -- after a scan of the tile
-// counts -- the candidates themselves, in mask order: chunk, position, then (ref, alt) in
-// ASCII order.  The sort key of a candidate == the sort key of its record: (tpos, chunk,
-// ref, alt), natsorted order of the reference's tuples (caller.py:622).
-__device__ __forceinline__ int popc128(const uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+// The candidate list = the set bits of the mask (16 bits per cell: one per (ref, alt)).  Cells
+// with a bit are few (one in ~150 at 30x), so k_propose also sets one bit per touched cell in a
+// summary bitmap and the two sweeps read that instead of the mask: bits per tile of 8192 cells
+// (a 32-bit summary word per thread), then -- after a scan of the tile counts -- the candidates
+// themselves, in mask order: chunk, position, then (ref, alt) in ASCII order.  The sort key of
+// a candidate == the sort key of its record: (tpos, chunk, ref, alt), natsorted order of the
+// reference's tuples (caller.py:622).  The emit sweep leaves mask and summary zeroed for the
+// next run.
+constexpr int MASK_TILE_CELLS = 8192;
 
-__global__ void __launch_bounds__(256) k_mask_count(const uint4* mask4, int64_t n4, uint32_t* tilecnt) {
+__global__ void __launch_bounds__(256) k_mask_count(const uint32_t* anyb, int64_t nwords, const uint16_t* mask16, uint32_t* tilecnt) {
     __shared__ int s_w[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int c = 0;
-    if (i < n4) c = popc128(mask4[i]);
+    uint32_t w = i < nwords ? anyb[i] : 0u;
+    while (w) { const int b = __ffs((int)w) - 1; w &= w - 1; c += __popc((uint32_t)mask16[i * 32 + b]); }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
@@ -774,32 +781,36 @@ __global__ void __launch_bounds__(256) k_mask_count(const uint4* mask4, int64_t 
     if (threadIdx.x == 0) tilecnt[blockIdx.x] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
 }
 
-__global__ void __launch_bounds__(256) k_mask_emit(const uint4* mask4, int64_t n4, const uint32_t* tileoff, Chunks C,
-                                                   Cand* cands, uint64_t* keys) {
+// cap: capacity of cands / keys (the host may have sized them before the count was known: nothing is
+// written past it, and the true count lands in *total for the host to compare with cap)
+__global__ void __launch_bounds__(256) k_mask_emit(uint32_t* anyb, int64_t nwords, uint16_t* mask16, const uint32_t* tileoff, Chunks C,
+                                                   Cand* cands, uint64_t* keys, int64_t cap, unsigned long long* total) {
     __shared__ int s_w[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (i < n4) v = mask4[i];
-    const int c = popc128(v);
+    uint32_t w = i < nwords ? anyb[i] : 0u;
+    int c = 0;
+    for (uint32_t x = w; x; x &= x - 1) c += __popc((uint32_t)mask16[i * 32 + (__ffs((int)x) - 1)]);
     const int incl = wave_incl_add(c, lane);
     if (lane == 63) s_w[wv] = incl;
     __syncthreads();
-    if (!c) return;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        *total = (unsigned long long)tileoff[blockIdx.x] + (unsigned long long)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+    if (!w) return;
+    anyb[i] = 0u;
     int64_t slot = (int64_t)tileoff[blockIdx.x] + (incl - c);
 #pragma unroll
     for (int k = 0; k < 4; k++) if (k < wv) slot += s_w[k];
-    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
     // the chunk of the tile's first cell comes with the tile; cells may run into the next chunks
-    int64_t cell = i * 8;
     const MaskTile mt = C.mtile[blockIdx.x];
     int64_t ck = mt.ck0;
     int64_t cbeg = mt.off0, cend_ = mt.off1;
     int32_t cstart = mt.start0;
-#pragma unroll
-    for (int p = 0; p < 8; p++, cell++) {
-        const uint32_t m = (words[p >> 1] >> ((p & 1) * 16)) & 0xffffu;
-        if (!m) continue;
+    while (w) {
+        const int b = __ffs((int)w) - 1; w &= w - 1;
+        const int64_t cell = i * 32 + b;
+        const uint32_t m = mask16[cell];
+        mask16[cell] = 0;
         while (cell >= cend_) { ck++; cbeg = cend_; cend_ = C.maskoff[ck + 1]; cstart = C.start[ck]; }
         const int32_t tpos = cstart + (int32_t)(cell - cbeg);
 #pragma unroll
@@ -807,9 +818,11 @@ __global__ void __launch_bounds__(256) k_mask_emit(const uint4* mask4, int64_t n
             const int ra = (0x1230 >> (4 * (rk >> 2))) & 15, aa = (0x1230 >> (4 * (rk & 3))) & 15;
             const int bit = (ra << 2) | aa;
             if ((m >> bit) & 1u) {
-                Cand cd; cd.tpos = tpos; cd.chunk_bit = ((uint32_t)ck << 4) | (uint32_t)bit;
-                cands[slot] = cd;
-                keys[slot] = ((uint64_t)(uint32_t)tpos << 28) | ((uint64_t)ck << 4) | (uint64_t)rk;
+                if (slot < cap) {
+                    Cand cd; cd.tpos = tpos; cd.chunk_bit = ((uint32_t)ck << 4) | (uint32_t)bit;
+                    cands[slot] = cd;
+                    keys[slot] = ((uint64_t)(uint32_t)tpos << 28) | ((uint64_t)ck << 4) | (uint64_t)rk;
+                }
                 slot++;
             }
         }
@@ -878,9 +891,16 @@ __device__ __forceinline__ uint32_t pos_rank(const PosIndex& X, int32_t rpos) {
     return X.rank[w] + (uint32_t)__popc(X.bits[w] & ((1u << (rpos & 31)) - 1u));
 }
 
-__global__ void __launch_bounds__(256) k_candpos_set(const Cand* cands, int64_t n, uint32_t* bits) {
+// The kernels behind the candidate count take it from device memory (*n_dev, clamped to the capacity the
+// grid was sized for): the host need not have seen it yet.
+__device__ __forceinline__ int64_t dev_count(const unsigned long long* n_dev, int64_t cap) {
+    const unsigned long long n = *n_dev;
+    return n < (unsigned long long)cap ? (int64_t)n : cap;
+}
+
+__global__ void __launch_bounds__(256) k_candpos_set(const Cand* cands, const unsigned long long* n_dev, int64_t cap, uint32_t* bits) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    if (j >= dev_count(n_dev, cap)) return;
     const int32_t rpos = cands[j].tpos - 1;
     if (rpos >= 0) atomicOr(bits + (rpos >> 5), 1u << (rpos & 31));
 }
@@ -927,6 +947,7 @@ struct CaptureArgs {
     int64_t nslots;
     int64_t r_begin, r_end;      // reads of this launch
     const uint32_t* callable;    // normcounts: one bit per query base (bit q of read r at word (qoff[r] + q) >> 5)
+    const int* err;              // a device error raised by an earlier kernel of the run: nothing is captured then
 };
 
 constexpr int CLQ = 128;    // candidate list entries per wave (circular, power of two)
@@ -965,7 +986,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     const Reads& R = A.R;
     const PosIndex& X = A.X;
     const int64_t r64 = A.r_begin + (int64_t)blockIdx.x * 4 + wv;
-    if (r64 >= A.r_end) return;
+    if (r64 >= A.r_end || uni(*A.err)) return;
     const int32_t r = (int32_t)r64;
     const ReadMeta Mv = A.D.meta[r];
     const int32_t qstart = uni(R.qstart[r]), qlen = uni(R.qlen[r]);
@@ -1335,13 +1356,15 @@ struct EvalArgs {
     SiteSets S;
     const GtLut* lut;
     const Cand* cands;       // sorted by record key
-    int64_t ncand;
+    int64_t ncand;           // capacity the grid covers; the count itself is *ncand_dev
+    const unsigned long long* ncand_dev;
     Reads R;
     Derived D;
     Chunks C;
     Phase H;
     PosIndex X;
     const uint16_t* colstore;
+    int64_t nslots;          // capacity of colstore
     himut_record* recs;      // record j belongs to candidate j
     int* err;
 };
@@ -1355,7 +1378,7 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
     if (tid < 4) s_prior[tid] = A.lut->prior[tid];
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + tid;
-    if (j >= A.ncand) return;
+    if (j >= dev_count(A.ncand_dev, A.ncand) || *A.err) return;
     const Cand cd = A.cands[j];
     const int32_t tpos = cd.tpos;
     const int chunk = (int)(cd.chunk_bit >> 4);
@@ -1366,6 +1389,8 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
     const uint32_t n = bt.ncnt & BT_N_MASK, stride = bt.ncnt >> 22;
     const int32_t lo = bt.lo;
     const uint16_t* col = A.colstore + ((int64_t)bt.boff + (int64_t)(u - bt.ufirst));
+    // a column past the capacity: the store was sized before the slot count was known and the host runs again
+    if (n && (int64_t)bt.boff + (int64_t)(u - bt.ufirst) + (int64_t)(n - 1) * (int64_t)stride >= A.nslots) return;
     const int min_bq = A.P.p.min_bq;
     const int32_t cs_ = A.C.start[chunk];
     // Only next to the chunk start can a read lie in the pile of the position without having
@@ -1756,8 +1781,10 @@ __global__ void __launch_bounds__(NT) k_pile_dense(DenseArgs A) {
 
 // som_seen across chunks (caller.py:244,347; bamlib.py:77): a candidate whose
 // tpos was already added by an EARLIER chunk is never proposed again.
-__global__ void __launch_bounds__(256) k_resolve_seen(himut_record* recs, const uint64_t* keys, const uint32_t* vals, int64_t n) {
+__global__ void __launch_bounds__(256) k_resolve_seen(himut_record* recs, const uint64_t* keys, const uint32_t* vals,
+                                                      const unsigned long long* n_dev, int64_t cap) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = dev_count(n_dev, cap);
     if (i >= n) return;
     const uint64_t tp = keys[i] >> 28;
     if (i > 0 && (keys[i - 1] >> 28) == tp) return;  // not a group head
@@ -1780,12 +1807,16 @@ __global__ void __launch_bounds__(256) k_resolve_seen(himut_record* recs, const 
 }
 
 // counters (caller.py:625-641) + output flags in sorted order
-__global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, const uint64_t* keys, const uint32_t* vals, int64_t n,
-                                                        uint32_t* emit, unsigned long long* log) {
+// emit[] is written for the whole capacity (zeros past the count), so that its scan can run over the capacity
+__global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, const uint64_t* keys, const uint32_t* vals,
+                                                        const unsigned long long* n_dev, int64_t cap, uint32_t* emit,
+                                                        unsigned long long* log) {
     __shared__ unsigned int s_log[16];
     if (threadIdx.x < 16) s_log[threadIdx.x] = 0;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = dev_count(n_dev, cap);
+    if (i >= n && i < cap) emit[i] = 0;
     if (i < n) {
         himut_record& rec = recs[vals ? vals[i] : (uint32_t)i];
         uint32_t e = 0;
@@ -1827,9 +1858,9 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
 }
 
 __global__ void __launch_bounds__(256) k_compact(const himut_record* recs, const uint32_t* vals, const uint32_t* emit,
-                                                 const uint32_t* pos, int64_t n, himut_record* out) {
+                                                 const uint32_t* pos, const unsigned long long* n_dev, int64_t cap, himut_record* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !emit[i]) return;
+    if (i >= dev_count(n_dev, cap) || !emit[i]) return;
     const uint4* src = reinterpret_cast<const uint4*>(recs + (vals ? vals[i] : (uint32_t)i));
     uint4 a = src[0], b = src[1], c = src[2], d = src[3];
     b.y &= 0xff00ffffu;  // flags byte (offset 22) -> 0
@@ -1843,6 +1874,15 @@ __global__ void __launch_bounds__(256) k_count_flags(const uint8_t* flags, int64
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, (unsigned long long)local);
+}
+
+// the totals the host reads once at the end of a run: records out (the scan of emit[] over the capacity),
+// column slots (the scan of the block slot counts)
+__global__ void k_run_totals(const uint32_t* emit, const uint32_t* pos, int64_t cap, const uint32_t* blkoff,
+                             const uint32_t* blkslots, int64_t nblk, unsigned long long* nrec, unsigned long long* nslots) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *nrec = cap > 0 ? (unsigned long long)pos[cap - 1] + emit[cap - 1] : 0ull;
+    *nslots = nblk > 0 ? (unsigned long long)blkoff[nblk - 1] + blkslots[nblk - 1] : 0ull;
 }
 
 }  // namespace himut

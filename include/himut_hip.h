@@ -132,8 +132,8 @@ typedef struct himut_record {
  * context's stream, in milliseconds). */
 typedef struct himut_run_stats {
     double ms_total;
-    double ms_parse;            /* k_parse_cs (cs decode) with k_bq_sum running beside it on a second stream */
-    double ms_bqsum;            /* k_bq_sum alone: whole-read BQ stream (qv); overlapped, already inside ms_parse */
+    double ms_parse;            /* k_parse_cs: whole-read BQ stream (qv) + cs decode, one wave per read */
+    double ms_bqsum;            /* 0: the quality stream is the first phase of k_parse_cs (kept for ABI layout) */
     double ms_hap;              /* k_read_hap (phase only) */
     double ms_emit;             /* k_propose (read filters, proposals -> mask), mask bit count + scan, k_window_index */
     double ms_index;            /* k_mask_emit (+ sort when chunks are out of order), position bitmap + rank,
