@@ -47,7 +47,7 @@ EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_err
            "himut_set_gt_lut", "himut_set_chunks", "himut_set_site_set", "himut_set_phase", "himut_push_reads",
            "himut_run", "himut_get_records", "himut_get_log", "himut_get_stats", "himut_records_device",
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
-           "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges"]
+           "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing"]
 
 _lib = None
 
@@ -107,6 +107,7 @@ def lib():
     L.himut_run_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.himut_get_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.himut_ref_tricounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.himut_set_stage_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.himut_run_edges.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int64, ctypes.c_void_p]
     for name in EXPORTS:
@@ -214,6 +215,10 @@ class Context:
         s = RunStats()
         self._check(self._L.himut_get_stats(self._h, ctypes.byref(s)))
         return s.as_dict()
+
+    def set_stage_timing(self, level):
+        """0: total only; 1: + column capture (default); 2: every stage (costs a few microseconds per event)."""
+        self._check(self._L.himut_set_stage_timing(self._h, int(level)))
 
     def records_device(self):
         p = ctypes.c_void_p()

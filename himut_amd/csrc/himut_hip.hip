@@ -58,7 +58,7 @@ void upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
 template <class T>
 void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) { upload(b, v.data(), v.size(), st); }
 
-enum { EV_START = 0, EV_FORK, EV_SIDE, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
+enum { EV_START = 0, EV_SIDE, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
 
 }  // namespace
 
@@ -110,6 +110,7 @@ struct himut_ctx {
     // capacities the candidate / column buffers were last sized for: a run whose counts fit them goes
     // through without a host round trip in the middle (0 = not known yet)
     int64_t cap_cand = 0, cap_slots = 0;
+    int timing = 1;                          // himut_set_stage_timing: 0 total only, 1 + the column capture, 2 every stage
     bool mask_clean = false;                 // d_mask / d_any hold zeros only (k_mask_emit leaves them so)
     void* h_scalars = nullptr;               // pinned landing zone of the scalars block
     std::vector<himut_record> h_recs;
@@ -129,8 +130,9 @@ struct Scalars {
     unsigned long long nccs;
     unsigned long long log[16];
     int err;
-    int pad;
+    int pad[23];             // 256 bytes: one aligned fill clears it
 };
+static_assert(sizeof(Scalars) == 256, "Scalars is cleared with one aligned fill");
 
 const char* err_text(int code) {
     switch (code) {
@@ -151,6 +153,7 @@ int fail(himut_ctx* c, int code, const std::string& msg) {
 template <class F>
 int guarded(himut_ctx* c, F f) {
     try {
+        (void)hipGetLastError();   // an error some earlier call left behind is not this call's
         return f();
     } catch (const HipFail& h) {
         char buf[512];
@@ -313,20 +316,25 @@ int check_device_err(himut_ctx* c, int bits) {
     return fail(c, HIMUT_ERR_ARG, "device error");
 }
 
+// stage events cost a barrier packet each (a few microseconds of queue time): only the ones asked for are recorded
+inline void stage_event(himut_ctx* c, int ev, int level, hipStream_t st) {
+    if (c->timing >= level) HCHECK(hipEventRecord(c->ev[ev], st));
+}
+
 // side_work: work for the second stream, done while the quality stream + cs decode run
 template <class F>
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, F side_work) {
     hipStream_t st = c->stream;
-    // the side stream takes the work that needs nothing from the decode
-    HCHECK(hipEventRecord(c->ev[EV_FORK], st));
-    hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err);
-    HCHECK(hipStreamWaitEvent(c->side, c->ev[EV_FORK], 0));
+    // the side stream takes the work that needs nothing from the decode (it starts behind EV_START: the
+    // previous run on this context is over by then)
+    hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err, c->d_ccs.as<uint8_t>());
+    HCHECK(hipStreamWaitEvent(c->side, c->ev[EV_START], 0));
     side_work(c->side);
     HCHECK(hipEventRecord(c->ev[EV_SIDE], c->side));
     if (c->any_longcs)
         hipLaunchKernelGGL(k_check_longcs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, &sc->err);
     HCHECK(hipStreamWaitEvent(st, c->ev[EV_SIDE], 0));
-    HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+    stage_event(c, EV_PARSE, 2, st);
 }
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {
     run_parse_stage(c, R, D, sc, [](hipStream_t) {});
@@ -400,7 +408,6 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
-    HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
     // window index for the column kernel, and the empty mask: neither needs the cs decode, so both
     // run behind the quality sum on the second stream
     int32_t maxend = 0;
@@ -408,8 +415,14 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
     c->d_winlo.reserve((size_t)nblk * 4 + 64);
     c->d_winhi.reserve((size_t)nblk * 4 + 64);
+    // bitmap of candidate positions: probed at every position a read covers, so it spans reads as well as chunks
+    int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
+    for (int32_t e : c->cend) maxpos = std::max(maxpos, e);
+    const int64_t nwords = ((int64_t)maxpos >> 5) + 2;
+    c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
     if (c->n > 0)
         run_parse_stage(c, R, D, sc, [&](hipStream_t side) {
+            HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, side));
             if (clear_mask) {
                 HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, side));
                 HCHECK(hipMemsetAsync(c->d_any.p, 0, c->d_any.cap, side));
@@ -422,11 +435,11 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
             HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, st));
             HCHECK(hipMemsetAsync(c->d_any.p, 0, c->d_any.cap, st));
         }
-        HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+        stage_event(c, EV_PARSE, 2, st);
     }
     if (phase && T.npairs > 0)
         hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
-    HCHECK(hipEventRecord(c->ev[EV_HAP], st));
+    stage_event(c, EV_HAP, 2, st);
     if (c->n > 0)
         hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, C, H, c->params,
                            c->d_mask.as<uint32_t>(), c->d_any.as<uint32_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
@@ -435,7 +448,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     uint32_t last_tcnt = 0, last_toff = 0;
     if (anyw > 0) {
         hipLaunchKernelGGL(k_mask_count, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
-                           c->d_tilecnt.as<uint32_t>());
+                           c->d_tilecnt.as<uint32_t>(), c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
         HCHECK(rocprim::exclusive_scan(nullptr, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
                                        (size_t)mtiles, rocprim::plus<uint32_t>(), st));
         c->d_tmp2.reserve(scan_tiles + 256);
@@ -446,7 +459,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
             HCHECK(hipMemcpyAsync(&last_toff, c->d_tileoff2.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
         }
     }
-    HCHECK(hipEventRecord(c->ev[EV_EMIT], st));
+    stage_event(c, EV_EMIT, 2, st);
 
     // number of candidate evaluations -> record capacity
     Scalars& hs = *reinterpret_cast<Scalars*>(c->h_scalars);
@@ -474,30 +487,27 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
                                        (size_t)ncap, rocprim::plus<uint32_t>(), st));
         if (c->chunks_in_order) {
             hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
-                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands2.as<Cand>(), c->d_keys2.as<uint64_t>(), ncap, &sc->ncand);
+                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands2.as<Cand>(), c->d_keys2.as<uint64_t>(), ncap, &sc->ncand,
+                               c->d_posbits_c.as<uint32_t>());
             c->d_tmp.reserve(scan_tmp + 256);
         } else {
             hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
-                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(), c->d_keys.as<uint64_t>(), ncap, &sc->ncand);
+                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(), c->d_keys.as<uint64_t>(), ncap, &sc->ncand,
+                               (uint32_t*)nullptr);
             HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
             c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
             HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
         }
-        // bitmap of candidate positions + rank index + per unique position window / column offset
-        // the bitmap is probed at every position a read covers, so it spans reads as well as chunks
-        int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
-        for (int32_t e : c->cend) maxpos = std::max(maxpos, e);
-        const int64_t nwords = ((int64_t)maxpos >> 5) + 2;
-        c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
+        // rank index of the position bitmap + per unique position window / column offset
         c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
         c->d_poppc.reserve((size_t)(nwords + 2) * 4 + 256);
         c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
         c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
-        HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
-        hipLaunchKernelGGL(k_candpos_set, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand_dev, ncap,
-                           c->d_posbits_c.as<uint32_t>());
+        if (!c->chunks_in_order)    // the in-order emit sweep has set the bits already
+            hipLaunchKernelGGL(k_candpos_set, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand_dev, ncap,
+                               c->d_posbits_c.as<uint32_t>());
         // rank[w] for w = 0 .. nwords (the last entry is the number of unique candidate positions)
         hipLaunchKernelGGL(k_word_popc, dim3(blocks_for(nwords + 1, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
                            nwords + 1, c->d_poppc.as<uint32_t>());
@@ -536,9 +546,9 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         CaptureArgs G;
         G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)slot_cap;
         G.r_begin = 0; G.r_end = c->n; G.callable = nullptr; G.err = &sc->err;
-        HCHECK(hipEventRecord(c->ev[EV_INDEX], st));
+        stage_event(c, EV_INDEX, 1, st);
         hipLaunchKernelGGL(k_stream_capture<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
-        HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
+        stage_event(c, EV_GATHER, 1, st);
         EvalArgs A;
         A.P = c->params;
         A.S.pon = c->d_pon.as<uint64_t>(); A.S.npon = c->npon; A.S.com = c->d_com.as<uint64_t>(); A.S.ncom = c->ncom;
@@ -552,10 +562,10 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         if (phase) hipLaunchKernelGGL(k_eval_columns<true>, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, A);
         else hipLaunchKernelGGL(k_eval_columns<false>, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, A);
     } else {
-        HCHECK(hipEventRecord(c->ev[EV_INDEX], st));
-        HCHECK(hipEventRecord(c->ev[EV_GATHER], st));
+        stage_event(c, EV_INDEX, 1, st);
+        stage_event(c, EV_GATHER, 1, st);
     }
-    HCHECK(hipEventRecord(c->ev[EV_SWEEP], st));
+    stage_event(c, EV_SWEEP, 2, st);
 
     // ---- finalisation: order, cross-chunk som_seen, counters, compaction (every set mask bit is one evaluation)
     if (ncap > 0) {
@@ -571,7 +581,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         hipLaunchKernelGGL(k_run_totals, dim3(1), dim3(64), 0, st, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), ncap,
                            c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), nblk, &sc->nrec, &sc->reserved0);
     }
-    if (c->n > 0)
+    if (c->n > 0 && anyw <= 0)   // no mask sweep ran: count the flagged reads here
         hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
     HCHECK(hipEventRecord(c->ev[EV_FINAL], st));
 
@@ -594,14 +604,16 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     auto ms = [&](int a, int b) { float f = 0; (void)hipEventElapsedTime(&f, c->ev[a], c->ev[b]); return (double)f; };
     himut_run_stats& S = c->stats;
     S.ms_total = ms(EV_START, EV_FINAL);
-    S.ms_parse = ms(EV_START, EV_PARSE);
     S.ms_bqsum = 0.0;
-    S.ms_hap = ms(EV_PARSE, EV_HAP);
-    S.ms_emit = ms(EV_HAP, EV_EMIT);
-    S.ms_index = ms(EV_EMIT, EV_INDEX);
-    S.ms_capture = ms(EV_INDEX, EV_GATHER);
-    S.ms_eval = ms(EV_GATHER, EV_SWEEP);
-    S.ms_finalize = ms(EV_SWEEP, EV_FINAL);
+    if (c->timing >= 1) S.ms_capture = ms(EV_INDEX, EV_GATHER);
+    if (c->timing >= 2) {
+        S.ms_parse = ms(EV_START, EV_PARSE);
+        S.ms_hap = ms(EV_PARSE, EV_HAP);
+        S.ms_emit = ms(EV_HAP, EV_EMIT);
+        S.ms_index = ms(EV_EMIT, EV_INDEX);
+        S.ms_eval = ms(EV_GATHER, EV_SWEEP);
+        S.ms_finalize = ms(EV_SWEEP, EV_FINAL);
+    }
     S.n_reads = c->n;
     S.read_bases = c->read_bases;
     S.positions = T.positions;
@@ -666,6 +678,13 @@ void himut_destroy(himut_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     delete c;
+}
+
+int himut_set_stage_timing(himut_ctx* c, int level) {
+    if (!c) return HIMUT_ERR_ARG;
+    if (level < 0 || level > 2) return fail(c, HIMUT_ERR_ARG, "stage timing level must be 0, 1 or 2");
+    c->timing = level;
+    return HIMUT_OK;
 }
 
 const char* himut_last_error(const himut_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -890,7 +909,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     HCHECK(hipMemsetAsync(c->d_tri.p, 0, (2 * ntri + 16) * 8, st));
     HCHECK(hipMemsetAsync(c->d_callable.p, 0, cwords * 4, st));
     if (c->n > 0) run_parse_stage(c, R, D, sc);
-    else HCHECK(hipEventRecord(c->ev[EV_PARSE], st));
+    else stage_event(c, EV_PARSE, 2, st);
     int32_t maxend = 0;
     for (int32_t e : c->cend) maxend = std::max(maxend, e);
     const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
@@ -1005,8 +1024,10 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     float f = 0;
     (void)hipEventElapsedTime(&f, c->ev[EV_START], c->ev[EV_FINAL]);
     c->stats.ms_total = (double)f;
-    (void)hipEventElapsedTime(&f, c->ev[EV_START], c->ev[EV_PARSE]);
-    c->stats.ms_parse = (double)f;
+    if (c->timing >= 2) {   // recorded by run_parse_stage only then (an unrecorded event leaves a sticky HIP error)
+        (void)hipEventElapsedTime(&f, c->ev[EV_START], c->ev[EV_PARSE]);
+        c->stats.ms_parse = (double)f;
+    }
     c->stats.n_reads = c->n; c->stats.read_bases = c->read_bases; c->stats.positions = T.positions;
     c->stats.column_slots = slots_total;
     c->have_norm = true;

@@ -284,12 +284,13 @@ __device__ __forceinline__ void bq_sum_read(const Reads& R, int64_t r, int lane,
 
 // The wave first streams its read's qualities for the mean (bq_sum_read): waves in that phase are bound by
 // HBM, waves in the decode by VALU, and a CU holds both kinds at any time.
-__global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err) {
+__global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
     __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
+    if (lane == 0) ccs[r] = 0;               // the flag k_propose raises for a read that may propose (num_ccs)
     bq_sum_read(R, r, lane, D.bqsum);
     const int64_t cs0 = uni(R.cs_off[r]);
     const int64_t sb = (cs0 >> 1) + r;
@@ -768,23 +769,32 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
 // next run.
 constexpr int MASK_TILE_CELLS = 8192;
 
-__global__ void __launch_bounds__(256) k_mask_count(const uint32_t* anyb, int64_t nwords, const uint16_t* mask16, uint32_t* tilecnt) {
-    __shared__ int s_w[4];
+// Also counts the reads k_propose flagged (num_ccs, caller.py:318-320): ccs[0 .. nreads), added to *nccs.
+__global__ void __launch_bounds__(256) k_mask_count(const uint32_t* anyb, int64_t nwords, const uint16_t* mask16, uint32_t* tilecnt,
+                                                    const uint8_t* ccs, int64_t nreads, unsigned long long* nccs) {
+    __shared__ int s_w[4], s_f[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int c = 0;
+    int c = 0, f = 0;
     uint32_t w = i < nwords ? anyb[i] : 0u;
     while (w) { const int b = __ffs((int)w) - 1; w &= w - 1; c += __popc((uint32_t)mask16[i * 32 + b]); }
+    for (int64_t j = i; j < nreads; j += (int64_t)gridDim.x * 256) f += ccs[j];
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d, 64); f += __shfl_xor(f, d, 64); }
+    if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = c; s_f[threadIdx.x >> 6] = f; }
     __syncthreads();
-    if (threadIdx.x == 0) tilecnt[blockIdx.x] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) {
+        tilecnt[blockIdx.x] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+        const int ft = s_f[0] + s_f[1] + s_f[2] + s_f[3];
+        if (ft) atomicAdd(nccs, (unsigned long long)ft);
+    }
 }
 
 // cap: capacity of cands / keys (the host may have sized them before the count was known: nothing is
 // written past it, and the true count lands in *total for the host to compare with cap)
+// posbits (optional): the bitmap of candidate positions (bit rpos = tpos - 1), zeroed by the host beforehand
 __global__ void __launch_bounds__(256) k_mask_emit(uint32_t* anyb, int64_t nwords, uint16_t* mask16, const uint32_t* tileoff, Chunks C,
-                                                   Cand* cands, uint64_t* keys, int64_t cap, unsigned long long* total) {
+                                                   Cand* cands, uint64_t* keys, int64_t cap, unsigned long long* total,
+                                                   uint32_t* posbits) {
     __shared__ int s_w[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -813,6 +823,7 @@ __global__ void __launch_bounds__(256) k_mask_emit(uint32_t* anyb, int64_t nword
         mask16[cell] = 0;
         while (cell >= cend_) { ck++; cbeg = cend_; cend_ = C.maskoff[ck + 1]; cstart = C.start[ck]; }
         const int32_t tpos = cstart + (int32_t)(cell - cbeg);
+        if (posbits && tpos >= 1) atomicOr(posbits + ((tpos - 1) >> 5), 1u << ((tpos - 1) & 31));
 #pragma unroll
         for (int rk = 0; rk < 16; rk++) {   // (ref, alt) in ASCII order A C G T = alleles 0 3 2 1
             const int ra = (0x1230 >> (4 * (rk >> 2))) & 15, aa = (0x1230 >> (4 * (rk & 3))) & 15;
@@ -1807,7 +1818,8 @@ __global__ void __launch_bounds__(256) k_resolve_seen(himut_record* recs, const 
 }
 
 // counters (caller.py:625-641) + output flags in sorted order
-// emit[] is written for the whole capacity (zeros past the count), so that its scan can run over the capacity
+// emit[] is written for the whole capacity (zeros past the count), so that its scan can run over the capacity.
+// Counters: one ballot per counter and wave, one shared-memory add per wave, one global add per block.
 __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, const uint64_t* keys, const uint32_t* vals,
                                                         const unsigned long long* n_dev, int64_t cap, uint32_t* emit,
                                                         unsigned long long* log) {
@@ -1817,28 +1829,30 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = dev_count(n_dev, cap);
     if (i >= n && i < cap) emit[i] = 0;
+    int slot = -1, slot2 = -1;     // the counters this record adds to (besides num_sbs, slot 1)
+    bool counted = false;
     if (i < n) {
         himut_record& rec = recs[vals ? vals[i] : (uint32_t)i];
         uint32_t e = 0;
         if (!(rec.flags & REC_SUPPRESSED)) {
-            atomicAdd(&s_log[1], 1u);  // num_sbs
+            counted = true;  // num_sbs
             if (rec.flags & REC_GERM) {
-                if (rec.gt_state == 1) atomicAdd(&s_log[2], 1u);
-                else if (rec.gt_state == 2) atomicAdd(&s_log[3], 1u);
-                else if (rec.gt_state == 3) atomicAdd(&s_log[4], 1u);
+                if (rec.gt_state == 1) slot = 2;
+                else if (rec.gt_state == 2) slot = 3;
+                else if (rec.gt_state == 3) slot = 4;
             } else {
                 const int st = rec.status;
-                if (st == HIMUT_ST_HET || st == HIMUT_ST_HETALT || st == HIMUT_ST_HOMALT) atomicAdd(&s_log[5], 1u);
-                else if (st == HIMUT_ST_INDEL) atomicAdd(&s_log[7], 1u);
+                if (st == HIMUT_ST_HET || st == HIMUT_ST_HETALT || st == HIMUT_ST_HOMALT) slot = 5;
+                else if (st == HIMUT_ST_INDEL) slot = 7;
                 else {
-                    atomicAdd(&s_log[6], 1u);  // num_homref_sbs
-                    if (st == HIMUT_ST_LOWGQ) atomicAdd(&s_log[8], 1u);
-                    else if (st == HIMUT_ST_LOWBQ) atomicAdd(&s_log[9], 1u);
-                    else if (st == HIMUT_ST_PON) atomicAdd(&s_log[10], 1u);
-                    else if (st == HIMUT_ST_COMSNP) atomicAdd(&s_log[11], 1u);
-                    else if (st == HIMUT_ST_HIGHDEPTH) atomicAdd(&s_log[12], 1u);
-                    else if (st == HIMUT_ST_LOWDEPTH) atomicAdd(&s_log[13], 1u);
-                    else atomicAdd(&s_log[14], 1u);  // num_som: PASS and Unphased (caller.py:553,605)
+                    slot = 6;  // num_homref_sbs
+                    if (st == HIMUT_ST_LOWGQ) slot2 = 8;
+                    else if (st == HIMUT_ST_LOWBQ) slot2 = 9;
+                    else if (st == HIMUT_ST_PON) slot2 = 10;
+                    else if (st == HIMUT_ST_COMSNP) slot2 = 11;
+                    else if (st == HIMUT_ST_HIGHDEPTH) slot2 = 12;
+                    else if (st == HIMUT_ST_LOWDEPTH) slot2 = 13;
+                    else slot2 = 14;  // num_som: PASS and Unphased (caller.py:553,605)
                 }
                 e = 1;
                 if (st == HIMUT_ST_HETALT && i > 0) {
@@ -1852,6 +1866,18 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
             }
         }
         emit[i] = e;
+    }
+    const int lane = threadIdx.x & 63;
+    {
+        const unsigned long long b = __ballot(counted);
+        if (lane == 0 && b) atomicAdd(&s_log[1], (unsigned int)__popcll(b));
+    }
+    if (__ballot(slot >= 0 || slot2 >= 0)) {
+#pragma unroll
+        for (int k = 2; k < 15; k++) {
+            const unsigned long long b = __ballot(slot == k || slot2 == k);
+            if (lane == 0 && b) atomicAdd(&s_log[k], (unsigned int)__popcll(b));
+        }
     }
     __syncthreads();
     if (threadIdx.x < 15 && s_log[threadIdx.x]) atomicAdd(&log[threadIdx.x], (unsigned long long)s_log[threadIdx.x]);

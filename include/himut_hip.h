@@ -129,7 +129,8 @@ typedef struct himut_record {
 } himut_record;
 
 /* Per-run figures for bench.py / DESIGN.md (times from hipEvents on the
- * context's stream, in milliseconds). */
+ * context's stream, in milliseconds).  A stage time is 0 unless its events were
+ * recorded: see himut_set_stage_timing. */
 typedef struct himut_run_stats {
     double ms_total;
     double ms_parse;            /* k_parse_cs: whole-read BQ stream (qv) + cs decode, one wave per read */
@@ -174,6 +175,10 @@ int himut_run(himut_ctx* ctx);
 int himut_get_records(himut_ctx* ctx, const himut_record** records, int64_t* n);
 int himut_get_log(himut_ctx* ctx, int64_t out[15]);
 int himut_get_stats(himut_ctx* ctx, himut_run_stats* out);
+/* Which hipEvents himut_run records (each costs a barrier packet, i.e. a few microseconds of queue time):
+ * 0 = run start / end only (ms_total), 1 = also around k_stream_capture (ms_capture; the default),
+ * 2 = every stage of himut_run_stats.  No counterpart in the reference (it has no timers). */
+int himut_set_stage_timing(himut_ctx* ctx, int level);
 
 /* Device-resident copy of the result for the multi-GPU gather: number of
  * records, and a device-to-device copy into caller-provided device memory
