@@ -441,7 +441,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
     stage_event(c, EV_HAP, 2, st);
     if (c->n > 0)
-        hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, C, H, c->params,
+        hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, 16)), dim3(256), 0, st, R, D, C, H, c->params,
                            c->d_mask.as<uint32_t>(), c->d_any.as<uint32_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
     // the candidates = the set bits of the mask: bits per tile, then a scan
     size_t scan_tiles = 0;

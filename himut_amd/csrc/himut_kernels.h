@@ -623,20 +623,24 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
 }
 
 // ---------------------------------------------------------------------------------------
-// k_propose: one wave per read.  Applies the read filters (caller.py:310-317), checks
+// k_propose: sixteen lanes per read, four reads per wave (a read has about ten mismatch entries and the chunk
+// look-up needs sixteen lanes: a whole wave per read would leave the kernel bound by the number of
+// resident waves times the latency of its dependent loads).  Applies the read filters (caller.py:310-317), checks
 // every substitution of the cs tag against SEQ, and for every substitution that survives
 // the trim and mismatch-window filters (bamlib.py:69-86,222-282), and for every chunk that
 // both contains tpos (caller.py:104-108,325) and fetched the read (caller.py:299), sets the
 // (ref, alt) bit of the position in that chunk's mask -- the set() of caller.py:324.
-// Nothing is read back: the atomics carry no return value and the candidates are
-// enumerated from the mask afterwards, so a wave never waits on its own stores.
+// The candidates are enumerated from the mask afterwards.
 constexpr int EMIT_MAXC = 4;   // chunks of one read kept in registers
 
 __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, Phase H, Params P, uint32_t* mask, uint32_t* anyb,
                                                  uint8_t* ccs_flag, int* err) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gl = threadIdx.x & 15, gsh = (threadIdx.x & 48);      // lane in its group of 16, the group's first lane
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (r >= R.n) return;
+    // cross-lane operations below stay inside the group: shuffles of width 16, the group's 16 bits of a ballot;
+    // every branch around them is decided per read, i.e. uniform in the group
+#define GBALLOT(P) ((uint32_t)((__ballot(P) >> gsh) & 0xffffull))
     const ReadMeta M = D.meta[r];
     const int32_t qlen = R.qlen[r];
     const int mapq = R.mapq[r];
@@ -651,8 +655,8 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
     if (!(P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit)) live = false;
     const int32_t ts = M.tstart, te = M.tend;
 
-    // the chunks that fetched this read (start < tend and end > tstart): 16 records of the
-    // sorted table around the look-up hint, one per lane, decided with one ballot
+    // the chunks that fetched this read (start < tend and end > tstart): 15 records of the
+    // sorted table around the look-up hint (and the one in front of them), one per lane, decided with one ballot
     int nc = 0;
     bool overflow = false;
     int64_t hi = 0;
@@ -663,17 +667,17 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
     if (live && C.n > 0) {
         const int64_t h0 = C.hint[min((int64_t)(te > 0 ? te : 0) >> CHUNK_HINT_SHIFT, C.nhint - 1)];
         const int64_t wlo = max(h0 - 8, (int64_t)0);
-        const int64_t j = wlo - 1 + lane;               // lane 0: the record in front of the window
+        const int64_t j = wlo - 1 + gl;                 // lane 0: the record in front of the window
         ChunkRec rec;
         rec.start = 0x7fffffff; rec.end = -0x7fffffff - 1; rec.idx = -1; rec.pmaxend = -0x7fffffff - 1; rec.maskoff = 0; rec.pairbase = 0;
-        if (lane <= 16 && j >= 0 && j < C.n) rec = C.rec[j];
+        if (j >= 0 && j < C.n) rec = C.rec[j];
         // complete when no chunk in front of the window reaches the read and none behind it starts inside
-        const bool front_ok = __shfl(rec.pmaxend, 0, 64) <= ts;
-        const bool back_ok = wlo + 16 >= C.n || __ballot(lane >= 1 && lane <= 16 && rec.start >= te) != 0ULL;
-        bool take = lane >= 1 && lane <= 16 && rec.idx >= 0 && rec.start < te && rec.end > ts;
+        const bool front_ok = __shfl(rec.pmaxend, 0, 16) <= ts;
+        const bool back_ok = wlo + 15 >= C.n || GBALLOT(gl >= 1 && rec.start >= te) != 0u;
+        bool take = gl >= 1 && rec.idx >= 0 && rec.start < te && rec.end > ts;
         if (take && phase && H.hap[rec.pairbase + r] == HAP_NONE) take = false;     // caller.py:306-309
-        const unsigned long long tk = __ballot(take);
-        nc = __popcll(tk);
+        const uint32_t tk = GBALLOT(take);
+        nc = __popc(tk);
         if (!front_ok || !back_ok || nc > EMIT_MAXC) {
             // unusual chunk tables (deep nesting, a read across many chunks): walk the table per entry
             overflow = true;
@@ -687,20 +691,20 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
                 nc++;
             }
         } else {
-            unsigned long long rest = tk;
+            uint32_t rest = tk;
 #pragma unroll
             for (int k = 0; k < EMIT_MAXC; k++) {
                 if (rest) {
-                    const int src = __ffsll((long long)rest) - 1;
+                    const int src = __ffs((int)rest) - 1;
                     rest &= rest - 1;
-                    cc[k] = __shfl(rec.idx, src, 64); cst[k] = __shfl(rec.start, src, 64); cen[k] = __shfl(rec.end, src, 64);
-                    cmo[k] = ((int64_t)__shfl((int)(rec.maskoff >> 32), src, 64) << 32) | (uint32_t)__shfl((int)rec.maskoff, src, 64);
+                    cc[k] = __shfl(rec.idx, src, 16); cst[k] = __shfl(rec.start, src, 16); cen[k] = __shfl(rec.end, src, 16);
+                    cmo[k] = ((int64_t)__shfl((int)(rec.maskoff >> 32), src, 16) << 32) | (uint32_t)__shfl((int)rec.maskoff, src, 16);
                 }
             }
         }
         // num_ccs (caller.py:318-320): counted once it passes in any chunk that fetched it
         if (nc == 0) live = false;
-        else if (lane == 0) ccs_flag[qid] = 1;
+        else if (gl == 0) ccs_flag[qid] = 1;
     } else live = false;
 
     const int32_t* mis = D.mis + M.segbase;
@@ -709,7 +713,7 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
     const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);   // bamlib.py:227
     const int64_t w = P.p.mismatch_window_size;
     int bad = 0;
-    for (int e = lane; e < nm; e += 64) {
+    for (int e = gl; e < nm; e += 16) {
         const uint32_t v = mq[e];
         const int32_t tp1 = mis[e];
         const int32_t mprev = e > 0 ? mis[e - 1] : -0x7fffffff - 1;
@@ -741,8 +745,11 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
                 if (cc[k] >= 0 && cst[k] <= tp1 && tp1 <= cen[k]) {
                     // 16 mask bits per position, two positions per 32-bit word
                     const int64_t cell = cmo[k] + (tp1 - cst[k]);
-                    atomicOr(mask + (cell >> 1), (1u << bit) << ((cell & 1) ? 16 : 0));
-                    atomicOr(anyb + (cell >> 5), 1u << (cell & 31));
+                    // the summary bit is set by whoever touches the cell first: far fewer atomics on the (much denser,
+                    // hence much more contended) summary words than one per proposal
+                    const int sh = (cell & 1) ? 16 : 0;
+                    const uint32_t old = atomicOr(mask + (cell >> 1), (1u << bit) << sh);
+                    if (!((old >> sh) & 0xffffu)) atomicOr(anyb + (cell >> 5), 1u << (cell & 31));
                 }
         } else {
             for (int64_t jj = hi - 1; jj >= 0 && C.rec[jj].pmaxend > ts; jj--) {
@@ -750,12 +757,14 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
                 if (qr.end <= ts || !(qr.start <= tp1 && tp1 <= qr.end)) continue;
                 if (phase && H.hap[qr.pairbase + r] == HAP_NONE) continue;
                 const int64_t cell = qr.maskoff + (tp1 - qr.start);
-                atomicOr(mask + (cell >> 1), (1u << bit) << ((cell & 1) ? 16 : 0));
-                atomicOr(anyb + (cell >> 5), 1u << (cell & 31));
+                const int sh = (cell & 1) ? 16 : 0;
+                const uint32_t old = atomicOr(mask + (cell >> 1), (1u << bit) << sh);
+                if (!((old >> sh) & 0xffffu)) atomicOr(anyb + (cell >> 5), 1u << (cell & 31));
             }
         }
     }
     if (bad) set_err(err, bad);
+#undef GBALLOT
 }
 
 // ---------------------------------------------------------------------------------------
