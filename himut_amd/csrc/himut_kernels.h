@@ -218,6 +218,77 @@ __device__ __forceinline__ unsigned long long wave_reserve(unsigned long long* c
 }
 
 // ---------------------------------------------------------------------------------------
+// bq_issue / bq_finish: the wave streams its read's qualities with 16-byte coalesced loads, eight in flight
+// (np.mean of the whole query, bamlib.py:34-36).  k_parse_cs issues the first eight rows before it decodes
+// the cs tag and sums after it.
+constexpr int BQ_AHEAD = 4;   // rows of 1 KB issued ahead of the decode
+
+struct BqAhead {            // the first rows of a read's qualities, in flight while the wave decodes its cs tag
+    uint4 v[BQ_AHEAD];
+    const uint8_t* base;   // this lane's 16 bytes of row 0
+    int n, npre;           // quality bytes of the read; whole 1 KB rows among the BQ_AHEAD (the others were clamped loads)
+};
+
+__device__ __forceinline__ void bq_issue(const Reads& R, int64_t r, int lane, BqAhead& A) {
+    const uint8_t* row0 = R.bq + uni(R.qoff[r]);
+    A.base = row0 + lane * 16;
+    A.n = uni(R.qlen[r]);
+    A.npre = min(BQ_AHEAD, A.n >> 10);
+#pragma unroll
+    for (int k = 0; k < BQ_AHEAD; k++)                   // a row past the whole ones: reload the read's first bytes (always there)
+        A.v[k] = *reinterpret_cast<const uint4*>(k < A.npre ? A.base + k * 1024 : row0);
+}
+
+__device__ __forceinline__ void bq_finish(const BqAhead& A, int64_t r, int lane, uint32_t* bqsum) {
+    const uint8_t* base = A.base;
+    const int n = A.n;
+    uint32_t sum = 0;
+    const int nfull = n & ~1023;                 // whole 1 KB steps: four byte sums per lane and step
+#define BQ_ADD(V) do { sum = __builtin_amdgcn_sad_u8(V.x, 0u, sum); sum = __builtin_amdgcn_sad_u8(V.y, 0u, sum); \
+        sum = __builtin_amdgcn_sad_u8(V.z, 0u, sum); sum = __builtin_amdgcn_sad_u8(V.w, 0u, sum); } while (0)
+#pragma unroll
+    for (int k = 0; k < BQ_AHEAD; k++) if (k < A.npre) BQ_ADD(A.v[k]);
+    int o = A.npre * 1024;
+    for (; o + 8192 <= nfull; o += 8192) {       // eight loads in flight per lane
+        const uint4 a = *reinterpret_cast<const uint4*>(base + o);
+        const uint4 b = *reinterpret_cast<const uint4*>(base + o + 1024);
+        const uint4 c = *reinterpret_cast<const uint4*>(base + o + 2048);
+        const uint4 d = *reinterpret_cast<const uint4*>(base + o + 3072);
+        const uint4 e = *reinterpret_cast<const uint4*>(base + o + 4096);
+        const uint4 f = *reinterpret_cast<const uint4*>(base + o + 5120);
+        const uint4 g = *reinterpret_cast<const uint4*>(base + o + 6144);
+        const uint4 h = *reinterpret_cast<const uint4*>(base + o + 7168);
+        BQ_ADD(a); BQ_ADD(b); BQ_ADD(c); BQ_ADD(d); BQ_ADD(e); BQ_ADD(f); BQ_ADD(g); BQ_ADD(h);
+    }
+    for (; o + 4096 <= nfull; o += 4096) {       // four loads in flight per lane
+        const uint4 a = *reinterpret_cast<const uint4*>(base + o);
+        const uint4 b = *reinterpret_cast<const uint4*>(base + o + 1024);
+        const uint4 c = *reinterpret_cast<const uint4*>(base + o + 2048);
+        const uint4 d = *reinterpret_cast<const uint4*>(base + o + 3072);
+        BQ_ADD(a); BQ_ADD(b); BQ_ADD(c); BQ_ADD(d);
+    }
+    for (; o < nfull; o += 1024) {
+        const uint4 a = *reinterpret_cast<const uint4*>(base + o);
+        BQ_ADD(a);
+    }
+#undef BQ_ADD
+    if (nfull + lane * 16 < n) {                 // the last, partial step: bytes behind the read are masked off
+        const uint4 v = *reinterpret_cast<const uint4*>(base + nfull);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rem = n - (nfull + lane * 16 + 4 * k);
+            uint32_t x = w[k];
+            if (rem < 4) x = rem <= 0 ? 0u : (x & (0xffffffffu >> (8 * (4 - rem))));
+            sum = __builtin_amdgcn_sad_u8(x, 0u, sum);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if (lane == 0) bqsum[r] = sum;
+}
+
+// ---------------------------------------------------------------------------------------
 // k_parse_cs: one WAVE per read, a wave-parallel cs tokenizer.
 //
 // The tag is consumed 1 KB per step, 16 bytes per lane.  Operation starts are the bytes
@@ -280,10 +351,10 @@ __device__ __forceinline__ uint32_t cs_pack4(uint32_t f) {                      
     return (g | (g >> 7) | (g >> 14) | (g >> 21)) & 15u;
 }
 
-__device__ __forceinline__ void bq_sum_read(const Reads& R, int64_t r, int lane, uint32_t* bqsum);
 
-// The wave first streams its read's qualities for the mean (bq_sum_read): waves in that phase are bound by
-// HBM, waves in the decode by VALU, and a CU holds both kinds at any time.
+// The wave issues the first rows of its read's qualities (bq_issue) behind the first KB of the tag, decodes the
+// tag while they are in flight, then sums the qualities (bq_finish): waves in that phase are bound by HBM,
+// waves in the decode by VALU, and a CU holds both kinds at any time.
 __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
     __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
@@ -291,7 +362,6 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
     if (lane == 0) ccs[r] = 0;               // the flag k_propose raises for a read that may propose (num_ccs)
-    bq_sum_read(R, r, lane, D.bqsum);
     const int64_t cs0 = uni(R.cs_off[r]);
     const int64_t sb = (cs0 >> 1) + r;
     ReadMeta M;
@@ -320,17 +390,23 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     int last_kind = 0;                                                 // kind of the last finished operation
     bool has_long = false;
 
+    // The text is loaded one step ahead, always exactly one load per step at an address that depends on no loaded
+    // data (clamped to the last step): with loads inside branches the compiler waits for every load in flight at
+    // the join, and the first rows of the qualities are in flight here (bq_issue) while the tag is decoded.
+    const int last_base = ((max(n, 1) - 1) / PB) * PB;
+    uint4 vcur;
+    __builtin_memcpy(&vcur, cs + 16 * lane, 16);                   // buffers carry 256 bytes of slack
+    BqAhead Q;
+    bq_issue(R, r, lane, Q);
     for (int base = 0; base < n; base += PB) {
         const int nb = min(PB, n - base);
-        // ---- text of this step (and the 32 bytes before it) into LDS
-        uint4 v;
-        __builtin_memcpy(&v, cs + base + 16 * lane, 16);           // buffers carry 256 bytes of slack
+        // ---- text of this step into LDS, behind the last 32 bytes of the previous step (still in LDS)
+        const uint4 v = vcur;
+        uint4 pb = make_uint4(0, 0, 0, 0);
+        if (lane < 2 && base > 0) pb = *reinterpret_cast<const uint4*>(txt + PB + 16 * lane);
         *reinterpret_cast<uint4*>(txt + 32 + 16 * lane) = v;
-        if (lane < 2) {
-            uint4 b = make_uint4(0, 0, 0, 0);
-            if (base >= 32) __builtin_memcpy(&b, cs + base - 32 + 16 * lane, 16);
-            *reinterpret_cast<uint4*>(txt + 16 * lane) = b;
-        }
+        if (lane < 2) *reinterpret_cast<uint4*>(txt + 16 * lane) = pb;
+        __builtin_memcpy(&vcur, cs + min(base + PB, last_base) + 16 * lane, 16);
         __builtin_amdgcn_wave_barrier();
         // ---- operation starts in this lane's 16 bytes, four bytes at a time in the registers they came in
         uint32_t mask16 = 0;
@@ -479,6 +555,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
         }
         __builtin_amdgcn_wave_barrier();
     }
+    bq_finish(Q, r, lane, D.bqsum);
     // a reduction of the lanes' error codes
     {
         int b = bad;
@@ -541,45 +618,6 @@ __global__ void __launch_bounds__(256) k_check_longcs(Reads R, Derived D, int* e
 }
 
 // ---------------------------------------------------------------------------------------
-// bq_sum_read: the wave streams its read's qualities with 16-byte coalesced loads, four in flight
-// (np.mean of the whole query, bamlib.py:34-36).  First phase of k_parse_cs.
-__device__ __forceinline__ void bq_sum_read(const Reads& R, int64_t r, int lane, uint32_t* bqsum) {
-    if (uni((int)R.flag[r]) & 0x100) return;
-    const uint8_t* base = R.bq + uni(R.qoff[r]) + lane * 16;
-    const int n = uni(R.qlen[r]);
-    uint32_t sum = 0;
-    const int nfull = n & ~1023;                 // whole 1 KB steps: four byte sums per lane and step
-    int o = 0;
-#define BQ_ADD(V) do { sum = __builtin_amdgcn_sad_u8(V.x, 0u, sum); sum = __builtin_amdgcn_sad_u8(V.y, 0u, sum); \
-        sum = __builtin_amdgcn_sad_u8(V.z, 0u, sum); sum = __builtin_amdgcn_sad_u8(V.w, 0u, sum); } while (0)
-    for (; o + 4096 <= nfull; o += 4096) {       // four loads in flight per lane
-        const uint4 a = *reinterpret_cast<const uint4*>(base + o);
-        const uint4 b = *reinterpret_cast<const uint4*>(base + o + 1024);
-        const uint4 c = *reinterpret_cast<const uint4*>(base + o + 2048);
-        const uint4 d = *reinterpret_cast<const uint4*>(base + o + 3072);
-        BQ_ADD(a); BQ_ADD(b); BQ_ADD(c); BQ_ADD(d);
-    }
-    for (; o < nfull; o += 1024) {
-        const uint4 a = *reinterpret_cast<const uint4*>(base + o);
-        BQ_ADD(a);
-    }
-#undef BQ_ADD
-    if (nfull + lane * 16 < n) {                 // the last, partial step: bytes behind the read are masked off
-        const uint4 v = *reinterpret_cast<const uint4*>(base + nfull);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int rem = n - (nfull + lane * 16 + 4 * k);
-            uint32_t x = w[k];
-            if (rem < 4) x = rem <= 0 ? 0u : (x & (0xffffffffu >> (8 * (4 - rem))));
-            sum = __builtin_amdgcn_sad_u8(x, 0u, sum);
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
-    if (lane == 0) bqsum[r] = sum;
-}
-
 // ---------------------------------------------------------------------------------------
 // k_read_hap: thread per (chunk, read-in-window) pair; haplib.get_ccs_hap (haplib.py:61-83).
 __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, Phase H, int64_t npairs, int* err) {
