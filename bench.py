@@ -42,8 +42,8 @@ def algorithmic_bytes(stage, st, cs_bytes):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--contig-len", type=int, default=CHR20_LEN)
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

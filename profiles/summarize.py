@@ -42,7 +42,7 @@ def pmc_avg(d, counter):
 
 
 # kernels whose reads are wide coalesced streams: FETCH_SIZE on gfx950 reports half of their bytes
-STREAMING = ("k_parse_cs", "k_stream_capture", "k_mask_count", "k_mask_emit")
+STREAMING = ("k_parse_cs", "k_stream_capture")
 
 
 def pmc(fetch_dir, write_dir, out):
