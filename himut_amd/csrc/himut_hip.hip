@@ -98,7 +98,7 @@ struct himut_ctx {
     DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs, d_order;
     // run state
     DevBuf d_mask, d_any, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
-    DevBuf d_tilecnt, d_tileoff2;
+    DevBuf d_tilecnt, d_tileoff2, d_logpart;
     // normcounts
     DevBuf d_refseq, d_live, d_callable, d_tri;
     int64_t reflen = 0;
@@ -572,14 +572,17 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         const unsigned nb = blocks_for(ncap, 256);
         hipLaunchKernelGGL(k_resolve_seen, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
                            c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, ncand_dev, ncap);
+        c->d_logpart.reserve((size_t)nb * 16 * 4 + 64);
         hipLaunchKernelGGL(k_finalize_flags, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
-                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, ncand_dev, ncap, c->d_emit.as<uint32_t>(), sc->log);
+                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, ncand_dev, ncap, c->d_emit.as<uint32_t>(),
+                           c->d_logpart.as<uint32_t>());
         HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
                                        (size_t)ncap, rocprim::plus<uint32_t>(), st));
         hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), (const uint32_t*)nullptr,
                            c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), ncand_dev, ncap, c->d_recs_out.as<himut_record>());
-        hipLaunchKernelGGL(k_run_totals, dim3(1), dim3(64), 0, st, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), ncap,
-                           c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), nblk, &sc->nrec, &sc->reserved0);
+        hipLaunchKernelGGL(k_run_totals, dim3(1), dim3(1024), 0, st, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), ncap,
+                           c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), nblk, &sc->nrec, &sc->reserved0,
+                           c->d_logpart.as<uint32_t>(), (int64_t)nb, sc->log);
     }
     if (c->n > 0 && anyw <= 0)   // no mask sweep ran: count the flagged reads here
         hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);

@@ -1869,7 +1869,7 @@ __global__ void __launch_bounds__(256) k_resolve_seen(himut_record* recs, const 
 // Counters: one ballot per counter and wave, one shared-memory add per wave, one global add per block.
 __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, const uint64_t* keys, const uint32_t* vals,
                                                         const unsigned long long* n_dev, int64_t cap, uint32_t* emit,
-                                                        unsigned long long* log) {
+                                                        uint32_t* logpart) {
     __shared__ unsigned int s_log[16];
     if (threadIdx.x < 16) s_log[threadIdx.x] = 0;
     __syncthreads();
@@ -1927,7 +1927,9 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
         }
     }
     __syncthreads();
-    if (threadIdx.x < 15 && s_log[threadIdx.x]) atomicAdd(&log[threadIdx.x], (unsigned long long)s_log[threadIdx.x]);
+    // per-block partial counters: k_run_totals adds them up (one global atomic per block and counter would be
+    // ~10^4 atomics on two cache lines, which cost more than the rest of this kernel)
+    if (threadIdx.x < 16) logpart[(int64_t)blockIdx.x * 16 + threadIdx.x] = s_log[threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256) k_compact(const himut_record* recs, const uint32_t* vals, const uint32_t* emit,
@@ -1950,12 +1952,37 @@ __global__ void __launch_bounds__(256) k_count_flags(const uint8_t* flags, int64
 }
 
 // the totals the host reads once at the end of a run: records out (the scan of emit[] over the capacity),
-// column slots (the scan of the block slot counts)
-__global__ void k_run_totals(const uint32_t* emit, const uint32_t* pos, int64_t cap, const uint32_t* blkoff,
-                             const uint32_t* blkslots, int64_t nblk, unsigned long long* nrec, unsigned long long* nslots) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    *nrec = cap > 0 ? (unsigned long long)pos[cap - 1] + emit[cap - 1] : 0ull;
-    *nslots = nblk > 0 ? (unsigned long long)blkoff[nblk - 1] + blkslots[nblk - 1] : 0ull;
+// column slots (the scan of the block slot counts), the 15 counters (sums of k_finalize_flags' per-block partials)
+__global__ void __launch_bounds__(1024) k_run_totals(const uint32_t* emit, const uint32_t* pos, int64_t cap, const uint32_t* blkoff,
+                                                     const uint32_t* blkslots, int64_t nblk, unsigned long long* nrec,
+                                                     unsigned long long* nslots, const uint32_t* logpart, int64_t nparts,
+                                                     unsigned long long* log) {
+    __shared__ unsigned long long s_log[16];
+    if (threadIdx.x < 16) s_log[threadIdx.x] = 0;
+    __syncthreads();
+    // thread = (row phase, quarter of the 16 counters): 256 rows of partials per pass, 16-byte loads, a few passes
+    const int q = threadIdx.x & 3;
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+    for (int64_t b = threadIdx.x >> 2; b < nparts; b += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(logpart + b * 16 + q * 4);
+        a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+    }
+    // lanes with the same quarter: xor-shuffles over the row-phase bits of the lane index
+#pragma unroll
+    for (int d = 4; d < 64; d <<= 1) {
+        a0 += __shfl_xor(a0, d, 64); a1 += __shfl_xor(a1, d, 64); a2 += __shfl_xor(a2, d, 64); a3 += __shfl_xor(a3, d, 64);
+    }
+    if ((threadIdx.x & 63) < 4) {
+        atomicAdd(&s_log[q * 4 + 0], a0); atomicAdd(&s_log[q * 4 + 1], a1);
+        atomicAdd(&s_log[q * 4 + 2], a2); atomicAdd(&s_log[q * 4 + 3], a3);
+    }
+    __syncthreads();
+    if (threadIdx.x < 15) log[threadIdx.x] = s_log[threadIdx.x];
+    if (threadIdx.x == 0) {
+        *nrec = cap > 0 ? (unsigned long long)pos[cap - 1] + emit[cap - 1] : 0ull;
+        *nslots = nblk > 0 ? (unsigned long long)blkoff[nblk - 1] + blkslots[nblk - 1] : 0ull;
+    }
 }
 
 }  // namespace himut
