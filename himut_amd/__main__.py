@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""``python -m himut_amd call ...`` / ``normcounts ...`` -- the `himut call` and `himut normcounts` entry
-points (reference: src/himut/__main__.py:15-49,115-146)."""
+"""``python -m himut_amd call ...`` / ``normcounts ...`` / ``phase ...`` -- the `himut call`, `himut normcounts`
+and `himut phase` entry points (reference: src/himut/__main__.py:15-63,115-146)."""
 __version__ = "1.0.4+mi355x"
 
 from himut_amd.parse_args import parse_args
@@ -27,6 +27,12 @@ def main(arguments=None):
             options.max_mismatch_count, options.min_ref_count, options.min_alt_count, options.min_hap_count,
             options.somatic_snv_prior, options.germline_snv_prior, options.germline_indel_prior, options.threads,
             options.phase, options.non_human_sample, options.reference_sample, options.output,
+            devices=[int(d) for d in options.devices.split(",") if d != ""])
+    elif options.sub == "phase":
+        from himut_amd import phaselib
+        phaselib.get_chrom_hblock(
+            options.bam, options.vcf, options.region, options.region_list, options.min_bq, options.min_mapq,
+            options.min_p_value, options.min_phase_proportion, options.threads, __version__, options.output,
             devices=[int(d) for d in options.devices.split(",") if d != ""])
     else:
         parser.print_help()

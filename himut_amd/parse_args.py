@@ -77,6 +77,20 @@ def build_parser(program_version):
     n.add_argument("--reference_sample", required=False, action="store_true", help="reads from the reference sample")
     n.add_argument("-o", "--output", type=str, required=True, help="file to write the normalised SBS96 counts")
     n.add_argument("--devices", type=str, default="0", help="comma separated GPU ids (contigs are spread over them)")
+    # himut phase (reference: parse_args.py:343-415)
+    h = sub.add_parser("phase", help="returns phased hetsnps", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    h.add_argument("-i", "--bam", type=str, required=True,
+                   help="minimap2 (parameters: -ax map-hifi --cs=short) aligned BAM file")
+    h.add_argument("--vcf", type=str, required=True, help="deepvariant VCF file with germline mutations")
+    h.add_argument("--region", type=str, required=False, help="target chromosome")
+    h.add_argument("--region_list", type=str, required=False, help="list of target chromosomes separated by new line")
+    h.add_argument("--min_bq", type=int, default=20, help="minimum base quality score threshold")
+    h.add_argument("--min_mapq", type=int, default=20, help="minimum mapping quality score")
+    h.add_argument("--min_p_value", type=float, default=0.0001, help="maximum binomial p-value of a phase consistent edge")
+    h.add_argument("--min_phase_proportion", type=float, default=0.2, help="minimum proportion of phase consistent edges")
+    h.add_argument("-t", "--threads", type=int, default=1, help="BGZF inflate threads; the GPU counts the edges")
+    h.add_argument("-o", "--output", type=str, required=True, help="VCF file to write phased hetsnps")
+    h.add_argument("--devices", type=str, default="0", help="comma separated GPU ids (the first one is used)")
     return parser
 
 

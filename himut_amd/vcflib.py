@@ -26,7 +26,7 @@ LOG_ROWS = ["num_ccs", "num_sbs", "num_het_sbs", "num_hetalt_sbs", "num_homalt_s
 class VcfRecord:
     """Fields of one VCF data line that the path looks at (vcflib.py:13-52)."""
 
-    __slots__ = ("chrom", "pos", "ref", "alt_lst", "alt", "is_pass", "is_biallelic", "is_snp", "sample_gt",
+    __slots__ = ("chrom", "pos", "ref", "alt_lst", "alt", "qual", "is_pass", "is_biallelic", "is_snp", "sample_gt",
                  "sample_phase_set")
 
     def __init__(self, line):
@@ -35,6 +35,7 @@ class VcfRecord:
         self.pos = int(f[1])
         self.ref = f[3]
         self.alt_lst = f[4].split(",")
+        self.qual = float(f[5]) if f[5] != "." else f[5]       # printed back with str() by the phased-hetSNP writer
         self.is_pass = f[6] == "PASS"
         fmt = dict(zip(f[8].split(":"), f[9].split(":")))   # IndexError without a sample column, as the reference
         self.sample_gt = fmt.get("GT")
@@ -292,3 +293,104 @@ def dump_call_log(chrom_lst, chrom2tsbs_log, path="himut.log"):
         for k, name in enumerate(LOG_ROWS):
             cells = [str(int(x)) for x in table[k].tolist()] + [str(int(np.sum(table[k])))]
             o.write("{:30}{}\n".format(name, "\t".join(cells)))
+
+
+# --------------------------------------------------------------------------
+# `himut phase`: hetSNP input and the phased-hetSNP VCF (vcflib.py:84-147,462-550,704-817)
+
+def _is_het_snp(v):
+    return v.is_snp and v.is_pass and v.is_biallelic and v.sample_gt in ("0/1", "1/0")
+
+
+def _hetsnp_lines(vcf_file, chrom_lst):
+    """(line, record) of every data line the phaser looks at: the whole plain .vcf in file order, or the requested
+    contigs of a .bgz one after the other (what the reference's tabix queries return)."""
+    if vcf_file.endswith(".vcf"):
+        for line in _data_lines(vcf_file):
+            yield line, VcfRecord(line)
+    elif vcf_file.endswith(".bgz"):
+        for chrom in chrom_lst:
+            for line in _bgz_lines(vcf_file, chrom):
+                yield line, VcfRecord(line)
+
+
+def load_hetsnps(vcf_file, chrom, chrom_len):
+    """PASS bi-allelic 0/1 SNPs of ``chrom`` in file order: (hetsnp_lst, hidx2hetsnp, hetsnp2hidx)
+    (vcflib.py:462-499)."""
+    hetsnp_lst = [(v.pos, v.ref, v.alt) for _, v in _hetsnp_lines(vcf_file, [chrom]) if v.chrom == chrom and _is_het_snp(v)]
+    hidx2hetsnp = dict(enumerate(hetsnp_lst))
+    hetsnp2hidx = {h: i for i, h in hidx2hetsnp.items()}
+    return hetsnp_lst, hidx2hetsnp, hetsnp2hidx
+
+
+def load_hblock_hsh(vcf_file, chrom_lst, tname2tsize, chrom2hblock_lst):
+    """hetSNP -> haplotype state and hetSNP -> phase set (= position of the block's first hetSNP) for every
+    hetSNP a block holds (vcflib.py:502-550).  Keys carry no contig, as in the reference: the same (pos, ref, alt)
+    on two contigs share an entry."""
+    per_chrom = defaultdict(list)
+    for _, v in _hetsnp_lines(vcf_file, chrom_lst):
+        if _is_het_snp(v):
+            per_chrom[v.chrom].append((v.pos, v.ref, v.alt))
+    hetsnp2hstate, hetsnp2phase_set = {}, {}
+    for chrom, hblock_lst in chrom2hblock_lst.items():
+        snps = per_chrom[chrom]
+        for hblock in hblock_lst:
+            phase_set = snps[hblock[0][0]][0]
+            for hidx, hstate in hblock:
+                hetsnp2hstate[snps[hidx]] = hstate
+                hetsnp2phase_set[snps[hidx]] = phase_set
+    return hetsnp2hstate, hetsnp2phase_set
+
+
+def get_phased_vcf_header(bam_file, vcf_file, region, region_list, tname2tsize, min_bq, min_mapq, min_p_value,
+                          min_phase_proportion, threads, version, out_file, sample):
+    """Header of the phased-hetSNP VCF (vcflib.py:84-147); ``sample`` is the BAM's SM tag."""
+    h = ["##fileformat=VCFv4.2",
+         '##FILTER=<ID=PASS,Description="All filters passed">',
+         "##fileDate={}".format(datetime.now().strftime("%d%m%Y")),
+         "##source=himut",
+         "##source_version={}".format(version),
+         "##content=himut somatic single base substitutions",
+         '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+         '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Conditional genotype quality">',
+         '##FORMAT=<ID=BQ,Number=1,Type=Float,Description="Average base quality">',
+         '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read depth">',
+         '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="Read depth for each allele">',
+         '##FORMAT=<ID=VAF,Number=A,Type=Float,Description="Variant allele fractions">',
+         '##FORMAT=<ID=PL,Number=G,Type=Integer,Description="Phred-scaled genotype likelihoods rounded to the closest integer">',
+         '##FORMAT=<ID=PS,Number=1,Type=Integer,Description="Phase set">']
+    h += ["##contig=<ID={},length={}>".format(t, tname2tsize[t]) for t in natsorted(list(tname2tsize))]
+    if region_list is not None:
+        region_param = "--region_list {}".format(region_list)
+    elif region is not None:
+        region_param = "--region {}".format(region)
+    else:
+        region_param = ""
+    h.append("##himut_command=himut phase -i {} --vcf {} {} --min_bq {} --min_mapq {} --min_p_value {} "
+             "--min_phase_proportion {} --threads {} -o {}".format(bam_file, vcf_file, region_param, min_bq, min_mapq,
+                                                                   min_p_value, min_phase_proportion, threads, out_file))
+    h.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{}".format(sample))
+    return "\n".join(h)
+
+
+def dump_phased_hetsnps(bam_file, vcf_file, region, region_list, tname2tsize, min_bq, min_mapq, min_p_value,
+                        min_phase_proportion, threads, chrom_lst, chrom2hblock_lst, version, out_file, sample):
+    """The input's hetSNPs again, with GT 0|1 / 1|0 and PS for those inside a block and PS "." for the others
+    (vcflib.py:704-817).  The plain-.vcf branch prints the hetSNPs of every contig of the file, the .bgz branch
+    those of the requested contigs."""
+    hetsnp2hstate, hetsnp2phase_set = load_hblock_hsh(vcf_file, chrom_lst, tname2tsize, chrom2hblock_lst)
+    with open(out_file, "w") as o:
+        o.write("{}\n".format(get_phased_vcf_header(bam_file, vcf_file, region, region_list, tname2tsize, min_bq, min_mapq,
+                                                    min_p_value, min_phase_proportion, threads, version, out_file, sample)))
+        for line, v in _hetsnp_lines(vcf_file, chrom_lst):
+            if not _is_het_snp(v):
+                continue
+            fmt, sample_fmt = line.strip().split()[-2:]
+            hetsnp = (v.pos, v.ref, v.alt)
+            if hetsnp in hetsnp2hstate:
+                cols = sample_fmt.split(":")
+                cols[0] = "0|1" if hetsnp2hstate[hetsnp] == "0" else "1|0"
+                tail = "{}:{}".format(":".join(cols), hetsnp2phase_set[hetsnp])
+            else:
+                tail = "{}:.".format(sample_fmt)
+            o.write("{}\t{}\t.\t{}\t{}\t{}\tPASS\t.\t{}:PS\t{}\n".format(v.chrom, v.pos, v.ref, v.alt, v.qual, fmt, tail))

@@ -408,6 +408,53 @@ def edges_case(case, cfg, min_bq=20, min_mapq=20, mutate=None):
     save(case, exp, batch=b)
 
 
+def write_unphased_vcf(path, s, other_contig="chrOther"):
+    """A germline VCF as `himut phase` reads it: the sample's SNPs with unphased genotypes (0/1 for the
+    heterozygous ones), plus records the phaser must skip (1/1, a failed filter, an indel, a tri-allelic site,
+    hetSNPs of another contig)."""
+    name = s.batch.name
+    rows = []
+    for k, (p, r, a, g) in enumerate(zip(s.snp_pos, s.snp_ref, s.snp_alt, s.snp_gt)):
+        gt = "0/1" if g in (1, 2) else "1/1"
+        if g in (1, 2) and k % 7 == 3:
+            gt = "1/0"
+        flt = "q5" if k % 23 == 11 else "PASS"
+        rows.append((int(p) + 1, "{}\t{}\t.\t{}\t{}\t{}\t{}\t.\tGT:GQ:DP\t{}:{}:{}".format(
+            name, int(p) + 1, chr(r), chr(a), 30 + k % 20 if k % 5 else ".", flt, gt, 20 + k % 50, 25 + k % 11)))
+    first = int(s.snp_pos[0]) + 1
+    rows.append((first + 1, "{}\t{}\t.\tAC\tA\t40\tPASS\t.\tGT:GQ:DP\t0/1:30:31".format(name, first + 1)))
+    rows.append((first + 2, "{}\t{}\t.\tA\tC,G\t40\tPASS\t.\tGT:GQ:DP\t1/2:30:31".format(name, first + 2)))
+    rows.sort()
+    with open(path, "w") as o:
+        o.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsyn\n")
+        for _, line in rows:
+            o.write(line + "\n")
+        o.write("{}\t777\t.\tA\tG\t50\tPASS\t.\tGT:GQ:DP\t0/1:40:30\n".format(other_contig))
+
+
+def phase_case(case, cfg, min_bq=20, min_mapq=20, min_p_value=0.0001, min_phase_proportion=0.2, tmpdir="/tmp"):
+    """`himut phase` on one synthetic contig: haplotype blocks, statistics and the phased VCF."""
+    s = synth.generate(cfg)
+    b = s.batch
+    bam = "/fake/{}.bam".format(case)
+    H.register_bam(bam, {b.name: b})
+    vcf = os.path.join(tmpdir, case + ".germline.vcf")
+    write_unphased_vcf(vcf, s)
+    out = os.path.join(tmpdir, case + ".phased.vcf")
+    sizes = {b.name: b.length, "chrOther": 1000}
+    blocks, stats, text = H.run_reference_phase(bam, b.name, b.length, vcf, min_bq, min_mapq, min_p_value,
+                                                min_phase_proportion, out, sizes)
+    ref = H.load_reference()
+    hb, hp, hs, c2c = ref.vcflib.load_phased_hetsnps(out, [b.name], sizes)
+    exp = {"contig": b.name, "length": b.length, "sizes": sizes, "vcf_text": open(vcf).read(), "min_bq": min_bq,
+           "min_mapq": min_mapq, "min_p_value": min_p_value, "min_phase_proportion": min_phase_proportion,
+           "hblock_lst": blocks, "statistics": stats,
+           "phased_vcf_text": text.replace(tmpdir + "/", "").replace(bam, "in.bam"),
+           "phase_chunks": [[int(x) for x in c[1:]] for c in c2c[b.name]]}
+    print("   ", case, len(blocks), "blocks", stats)
+    save(case, exp, batch=b)
+
+
 def norm_host_case(tmpdir="/tmp"):
     """The host side of `himut normcounts` around the worker: thresholds from the SBS file's header, SBS96 counts,
     genome trinucleotide counts, the output table and norm.log, the command line."""
@@ -537,6 +584,12 @@ def main():
                 b.qid[j] = b.qid[i]
         worker_case("worker_flags", small_cfg(108, contig_len=20000, name="chrF", som_rate=2e-4), md_threshold=52,
                     mutate=mutate)
+    if want("phase_blocks"):
+        phase_case("phase_blocks", small_cfg(131, contig_len=60000, snp_rate=3e-3, name="chr9"))
+    if want("phase_sparse"):
+        # few reads per edge: most edges fail the binomial test, blocks break up, conflicting evidence appears
+        phase_case("phase_sparse", small_cfg(132, contig_len=50000, depth=9.0, snp_rate=4e-3, sub_rate=3e-3, name="chr4"),
+                   min_p_value=0.05, min_phase_proportion=0.1)
     if want("worker_pon_params"):
         # the thresholds --create_panel_of_normals switches to (util.py:44-63)
         worker_case("worker_pon_params", small_cfg(109, contig_len=20000, name="chrN", som_rate=2e-4), md_threshold=52,

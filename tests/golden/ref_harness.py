@@ -244,3 +244,30 @@ def run_reference_edges(bam_path, chrom, hetsnp_lst, min_bq, min_mapq):
     hidx = {h: i for i, h in enumerate(hetsnp_lst)}
     edge_lst, edge2counts = PL.get_edges(chrom, bam_path, min_bq, min_mapq, hpos, hetsnp_lst, hidx)
     return [list(e) for e in edge_lst], {"{},{}".format(*k): [float(x) for x in v] for k, v in edge2counts.items()}
+
+
+def _phaselib():
+    load_reference()
+    import scipy.stats
+    if not hasattr(scipy.stats, "binom_test"):      # removed from scipy >= 1.12; phaselib imports it by name
+        scipy.stats.binom_test = lambda x, n, p=0.5, alternative="two-sided": scipy.stats.binomtest(int(x), int(n), p, alternative).pvalue
+    import himut.phaselib as PL
+    return PL
+
+
+def run_reference_phase(bam_path, chrom, chrom_len, vcf_path, min_bq, min_mapq, min_p_value, min_phase_proportion,
+                        out_path, tname2tsize):
+    """The reference's `himut phase` for one contig without its process pool and input checks: get_hblock
+    (phaselib.py:235-250), get_hblock_statistics and vcflib.dump_phased_hetsnps.  Returns
+    (hblock_lst, statistics, phased VCF text)."""
+    import numpy as np
+    PL = _phaselib()
+    ref = load_reference()
+    out = {}
+    PL.get_hblock(chrom, chrom_len, bam_path, vcf_path, min_bq, min_mapq, min_p_value, min_phase_proportion, out)
+    hetsnp_lst, _, _ = ref.vcflib.load_hetsnps(vcf_path, chrom, chrom_len)
+    stats = PL.get_hblock_statistics(out[chrom], hetsnp_lst)
+    ref.vcflib.dump_phased_hetsnps(bam_path, vcf_path, chrom, None, tname2tsize, min_bq, min_mapq, min_p_value,
+                                   min_phase_proportion, 1, [chrom], out, "1.0.4", out_path)
+    blocks = [[[int(h), str(st)] for h, st in blk] for blk in out[chrom]]
+    return blocks, [int(x) for x in stats], open(out_path).read()
