@@ -184,9 +184,6 @@ def call_somatic_substitutions(
     t0 = time.time()
     if not out_file.endswith(".vcf"):
         raise ValueError("VCF file must have .vcf suffix")
-    if non_human_sample:
-        raise NotImplementedError("--non_human_sample needs germline priors from a FASTA/VCF pair "
-                                  "(vcflib.get_germline_priors); not part of the accelerated path")
     bam = bamio.read_bam(bam_file)
     tname2tsize = bam.tname2tsize
     chrom_lst, chrom2chunkloci_lst = util.load_loci(region, region_list, tname2tsize)       # caller.py:681-682
@@ -197,6 +194,8 @@ def call_somatic_substitutions(
     qlen_lower_limit, qlen_upper_limit, md_threshold = bamlib.get_thresholds(bam.batches, chrom_lst, tname2tsize)
     if create_panel_of_normals:                                                             # caller.py:707-718
         (min_bq, min_gq, min_qv, min_mapq, min_trim, min_hap_count, min_sequence_identity, phase) = util.load_pon_params()
+    if non_human_sample:                                                                    # caller.py:720-723
+        germline_snv_prior, germline_indel_prior = vcflib.get_germline_priors(chrom_lst, ref_file, vcf_file, reference_sample)
     # the header call passes (max_mismatch_count, mismatch_window_size) into parameters named
     # (mismatch_window, max_mismatch_count): reproduced (caller.py:742-743 vs vcflib.py:167-168)
     vcf_header = vcflib.get_himut_vcf_header(

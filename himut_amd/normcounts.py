@@ -304,9 +304,6 @@ def get_normcounts(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, comm
     """Driver of `himut normcounts` (normcounts.py:424-592): same arguments, the same table and norm.log; the PDF
     plot is left out.  Contigs go to the GPUs of ``devices`` round-robin."""
     from . import bamio, util, vcflib
-    if non_human_sample:
-        raise NotImplementedError("--non_human_sample needs germline priors from a FASTA/VCF pair "
-                                  "(vcflib.get_germline_priors); not part of the accelerated path")
     bam = bamio.read_bam(bam_file)
     tname2tsize = bam.tname2tsize
     chrom_lst, chrom2chunkloci_lst = util.load_loci(region, region_list, tname2tsize)
@@ -314,6 +311,8 @@ def get_normcounts(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, comm
     if phase:
         ps2hbit, ps2hpos, ps2hetsnp, chrom2chunkloci_lst = vcflib.load_phased_hetsnps(phased_vcf_file, chrom_lst,
                                                                                       tname2tsize)
+    if non_human_sample:                                                                    # normcounts.py:487-490
+        germline_snv_prior, germline_indel_prior = vcflib.get_germline_priors(chrom_lst, ref_file, vcf_file, reference_sample)
     qlen_lower_limit, qlen_upper_limit, md_threshold = get_thresholds(sbs_file)
     refseq = read_fasta(ref_file)
     ccs, ref, log = {}, {}, {}

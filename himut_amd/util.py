@@ -65,3 +65,11 @@ def load_pon_params():
     """Thresholds that --create_panel_of_normals switches to (util.py:44-63):
     (min_bq, min_gq, min_qv, min_mapq, min_trim, min_hap_count, min_sequence_identity, phase)."""
     return 20, 10, 20, 30, 0, 0, 0.8, False
+
+
+def get_truncated_float(f):
+    """f rounded to its first significant decimal place, for 0 <= f < 0.05 (util.py:539-544): the rounding one
+    place past the last one that still gives 0.0.  Anything that never rounds to 0.0 raises ValueError (max() of
+    an empty list), as in the reference."""
+    rounded = [round(f, i) for i in range(1, 10)]
+    return rounded[max(j for j, k in enumerate(rounded) if k == 0.0) + 1]

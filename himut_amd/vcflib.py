@@ -26,8 +26,8 @@ LOG_ROWS = ["num_ccs", "num_sbs", "num_het_sbs", "num_hetalt_sbs", "num_homalt_s
 class VcfRecord:
     """Fields of one VCF data line that the path looks at (vcflib.py:13-52)."""
 
-    __slots__ = ("chrom", "pos", "ref", "alt_lst", "alt", "qual", "is_pass", "is_biallelic", "is_snp", "sample_gt",
-                 "sample_phase_set")
+    __slots__ = ("chrom", "pos", "ref", "alt_lst", "alt", "qual", "is_pass", "is_biallelic", "is_snp", "is_indel",
+                 "sample_gt", "sample_phase_set")
 
     def __init__(self, line):
         f = line.strip().split()
@@ -43,6 +43,9 @@ class VcfRecord:
         self.is_biallelic = len(self.alt_lst) == 1
         self.alt = self.alt_lst[0] if self.is_biallelic else None
         self.is_snp = self.is_biallelic and len(self.ref) == 1 and len(self.alt) == 1
+        # vcflib.py:41-50: a doublet substitution is neither; anything else of unequal length is an indel
+        self.is_indel = (self.is_biallelic and not self.is_snp and not (len(self.ref) == len(self.alt) == 2)
+                         and len(self.ref) != len(self.alt))
 
 
 def _data_lines(path):
@@ -394,3 +397,45 @@ def dump_phased_hetsnps(bam_file, vcf_file, region, region_list, tname2tsize, mi
             else:
                 tail = "{}:.".format(sample_fmt)
             o.write("{}\t{}\t.\t{}\t{}\t{}\tPASS\t.\t{}:PS\t{}\n".format(v.chrom, v.pos, v.ref, v.alt, v.qual, fmt, tail))
+
+
+# --------------------------------------------------------------------------
+# --non_human_sample: germline priors from the sample's own VCF (vcflib.py:553-613)
+
+def load_germline_counts(vcf_file, chrom_lst):
+    """(het SNPs, hom-alt SNPs, het indels, hom-alt indels) among the PASS bi-allelic records of the target contigs;
+    only the genotype spellings 0/1 and 1/1 count (vcflib.py:553-593).  A .vcf.bgz is read as the gzip members it
+    is made of (the reference goes through cyvcf2)."""
+    import gzip
+    if vcf_file.endswith(".vcf"):
+        fh = open(vcf_file)
+    elif vcf_file.endswith(".vcf.bgz"):
+        fh = gzip.open(vcf_file, "rt")
+    else:
+        return 0, 0, 0, 0
+    n = defaultdict(int)
+    with fh:
+        for line in fh:
+            if line.startswith("#"):
+                continue
+            v = VcfRecord(line)
+            if v.is_pass and v.is_biallelic and v.sample_gt in ("0/1", "1/1") and (v.is_snp or v.is_indel):
+                n[(v.chrom, v.is_snp, v.sample_gt)] += 1
+    tot = lambda snp, gt: sum(n[(c, snp, gt)] for c in chrom_lst)
+    return tot(True, "0/1"), tot(True, "1/1"), tot(False, "0/1"), tot(False, "1/1")
+
+
+def get_germline_priors(chrom_lst, ref_file, vcf_file, reference_sample):
+    """Germline SNV and indel priors = variants per base of the target contigs, truncated to their first
+    significant digit (vcflib.py:596-613): a reference sample counts its het sites twice, any other sample its
+    het and hom-alt sites once."""
+    from .normcounts import read_fasta
+    from .util import get_truncated_float
+    refseq = read_fasta(ref_file)
+    target_sum = sum(len(refseq[chrom]) for chrom in chrom_lst)
+    hetsnp, homsnp, hetindel, homindel = load_germline_counts(vcf_file, chrom_lst)
+    if reference_sample:
+        snv, indel = (2 * hetsnp) / target_sum, (2 * hetindel) / target_sum
+    else:
+        snv, indel = (hetsnp + homsnp) / target_sum, (hetindel + homindel) / target_sum
+    return get_truncated_float(snv), get_truncated_float(indel)

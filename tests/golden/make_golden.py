@@ -455,6 +455,58 @@ def phase_case(case, cfg, min_bq=20, min_mapq=20, min_p_value=0.0001, min_phase_
     save(case, exp, batch=b)
 
 
+def germline_priors_case(tmpdir="/tmp"):
+    """vcflib.get_germline_priors / load_germline_counts / util.get_truncated_float (the --non_human_sample priors)."""
+    ref = H.load_reference_norm_host()
+    rs = np.random.RandomState(5)
+    fa = os.path.join(tmpdir, "gp.fa")
+    sizes = {"chrA": 120_000, "chrB": 45_000, "chrC": 9_000}
+    with open(fa, "w") as o:
+        for name, L in sizes.items():
+            seq = "".join("ACGT"[i] for i in rs.randint(0, 4, L))
+            o.write(">{} some description\n".format(name))
+            for k in range(0, L, 70):
+                o.write(seq[k:k + 70] + "\n")
+    vcf = os.path.join(tmpdir, "gp.germline.vcf")
+    rows = []
+    for name, L in sizes.items():
+        for k in range(int(L * 2e-3)):
+            pos = int(rs.randint(1, L))
+            kind = rs.rand()
+            gt = ["0/1", "1/1", "1/0", "0|1", "1/2"][int(rs.choice(5, p=[0.5, 0.3, 0.08, 0.07, 0.05]))]
+            flt = "PASS" if rs.rand() < 0.9 else "RefCall"
+            if kind < 0.75:
+                r_, a_ = "ACGT"[rs.randint(4)], "ACGT"[rs.randint(4)]
+            elif kind < 0.85:
+                r_, a_ = "A" + "C" * int(rs.randint(1, 4)), "A"
+            elif kind < 0.95:
+                r_, a_ = "G", "G" + "T" * int(rs.randint(1, 4))
+            elif kind < 0.98:
+                r_, a_ = "AC", "GT"
+            else:
+                r_, a_ = "A", "C,G"
+            rows.append((name, pos, r_, a_, flt, gt))
+    rows.sort()
+    with open(vcf, "w") as o:
+        o.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsyn\n")
+        for name, pos, r_, a_, flt, gt in rows:
+            o.write("{}\t{}\t.\t{}\t{}\t33\t{}\t.\tGT:GQ\t{}:30\n".format(name, pos, r_, a_, flt, gt))
+    exp = {"fasta_text": open(fa).read(), "vcf_text": open(vcf).read(), "cases": []}
+    for chroms in (["chrA"], ["chrA", "chrB"], ["chrB", "chrC"], ["chrC"]):
+        for refsample in (False, True):
+            counts = ref.vcflib.load_germline_counts(vcf, chroms)
+            try:
+                pri = [float(x) for x in ref.vcflib.get_germline_priors(chroms, fa, vcf, refsample)]
+            except (ValueError, IndexError) as e:       # a frequency of 0 (or >= 0.05) has no truncation
+                pri = type(e).__name__
+            exp["cases"].append({"chrom_lst": chroms, "reference_sample": refsample, "counts": [int(c) for c in counts],
+                                 "priors": pri})
+    core = H.load_reference()
+    exp["truncated"] = [[f, core.util.get_truncated_float(f)] for f in
+                        (0.0012345, 0.00099, 0.0409, 1e-6, 3.3e-5, 0.0005, 0.00149, 7.5e-9, 0.0449)]
+    save("germline_priors", exp)
+
+
 def norm_host_case(tmpdir="/tmp"):
     """The host side of `himut normcounts` around the worker: thresholds from the SBS file's header, SBS96 counts,
     genome trinucleotide counts, the output table and norm.log, the command line."""
@@ -584,6 +636,8 @@ def main():
                 b.qid[j] = b.qid[i]
         worker_case("worker_flags", small_cfg(108, contig_len=20000, name="chrF", som_rate=2e-4), md_threshold=52,
                     mutate=mutate)
+    if want("germline_priors"):
+        germline_priors_case()
     if want("phase_blocks"):
         phase_case("phase_blocks", small_cfg(131, contig_len=60000, snp_rate=3e-3, name="chr9"))
     if want("phase_sparse"):

@@ -119,3 +119,53 @@ def test_call_then_normcounts_end_to_end(tmp_path):
     assert open(tmp_path / "norm.log").read() == open(tmp_path / "exp.log").read()
     assert cmd.startswith("##himut_command=himut normcounts -i {} --ref {} --sbs {}".format(bam, fa, sbs))
     assert sum(log[c][13] for c in chrom_lst) > 1_000_000
+
+
+def test_call_non_human_sample_uses_germline_priors(tmp_path):
+    """--non_human_sample: the germline prior comes from the sample's own VCF and the FASTA
+    (vcflib.get_germline_priors, caller.py:720-723), PoN and common SNPs are ignored (caller.py:248-262); records and
+    counters equal the oracle's with that prior."""
+    import numpy as np
+    from himut_amd import __main__ as cli
+    from himut_amd import bamio, bamlib, caller, synth, util as hutil, vcflib
+    from oracle import oracle as O
+    from tests import util
+    s = synth.generate(synth.SynthConfig(seed=81, contig_len=210_000, read_len_mean=6000, read_len_sd=1200, read_len_min=2000,
+                                         read_len_max=12000, snp_rate=4e-3, som_rate=2e-4, name="chr2"), want_ref=True)
+    b = s.batch
+    bam = str(tmp_path / "in.bam")
+    bamio.write_bam(bam, [b], sample="SMP")
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "w") as o:
+        seq = bytes(s.ref).decode()
+        o.write(">chr2\n")
+        for i in range(0, len(seq), 70):
+            o.write(seq[i:i + 70] + "\n")
+    vcf = str(tmp_path / "germline.vcf")
+    with open(vcf, "w") as o:
+        o.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSMP\n")
+        for p, r, a, g in zip(s.snp_pos, s.snp_ref, s.snp_alt, s.snp_gt):
+            o.write("chr2\t{}\t.\t{}\t{}\t40\tPASS\t.\tGT\t{}\n".format(int(p) + 1, chr(r), chr(a), "0/1" if g in (1, 2) else "1/1"))
+        o.write("chr2\t50\t.\tAC\tA\t40\tPASS\t.\tGT\t0/1\n")
+    snv_prior, indel_prior = vcflib.get_germline_priors(["chr2"], fa, vcf, False)
+    assert 0.002 <= snv_prior <= 0.006 and indel_prior == 5e-06
+    out = str(tmp_path / "calls.vcf")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        cli.main(["call", "-i", bam, "--ref", fa, "--vcf", vcf, "--non_human_sample", "-o", out])
+    finally:
+        os.chdir(cwd)
+    header = [l for l in open(out) if l.startswith("##himut_command")][0]
+    assert "--germline_snv_prior {} --germline_indel_prior 5e-06".format(snv_prior) in header
+    assert header.rstrip().endswith("--non_human_sample")
+    sizes = {"chr2": b.length}
+    chrom_lst, c2c = hutil.load_loci(None, None, sizes)
+    ql, qu, md = bamlib.get_thresholds({"chr2": b}, chrom_lst, sizes)
+    p = dict(util.CALL_DEFAULTS, qlen_lower_limit=ql, qlen_upper_limit=qu, md_threshold=md)
+    orecs, olog = O.call(b, [(c[1], c[2]) for c in c2c["chr2"]], p, snv_prior, None, None, None)
+    vcflib.dump_sbs(str(tmp_path / "exp.vcf"), "#H", chrom_lst, {"chr2": caller.records_to_tuples("chr2", orecs)})
+    body = lambda path: [l for l in open(path) if not l.startswith("#")]
+    assert body(out) == body(str(tmp_path / "exp.vcf")) and len(body(out)) > 100
+    log_rows = [l.split() for l in open(tmp_path / "himut.log")]
+    assert [int(r[1]) for r in log_rows[1:]] == [int(x) for x in olog]

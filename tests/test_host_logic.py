@@ -3,6 +3,8 @@ golden vectors captured from the reference.  CPU only."""
 import os
 import re
 
+import pytest
+
 import numpy as np
 
 from himut_amd import caller, gtlib, util as hutil, vcflib
@@ -201,3 +203,30 @@ def test_record_formatter_matches_reference_vcf_text(tmp_path):
         (vcflib.dump_phased_sbs if phased else vcflib.dump_sbs)(str(ref_out), "#HEADER", [exp["contig"]],
                                                                   {exp["contig"]: caller.records_to_tuples(exp["contig"], recs)})
         assert ref_out.read_text() == out.read_text()
+
+
+def test_germline_priors_match_reference(tmp_path):
+    """--non_human_sample: vcflib.load_germline_counts / get_germline_priors / util.get_truncated_float against
+    values captured from the reference (tests/golden/make_golden.py germline_priors_case)."""
+    from himut_amd import util as hutil, vcflib
+    exp = util.load_json("germline_priors")
+    fa, vcf = os.path.join(str(tmp_path), "gp.fa"), os.path.join(str(tmp_path), "gp.germline.vcf")
+    open(fa, "w").write(exp["fasta_text"])
+    open(vcf, "w").write(exp["vcf_text"])
+    for c in exp["cases"]:
+        assert list(vcflib.load_germline_counts(vcf, c["chrom_lst"])) == c["counts"]
+        if isinstance(c["priors"], str):
+            with pytest.raises((ValueError, IndexError)) as e:
+                vcflib.get_germline_priors(c["chrom_lst"], fa, vcf, c["reference_sample"])
+            assert type(e.value).__name__ == c["priors"]
+        else:
+            assert list(vcflib.get_germline_priors(c["chrom_lst"], fa, vcf, c["reference_sample"])) == c["priors"]
+    for f, want in exp["truncated"]:
+        assert hutil.get_truncated_float(f) == want
+    # a .vcf.bgz is the same records in gzip members
+    import gzip
+    bgz = vcf + ".bgz"
+    with gzip.open(bgz, "wt") as o:
+        o.write(exp["vcf_text"])
+    c = exp["cases"][2]
+    assert list(vcflib.load_germline_counts(bgz, c["chrom_lst"])) == c["counts"]
