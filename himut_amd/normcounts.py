@@ -136,12 +136,21 @@ def read_fasta(path):
     return seqs
 
 
+def _open_sbs(sbs_file):
+    """Lines of the SBS file `himut call` wrote: plain .vcf, or .vcf.bgz read as the gzip members it is made of
+    (the reference goes through cyvcf2, vcflib.py:666-701, mutlib.py:2058-2102)."""
+    if sbs_file.endswith(".vcf"):
+        return open(sbs_file)
+    if sbs_file.endswith(".vcf.bgz"):
+        import gzip
+        return gzip.open(sbs_file, "rt")
+    raise ValueError("SBS file must end in .vcf or .vcf.bgz")
+
+
 def get_thresholds(sbs_file):
     """qlen_lower_limit, qlen_upper_limit, md_threshold from the header `himut call` wrote."""
-    if not sbs_file.endswith(".vcf"):
-        raise ValueError("only plain .vcf SBS files are supported")
     opts, md = {}, None
-    for line in open(sbs_file):
+    for line in _open_sbs(sbs_file):
         if line.startswith("##FILTER=<ID=HighDepth"):
             md = line.strip().split()[-1].replace('">', "")
         elif line.startswith("##himut_command"):
@@ -169,11 +178,9 @@ def get_sbs96(chrom, pos, ref, alt, refseq):
 def load_sbs96_counts(vcf_file, refseq, chrom_lst):
     """SBS96 counts of the PASS bi-allelic SNVs of ``chrom_lst``; classes that contain an N are dropped."""
     from .vcflib import VcfRecord
-    if not vcf_file.endswith(".vcf"):
-        raise ValueError("only plain .vcf SBS files are supported")
     per_chrom = {}
     contigs = []
-    for line in open(vcf_file):
+    for line in _open_sbs(vcf_file):
         if line.startswith("##"):
             if line.startswith("##contig"):
                 contigs.append(line.strip().replace("##contig=<ID=", "").split(",")[0])

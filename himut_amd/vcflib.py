@@ -118,13 +118,11 @@ def load_phased_hetsnps(vcf_file, chrom_lst, tname2tsize):
     """Phase sets of 0|1 / 1|0 records (vcflib.py:617-663).  Returns
     (chrom2ps2hbit, chrom2ps2hpos, chrom2ps2hetsnp, chrom2chunkloci); the chunk
     list becomes one (chrom, first_pos, last_pos) per phase set."""
-    if not vcf_file.endswith(".vcf"):
-        raise ValueError("only plain .vcf phased files are supported (no tabix reader in this build)")
     hbit = {t: defaultdict(list) for t in tname2tsize}
     hpos = {t: defaultdict(list) for t in tname2tsize}
     hsnp = {t: defaultdict(list) for t in tname2tsize}
-    for line in _data_lines(vcf_file):
-        v = VcfRecord(line)
+    # a plain .vcf is read whole, a .bgz contig by contig in the order asked for (the reference's tabix queries)
+    for _, v in _hetsnp_lines(vcf_file, chrom_lst):
         if v.sample_gt in ("0|1", "1|0"):
             if v.alt is None:
                 raise AttributeError("multi-allelic phased record (the reference fails here too)")

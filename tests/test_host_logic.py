@@ -230,3 +230,31 @@ def test_germline_priors_match_reference(tmp_path):
         o.write(exp["vcf_text"])
     c = exp["cases"][2]
     assert list(vcflib.load_germline_counts(bgz, c["chrom_lst"])) == c["counts"]
+
+
+def test_bgz_phased_and_sbs_files_read_like_plain_ones(tmp_path):
+    """.bgz inputs are series of gzip members: the phased-hetSNP loader and the SBS-file readers of normcounts give
+    the same answers for a compressed copy (the reference reads them through tabix / cyvcf2)."""
+    import gzip
+    from himut_amd import normcounts as N
+    exp = util.load_json("phase_blocks")
+    plain = os.path.join(str(tmp_path), "phased.vcf")
+    open(plain, "w").write(exp["phased_vcf_text"])
+    bgz = plain + ".bgz"
+    with gzip.open(bgz, "wt") as o:
+        o.write(exp["phased_vcf_text"])
+    a = vcflib.load_phased_hetsnps(plain, [exp["contig"]], exp["sizes"])
+    b = vcflib.load_phased_hetsnps(bgz, [exp["contig"]], exp["sizes"])
+    assert a[3] == b[3] and {k: dict(v) for k, v in a[0].items()} == {k: dict(v) for k, v in b[0].items()}
+    assert {k: dict(v) for k, v in a[2].items()} == {k: dict(v) for k, v in b[2].items()}
+    host = util.load_json("norm_host")
+    sbs = os.path.join(str(tmp_path), "calls.vcf")
+    open(sbs, "w").write(host["sbs_vcf_text"])
+    with gzip.open(sbs + ".bgz", "wt") as o:
+        o.write(host["sbs_vcf_text"])
+    assert N.get_thresholds(sbs) == N.get_thresholds(sbs + ".bgz")
+    fa = os.path.join(str(tmp_path), "ref.fa")
+    open(fa, "w").write(host["fasta_text"])
+    refseq = N.read_fasta(fa)
+    chroms = list(refseq)
+    assert N.load_sbs96_counts(sbs, refseq, chroms) == N.load_sbs96_counts(sbs + ".bgz", refseq, chroms)
