@@ -41,7 +41,9 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     void reserve(size_t bytes) {
         if (bytes <= cap && p) return;
-        if (p) { HCHECK(hipFree(p)); p = nullptr; cap = 0; }
+        // growing = free + allocate.  Work already queued on the context's (non-blocking) streams may still use the
+        // old block, so the device is drained first; this happens when a contig is larger than the ones before it.
+        if (p) { HCHECK(hipDeviceSynchronize()); HCHECK(hipFree(p)); p = nullptr; cap = 0; }
         size_t want = std::max<size_t>(bytes, 256);
         HCHECK(hipMalloc(&p, want));
         cap = want;
@@ -121,6 +123,10 @@ struct himut_ctx {
 };
 
 namespace {
+
+struct PopcWord {
+    __host__ __device__ uint32_t operator()(uint32_t w) const { return (uint32_t)__builtin_popcount(w); }
+};
 
 // scalars block in device memory
 struct Scalars {
@@ -399,6 +405,18 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     c->d_tilecnt.reserve((size_t)mtiles * 4 + 64);
     c->d_tileoff2.reserve((size_t)mtiles * 4 + 64);
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
+    {   // scratch of the three scans whose lengths the host knows now: sized before anything is queued (growing a
+        // buffer in the middle of a run would free it under the kernels already queued on it)
+        int32_t mp = c->h_prefmax.empty() ? 0 : c->h_prefmax.back(), me = 0;
+        for (int32_t e : c->cend) { mp = std::max(mp, e); me = std::max(me, e); }
+        size_t a = 0, b = 0, d = 0;
+        uint32_t* nul = nullptr;
+        HCHECK(rocprim::exclusive_scan(nullptr, a, nul, nul, 0u, (size_t)std::max<unsigned>(mtiles, 1u), rocprim::plus<uint32_t>(), st));
+        HCHECK(rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator(nul, PopcWord()), nul, 0u,
+                                       (size_t)(((int64_t)mp >> 5) + 3), rocprim::plus<uint32_t>(), st));
+        HCHECK(rocprim::exclusive_scan(nullptr, d, nul, nul, 0u, (size_t)(((int64_t)me >> WIN_SHIFT) + 2), rocprim::plus<uint32_t>(), st));
+        c->d_tmp2.reserve(std::max(std::max(a, b), d) + 256);
+    }
 
     Reads R = make_reads(c);
     Derived D = make_derived(c);
@@ -502,22 +520,21 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         }
         // rank index of the position bitmap + per unique position window / column offset
         c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
-        c->d_poppc.reserve((size_t)(nwords + 2) * 4 + 256);
         c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
         c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
         if (!c->chunks_in_order)    // the in-order emit sweep has set the bits already
             hipLaunchKernelGGL(k_candpos_set, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand_dev, ncap,
                                c->d_posbits_c.as<uint32_t>());
         // rank[w] for w = 0 .. nwords (the last entry is the number of unique candidate positions)
-        hipLaunchKernelGGL(k_word_popc, dim3(blocks_for(nwords + 1, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
-                           nwords + 1, c->d_poppc.as<uint32_t>());
+        // (the bit counts are taken on the fly: the scan reads the bitmap through a transform iterator)
+        auto popc_in = rocprim::make_transform_iterator(c->d_posbits_c.as<uint32_t>(), PopcWord());
         size_t scan2 = 0, scan3 = 0;
-        HCHECK(rocprim::exclusive_scan(nullptr, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
+        HCHECK(rocprim::exclusive_scan(nullptr, scan2, popc_in, c->d_posrank.as<uint32_t>(), 0u,
                                        (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
         HCHECK(rocprim::exclusive_scan(nullptr, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
                                        (size_t)nblk, rocprim::plus<uint32_t>(), st));
         c->d_tmp2.reserve(std::max(std::max(scan2, scan3), scan_tiles) + 256);
-        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
+        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, popc_in, c->d_posrank.as<uint32_t>(), 0u,
                                        (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
         // per 256-position block: slots = candidate positions x reads of the window, then their offsets
         hipLaunchKernelGGL(k_block_slots, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
@@ -805,6 +822,9 @@ int himut_push_reads(himut_ctx* c, const himut_read_batch* b) {
         upload(c->d_qid, b->qid, (size_t)n, st); upload(c->d_qoff, b->qoff, (size_t)n, st);
         upload(c->d_csoff, b->cs_off, (size_t)n + 1, st);
         upload(c->d_seq, b->seq, (size_t)b->seq_bytes, st); upload(c->d_bq, b->bq, (size_t)b->bq_bytes, st);
+        // k_parse_cs takes the text 1 KB at a time, 16 bytes per lane, whatever is left of the tag: the last read's
+        // window runs up to 1 KB past the end of the text
+        c->d_cs.reserve((size_t)b->cs_bytes + 2048);
         upload(c->d_cs, b->cs, (size_t)b->cs_bytes, st);
         upload(c->d_prefmax, c->h_prefmax, st);
         // long-form cs ('=' operations) needs one extra checking kernel; find out once, on the host

@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     // the join, and the first rows of the qualities are in flight here (bq_issue) while the tag is decoded.
     const int last_base = ((max(n, 1) - 1) / PB) * PB;
     uint4 vcur;
-    __builtin_memcpy(&vcur, cs + 16 * lane, 16);                   // buffers carry 256 bytes of slack
+    __builtin_memcpy(&vcur, cs + 16 * lane, 16);                   // himut_push_reads leaves 2 KB of slack behind the text
     BqAhead Q;
     bq_issue(R, r, lane, Q);
     for (int base = 0; base < n; base += PB) {
