@@ -176,14 +176,17 @@ def call_somatic_substitutions(
     """Driver of `himut call` (reference: caller.py:645-838), host side.
 
     Same argument list and the same outputs (out_file, *.single_molecule_mutations.vcf,
-    ./himut.log).  Contigs are handed to the GPUs in ``devices`` round-robin in LPT order,
-    one context per device.  Unlike the reference it returns instead of calling
+    ./himut.log).  Under ``torch.distributed.run`` (one process per GPU) every rank scans its
+    LPT share of the contigs on its own GPU and rank 0 gathers the record buffers and writes
+    the files; in a single process the contigs go through the GPUs in ``devices`` one after the
+    other.  Unlike the reference it returns instead of calling
     sys.exit(0), and input problems raise instead of printing and exiting."""
     import time
     from . import bamio, bamlib, dist, util, vcflib
     t0 = time.time()
     if not out_file.endswith(".vcf"):
         raise ValueError("VCF file must have .vcf suffix")
+    group = dist.join_group(devices)       # (rank, world, device) under torch.distributed.run, else None
     bam = bamio.read_bam(bam_file)
     tname2tsize = bam.tname2tsize
     chrom_lst, chrom2chunkloci_lst = util.load_loci(region, region_list, tname2tsize)       # caller.py:681-682
@@ -191,7 +194,13 @@ def call_somatic_substitutions(
     if phase:                                                                               # caller.py:683-689
         ps2hbit, ps2hpos, ps2hetsnp, chrom2chunkloci_lst = vcflib.load_phased_hetsnps(phased_vcf_file, chrom_lst,
                                                                                       tname2tsize)
-    qlen_lower_limit, qlen_upper_limit, md_threshold = bamlib.get_thresholds(bam.batches, chrom_lst, tname2tsize)
+    if group is None or group[0] == 0:
+        qlen_lower_limit, qlen_upper_limit, md_threshold = bamlib.get_thresholds(bam.batches, chrom_lst, tname2tsize)
+    else:
+        qlen_lower_limit = qlen_upper_limit = md_threshold = 0
+    if group is not None:                  # the sampled thresholds are global: rank 0's three scalars go to everyone
+        qlen_lower_limit, qlen_upper_limit, md_threshold = dist.broadcast_ints(
+            [qlen_lower_limit, qlen_upper_limit, md_threshold])
     if create_panel_of_normals:                                                             # caller.py:707-718
         (min_bq, min_gq, min_qv, min_mapq, min_trim, min_hap_count, min_sequence_identity, phase) = util.load_pon_params()
     if non_human_sample:                                                                    # caller.py:720-723
@@ -206,18 +215,39 @@ def call_somatic_substitutions(
         create_panel_of_normals, version, out_file, bam.sample())
     chrom2tsbs_lst, chrom2tsbs_log, chrom2records = {}, {}, {}
     devices = list(devices) or [0]
-    plan = dist.lpt_assign({c: tname2tsize[c] for c in chrom_lst}, len(devices))
-    for dev, contigs in zip(devices, plan):
-        for chrom in contigs:
-            get_somatic_substitutions(
-                chrom, bam_file, common_snps, panel_of_normals, chrom2chunkloci_lst[chrom],
-                ps2hbit.get(chrom, {}), ps2hpos.get(chrom, {}), ps2hetsnp.get(chrom, {}), min_qv, min_mapq,
-                qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
-                max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
-                somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample,
-                create_panel_of_normals, chrom2tsbs_lst, chrom2tsbs_log, device=dev, read_batch=bam.batches[chrom],
-                chrom2records=chrom2records)
+
+    def scan(chrom, dev):
+        get_somatic_substitutions(
+            chrom, bam_file, common_snps, panel_of_normals, chrom2chunkloci_lst[chrom],
+            ps2hbit.get(chrom, {}), ps2hpos.get(chrom, {}), ps2hetsnp.get(chrom, {}), min_qv, min_mapq,
+            qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
+            max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
+            somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample,
+            create_panel_of_normals, chrom2tsbs_lst, chrom2tsbs_log, device=dev, read_batch=bam.batches[chrom],
+            chrom2records=chrom2records)
+
+    sizes = {c: tname2tsize[c] for c in chrom_lst}
+    if group is not None:
+        # one process per GPU (torch.distributed.run): this rank scans its share of the contigs -- the reference's
+        # starmap axis, caller.py:766-810 -- and one exchange at the end brings every contig's record buffer and
+        # counters to rank 0, which writes the files
+        rank, world, dev = group
+        for chrom in dist.lpt_assign(sizes, world)[rank]:
+            scan(chrom, dev)
+        res = dist.gather_contig_results({c: (chrom2records[c], chrom2tsbs_log[c]) for c in chrom2records},
+                                         chrom_lst, rank, world)
+        if rank != 0:
+            dist.leave_group()
+            return None, None
+        chrom2records = {c: r for c, (r, _) in res.items()}
+        chrom2tsbs_log = {c: l for c, (_, l) in res.items()}
+    else:
+        for dev, contigs in zip(devices, dist.lpt_assign(sizes, len(devices))):
+            for chrom in contigs:
+                scan(chrom, dev)
     vcflib.dump_call_log(chrom_lst, chrom2tsbs_log, path=log_path)                         # caller.py:812-817
     vcflib.dump_records(out_file, vcf_header, chrom_lst, chrom2records, bool(phase))       # = dump_sbs / dump_phased_sbs
     print("himut single molecule somatic mutation detection took {} minutes".format((time.time() - t0) / 60))
+    if group is not None:
+        dist.leave_group()
     return chrom2records, chrom2tsbs_log

@@ -24,6 +24,49 @@ def lpt_assign(contig_len, world):
     return out
 
 
+def join_group(devices=(0,)):
+    """(rank, world, device) when the process was started by torch.distributed.run with more than one rank -- the
+    process group is created on first use (RCCL; ``HIMUT_DIST_BACKEND=gloo`` for rehearsals on a box with fewer
+    GPUs than ranks, every rank then uses devices[0]) -- else None."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 and os.environ.get("HIMUT_DIST_SINGLE") != "1":     # =1: a group of one rank (rehearses the RCCL calls)
+        return None
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("HIMUT_DIST_BACKEND", "nccl")
+    device = local_rank if backend == "nccl" else (list(devices) or [0])[0]
+    torch.cuda.set_device(device)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, device
+
+
+def leave_group():
+    """Barrier + teardown of the process group join_group created."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def broadcast_ints(values, src=0):
+    """The integers of rank ``src`` on every rank."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src)
+    return [int(x) for x in t.tolist()]
+
+
 def gather_contig_results(local, contig_names, rank, world, device_buffers=None, materialize=True):
     """local: {contig: (records structured array, log list of 15)} for the
     contigs this rank scanned.  ``device_buffers``: optional {contig:

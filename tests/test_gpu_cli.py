@@ -169,3 +169,48 @@ def test_call_non_human_sample_uses_germline_priors(tmp_path):
     assert body(out) == body(str(tmp_path / "exp.vcf")) and len(body(out)) > 100
     log_rows = [l.split() for l in open(tmp_path / "himut.log")]
     assert [int(r[1]) for r in log_rows[1:]] == [int(x) for x in olog]
+
+
+def test_call_one_process_per_gpu_matches_single_process(tmp_path):
+    """`himut call` under torch.distributed.run (two ranks; gloo, both on cuda:0 of the one-GPU box): every rank
+    scans its LPT share of the contigs, rank 0 gathers the record buffers and writes the files -- byte-identical
+    to the single-process run."""
+    import subprocess
+    import sys
+    from himut_amd import __main__ as cli
+    from himut_amd import bamio, synth
+    samples = [synth.generate(synth.SynthConfig(seed=90 + k, contig_len=L, read_len_mean=6000, read_len_sd=1200,
+                                                read_len_min=2000, read_len_max=12000, som_rate=2e-4, name=name))
+               for k, (name, L) in enumerate([("chr1", 260_000), ("chr2", 150_000), ("chr10", 90_000), ("chrX", 40_000)])]
+    bam = str(tmp_path / "in.bam")
+    bamio.write_bam(bam, [s.batch for s in samples], sample="SMP")
+    com, pon = str(tmp_path / "common.vcf"), str(tmp_path / "pon.vcf")
+    synth.write_common_snps_vcf(com, samples[0], seed=1, other_contig="chr2")
+    synth.write_pon_vcf(pon, samples[1], seed=1, rate=2e-3)
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    args = ["call", "-i", bam, "--common_snps", com, "--panel_of_normals", pon, "-o"]
+    cwd = os.getcwd()
+    os.chdir(one)
+    try:
+        cli.main(args + [str(one / "calls.vcf")])
+    finally:
+        os.chdir(cwd)
+    env = dict(os.environ, HIMUT_DIST_BACKEND="gloo", PYTHONPATH=cwd + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29655", "-m", "himut_amd"] + args +
+                       [str(two / "calls.vcf")], cwd=str(two), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    strip = lambda p: [l for l in open(p) if not l.startswith(("##fileDate", "##himut_command"))]
+    assert strip(one / "calls.vcf") == strip(two / "calls.vcf") and len(strip(two / "calls.vcf")) > 500
+    # the same driver path over RCCL, as a group of one rank (broadcast, all-reduce and gather on device tensors)
+    solo = tmp_path / "solo"
+    solo.mkdir()
+    env1 = dict(os.environ, HIMUT_DIST_SINGLE="1", PYTHONPATH=env["PYTHONPATH"])
+    r1 = subprocess.run([sys.executable, "-m", "himut_amd"] + args + [str(solo / "calls.vcf")], cwd=str(solo), env=env1,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert strip(one / "calls.vcf") == strip(solo / "calls.vcf")
+    assert open(one / "himut.log").read() == open(two / "himut.log").read()
+    sm = "calls.single_molecule_mutations.vcf"
+    assert strip(one / sm) == strip(two / sm)
