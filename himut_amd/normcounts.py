@@ -310,7 +310,8 @@ def get_normcounts(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, comm
                    out_file, devices=(0,), log_path="norm.log"):
     """Driver of `himut normcounts` (normcounts.py:424-592): same arguments, the same table and norm.log; the PDF
     plot is left out.  Contigs go to the GPUs of ``devices`` round-robin."""
-    from . import bamio, util, vcflib
+    from . import bamio, dist, util, vcflib
+    group = dist.join_group(devices)       # (rank, world, device) under torch.distributed.run, else None
     bam = bamio.read_bam(bam_file)
     tname2tsize = bam.tname2tsize
     chrom_lst, chrom2chunkloci_lst = util.load_loci(region, region_list, tname2tsize)
@@ -323,14 +324,34 @@ def get_normcounts(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, comm
     qlen_lower_limit, qlen_upper_limit, md_threshold = get_thresholds(sbs_file)
     refseq = read_fasta(ref_file)
     ccs, ref, log = {}, {}, {}
-    for k, chrom in enumerate(chrom_lst):
+
+    def sweep(chrom, dev):
         get_callable_tricounts(
             chrom, refseq[chrom], bam_file, common_snps, panel_of_normals, chrom2chunkloci_lst[chrom],
             ps2hbit.get(chrom, {}), ps2hpos.get(chrom, {}), ps2hetsnp.get(chrom, {}), min_qv, min_mapq, min_trim,
             qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, mismatch_window,
             max_mismatch_count, min_ref_count, min_alt_count, min_hap_count, md_threshold, somatic_snv_prior,
             germline_snv_prior, germline_indel_prior, phase, non_human_sample, ccs, ref, log,
-            device=devices[k % len(devices)], read_batch=bam.batches[chrom])
+            device=dev, read_batch=bam.batches[chrom])
+
+    if group is not None:
+        # one process per GPU: each rank sweeps its LPT share of the contigs; the per-contig dictionaries (a few
+        # hundred integers each) are collected on every rank and rank 0 writes the table
+        import torch.distributed as tdist
+        rank, world, dev = group
+        for chrom in dist.lpt_assign({c: tname2tsize[c] for c in chrom_lst}, world)[rank]:
+            sweep(chrom, dev)
+        parts = [None] * world
+        tdist.all_gather_object(parts, (ccs, ref, log))
+        dist.leave_group()
+        if rank != 0:
+            return None, None, None
+        ccs, ref, log = {}, {}, {}
+        for c_, r_, l_ in parts:
+            ccs.update(c_); ref.update(r_); log.update(l_)
+    else:
+        for k, chrom in enumerate(chrom_lst):
+            sweep(chrom, devices[k % len(devices)])
     cmdline = get_normcounts_cmdline(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, min_qv, min_mapq,
                                      min_sequence_identity, min_gq, min_bq, min_trim, mismatch_window,
                                      max_mismatch_count, min_ref_count, min_alt_count, min_hap_count, common_snps,

@@ -180,8 +180,16 @@ def test_call_one_process_per_gpu_matches_single_process(tmp_path):
     from himut_amd import __main__ as cli
     from himut_amd import bamio, synth
     samples = [synth.generate(synth.SynthConfig(seed=90 + k, contig_len=L, read_len_mean=6000, read_len_sd=1200,
-                                                read_len_min=2000, read_len_max=12000, som_rate=2e-4, name=name))
+                                                read_len_min=2000, read_len_max=12000, som_rate=2e-4, name=name),
+                              want_ref=True)
                for k, (name, L) in enumerate([("chr1", 260_000), ("chr2", 150_000), ("chr10", 90_000), ("chrX", 40_000)])]
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "w") as o:
+        for s_ in samples:
+            seq = bytes(s_.ref).decode()
+            o.write(">{}\n".format(s_.batch.name))
+            for i in range(0, len(seq), 70):
+                o.write(seq[i:i + 70] + "\n")
     bam = str(tmp_path / "in.bam")
     bamio.write_bam(bam, [s.batch for s in samples], sample="SMP")
     com, pon = str(tmp_path / "common.vcf"), str(tmp_path / "pon.vcf")
@@ -211,6 +219,21 @@ def test_call_one_process_per_gpu_matches_single_process(tmp_path):
                         capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
     assert strip(one / "calls.vcf") == strip(solo / "calls.vcf")
+    # `himut normcounts` the same two ways
+    nargs = ["normcounts", "-i", bam, "--ref", fa, "--sbs", str(one / "calls.vcf"), "--common_snps", com,
+             "--panel_of_normals", pon, "-o"]
+    os.chdir(one)
+    try:
+        cli.main(nargs + [str(one / "norm.tsv")])
+    finally:
+        os.chdir(cwd)
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29656", "-m", "himut_amd"] + nargs +
+                        [str(two / "norm.tsv")], cwd=str(two), env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    table = lambda p: [l for l in open(p) if not l.startswith("##himut_command")]
+    assert table(one / "norm.tsv") == table(two / "norm.tsv") and len(table(two / "norm.tsv")) > 90
+    assert open(one / "norm.log").read() == open(two / "norm.log").read()
     assert open(one / "himut.log").read() == open(two / "himut.log").read()
     sm = "calls.single_molecule_mutations.vcf"
     assert strip(one / sm) == strip(two / sm)
