@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <future>
 #include <thread>
@@ -31,6 +32,11 @@
 #include <vector>
 
 namespace {
+
+// HIMUT_INGEST_PROFILE=1: seconds per stage of bam_load_threads on stderr
+struct Prof { double inflate0 = 0, wait = 0, hop = 0, decode = 0, place = 0, grow = 0, copy = 0; };
+static Prof g_prof;
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // BGZF reader: the file is mapped, its block headers are walked once (no inflate), and
 // the blocks are inflated a window (~64 MB of output) at a time by a pool of threads --
@@ -188,12 +194,16 @@ struct Bgzf {
         if (!started) {
             started = true;
             if (n_windows() == 0) { eof = true; return false; }
+            const double t0 = now_s();
             const std::string e = inflate_window(0, buf[0]);
+            g_prof.inflate0 += now_s() - t0;
             if (!e.empty()) { err = e; return false; }
             cur = 0;
         } else {
             if (cur + 1 >= n_windows()) { eof = true; return false; }
+            const double t0 = now_s();
             const std::string e = pending.get();
+            g_prof.wait += now_s() - t0;
             if (!e.empty()) { err = e; return false; }
             cur++;
         }
@@ -475,14 +485,22 @@ void* bam_load_threads(const char* path, int threads) {
     };
     auto finish_batch = [&](std::vector<RecInfo>& recs) -> bool {
         std::atomic<int> bad(0);
+        double t0 = now_s();
         run_pool(recs.size(), [&](size_t k) { if (!decode(recs[k])) bad = 1; });
+        g_prof.decode += now_s() - t0;
         if (bad) { perr = "malformed BAM record"; return false; }
+        t0 = now_s();
         for (auto& I : recs) place(I);
+        g_prof.place += now_s() - t0;
+        t0 = now_s();
         for (auto& C : B->contigs)
             if (!C.seq.grow((size_t)(C.bases_padded / 2)) || !C.bq.grow((size_t)C.bases_padded) || !C.cs.grow((size_t)C.cs_n)) {
                 perr = "out of memory"; return false;
             }
+        g_prof.grow += now_s() - t0;
+        t0 = now_s();
         run_pool(recs.size(), [&](size_t k) { copy_bytes(recs[k]); });
+        g_prof.copy += now_s() - t0;
         recs.clear();
         return true;
     };
@@ -492,6 +510,7 @@ void* bam_load_threads(const char* path, int threads) {
         // whole records inside the current window
         if (z.pos == z.len && !z.next_window()) { if (z.eof && z.err.empty()) break; return fail(z.err); }
         const uint8_t* wbuf = z.buf[z.cur & 1].data();
+        const double t_hop = now_s();
         while (z.pos + 4 <= z.len) {
             const uint32_t bs = le32(wbuf + z.pos);
             if (bs < 32) return fail("BAM record too short");
@@ -502,6 +521,7 @@ void* bam_load_threads(const char* path, int threads) {
             recs.push_back(I);
             z.pos += 4 + (size_t)bs;
         }
+        g_prof.hop += now_s() - t_hop;
         if (!finish_batch(recs)) return fail(perr);
         if (z.pos == z.len) continue;
         // a record that runs into the next window: assembled in scratch, handled on its own
@@ -518,6 +538,12 @@ void* bam_load_threads(const char* path, int threads) {
     }
     for (auto& C : B->contigs) { C.cs_off.push_back(C.cs_n); C.first_by_name.clear(); }
     z.close();
+    if (getenv("HIMUT_INGEST_PROFILE")) {
+        fprintf(stderr, "ingest profile (s): first window %.3f, waiting for inflate %.3f, hop %.3f, decode %.3f, place %.3f, "
+                        "grow %.3f, copy %.3f (threads %d)\n", g_prof.inflate0, g_prof.wait, g_prof.hop, g_prof.decode,
+                g_prof.place, g_prof.grow, g_prof.copy, threads);
+        g_prof = Prof();
+    }
     return B;
 }
 
