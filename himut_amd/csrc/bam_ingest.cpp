@@ -234,21 +234,40 @@ struct Bgzf {
 };
 
 // growable byte buffer that does not zero what it grows by
+// A contig's big arrays.  The copy pass that fills them is bound by first-touch page faults, so the arrays live in
+// one anonymous mapping reserved up front (address space only: MAP_NORESERVE) and backed by huge pages where the
+// kernel hands them out; growing inside the reservation costs nothing.  Without a reservation (or past it) the
+// buffer grows by realloc / mremap.
 struct RawBuf {
     uint8_t* p = nullptr;
     size_t n = 0, cap = 0;
+    bool mapped = false;
     RawBuf() = default;
     RawBuf(const RawBuf&) = delete;
     RawBuf& operator=(const RawBuf&) = delete;
-    RawBuf(RawBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
-    ~RawBuf() { free(p); }
+    RawBuf(RawBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), mapped(o.mapped) { o.p = nullptr; o.n = o.cap = 0; o.mapped = false; }
+    ~RawBuf() { if (mapped) munmap(p, cap); else free(p); }
+    void reserve(size_t bytes) {
+        if (p || bytes < ((size_t)8 << 20)) return;
+        bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) return;
+        (void)madvise(m, bytes, MADV_HUGEPAGE);
+        p = (uint8_t*)m; cap = bytes; mapped = true;
+    }
     bool grow(size_t want) {
         if (want > cap) {
             size_t nc = cap ? cap : 4096;
             while (nc < want) nc += nc / 2 + 4096;
-            uint8_t* q = (uint8_t*)realloc(p, nc);
-            if (!q) return false;
-            p = q; cap = nc;
+            if (mapped) {
+                void* q = mremap(p, cap, nc, MREMAP_MAYMOVE);
+                if (q == MAP_FAILED) return false;
+                p = (uint8_t*)q; cap = nc;
+            } else {
+                uint8_t* q = (uint8_t*)realloc(p, nc);
+                if (!q) return false;
+                p = q; cap = nc;
+            }
         }
         n = want;
         return true;
@@ -400,6 +419,8 @@ void* bam_load_threads(const char* path, int threads) {
         int64_t dst_bases, dst_cs; Contig* C;
     };
     std::string perr;
+    size_t inflated_total = 0;              // of the whole file: an upper bound for any contig's bytes
+    for (const BlockRef& b : z.blocks) inflated_total += b.isize;
     auto decode = [&](RecInfo& I) -> bool {
         const uint8_t* rec = I.rec;
         const uint32_t bs = I.bs;
@@ -443,6 +464,10 @@ void* bam_load_threads(const char* path, int threads) {
         if (I.status == 2) { B->n_missing_cs++; return; }
         Contig& C = B->contigs[(size_t)I.ref_id];
         if (!C.tstart.empty() && I.pos < C.tstart.back()) B->n_unsorted++;
+        if (C.tstart.empty()) {             // first record of the contig: reserve address space for its arrays
+            const size_t bound = std::min<size_t>(2 * inflated_total, (size_t)48 << 30);
+            C.bq.reserve(bound); C.seq.reserve(bound / 2); C.cs.reserve(std::min<size_t>(inflated_total, (size_t)16 << 30));
+        }
         const int32_t idx = (int32_t)C.tstart.size();
         C.tstart.push_back(I.pos);
         C.tend.push_back((int32_t)(I.pos + I.ref_len));
