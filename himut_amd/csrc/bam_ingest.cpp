@@ -622,15 +622,13 @@ struct VcfRec {
     uint32_t counts[6], bqsum[4];
 };
 
-int64_t vcf_format_records(const void* records, int64_t n, const char* chrom, int phased, int sm_file, char* out, int64_t cap) {
+static bool vcf_format_slice(const void* records, int64_t k0, int64_t k1, const char* chrom, int phased, int sm_file, std::string& out) {
     static const char* STATUS[] = {"PASS", "LowBQ", "LowGQ", "IndelSite", "HetSite", "HetAltSite", "HomAltSite", "ComSnp",
                                    "PanelOfNormal", "LowDepth", "HighDepth", "Unphased"};
     auto idx = [](int ch) { return ch == 'A' ? 0 : ch == 'T' ? 1 : ch == 'G' ? 2 : 3; };
     const VcfRec* R = (const VcfRec*)records;
-    int64_t w = 0;
-    for (int64_t k = 0; k < n; k++) {
+    for (int64_t k = k0; k < k1; k++) {
         const VcfRec& r = R[k];
-        if (cap - w < 512) return -1;
         const uint32_t* c = r.counts;
         const double depth = (double)(c[0] + c[1] + c[2] + c[3] + c[5]);
         const double ref_count = (double)c[idx(r.ref)];
@@ -657,11 +655,33 @@ int64_t vcf_format_records(const void* records, int64_t n, const char* chrom, in
                          r.ref, r.alt, r.status < 12 ? STATUS[r.status] : "?", fmt, r.gq, alt_bq, depth, ref_count, alt_count,
                          alt_count / depth);
         }
-        if (m < 0 || m >= (int)sizeof(line) - 24) return -1;
-        memcpy(out + w, line, (size_t)m);
-        w += m;
-        if (phased) { out[w++] = ':'; const size_t l = strlen(ps); memcpy(out + w, ps, l); w += (int64_t)l; }
-        out[w++] = '\n';
+        if (m < 0 || m >= (int)sizeof(line) - 24) return false;
+        out.append(line, (size_t)m);
+        if (phased) { out.push_back(':'); out.append(ps); }
+        out.push_back('\n');
+    }
+    return true;
+}
+
+// VCF body lines of n records into out (cap bytes); returns the length, or -1 when cap is too small.  Large inputs
+// are formatted by a few threads, a slice of the records each, and the slices are laid end to end.
+int64_t vcf_format_records(const void* records, int64_t n, const char* chrom, int phased, int sm_file, char* out, int64_t cap) {
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, n / 20000, (int64_t)std::thread::hardware_concurrency()}));
+    std::vector<std::string> part((size_t)nt);
+    std::vector<char> ok((size_t)nt, 1);
+    auto work = [&](int t) {
+        part[(size_t)t].reserve((size_t)((n / nt + 1) * 64));
+        ok[(size_t)t] = vcf_format_slice(records, n * t / nt, n * (t + 1) / nt, chrom, phased, sm_file, part[(size_t)t]) ? 1 : 0;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    int64_t w = 0;
+    for (int t = 0; t < nt; t++) {
+        if (!ok[(size_t)t] || w + (int64_t)part[(size_t)t].size() > cap) return -1;
+        memcpy(out + w, part[(size_t)t].data(), part[(size_t)t].size());
+        w += (int64_t)part[(size_t)t].size();
     }
     return w;
 }
