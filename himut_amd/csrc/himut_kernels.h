@@ -1461,6 +1461,8 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
 #pragma unroll
     for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
     uint32_t ref_count = 0, alt_count = 0, alt_hi = 0, h0_ref = 0, h1_ref = 0, som0 = 0, som1 = 0;
+    double R0 = 0.0, R1 = 0.0, R2 = 0.0, A0 = 0.0, A1 = 0.0, A2 = 0.0;    // the reference / alternative allele's three sums
+    uint32_t Rq = 0, Aq = 0;                                              // and their quality sums
     int bad = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += 8) {     // eight slots in flight: their addresses do not depend on each other
       uint32_t vv[8];
@@ -1482,17 +1484,25 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
             const uint32_t q = v >> 8;
             if (q == 0) bad |= 1 << HIMUT_ERR_BQ0;                     // gtlib.py:64
             const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q];
+            // sums in fetch order per allele (gtlib.py:84-93).  Nearly every cell is the candidate's reference or
+            // alternative allele: those two have accumulators of their own; the four-way update runs for the rest
+            if ((int)cell == ref) {
+                ref_count++; Rq += q;
+                R0 = R0 + vh; R1 = R1 + vt; R2 = R2 + ve;
+            } else if ((int)cell == alt) {
+                alt_count++; Aq += q; if ((int)q >= min_bq) alt_hi++;      // caller.py:160-171
+                A0 = A0 + vh; A1 = A1 + vt; A2 = A2 + ve;
+            } else {
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                if ((int)cell == b) {
-                    cnt[b]++; bqs[b] += q;
-                    S[0][b] = S[0][b] + vh;                            // sums in fetch order (gtlib.py:84-93)
-                    S[1][b] = S[1][b] + vt;
-                    S[2][b] = S[2][b] + ve;
+                for (int b = 0; b < 4; b++) {
+                    if ((int)cell == b) {
+                        cnt[b]++; bqs[b] += q;
+                        S[0][b] = S[0][b] + vh;
+                        S[1][b] = S[1][b] + vt;
+                        S[2][b] = S[2][b] + ve;
+                    }
                 }
             }
-            if ((int)cell == ref) ref_count++;
-            if ((int)cell == alt) { alt_count++; if ((int)q >= min_bq) alt_hi++; }   // caller.py:160-171
             if (PHASE) {
                 uint32_t hp = HAP_NONE;   // the vote counts reads that also cover rpos + 1 (caller.py:558)
                 if (tend > rpos + 1 && ((int)cell == ref || (int)cell == alt))
@@ -1505,6 +1515,12 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
       }
     }
 
+    // the two alleles' accumulators back into their places (ref != alt; nothing else touched those entries)
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        if (b == ref) { cnt[b] = ref_count; bqs[b] = Rq; S[0][b] = R0; S[1][b] = R1; S[2][b] = R2; }
+        if (b == alt) { cnt[b] = alt_count; bqs[b] = Aq; S[0][b] = A0; S[1][b] = A1; S[2][b] = A2; }
+    }
     // ten PLs, gtlib.py:72-110; np.argsort with the scalar insertion sort: ties -> lower index (gtlib.py:113-119)
     double best = 0.0, second = 0.0;
     int ibest = 0;
