@@ -986,7 +986,14 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     const unsigned ex = blocks_for(maxspan, 256 * NE_TILES);
 
     int64_t slots_total = 0;
-    if (c->n > 0 && T.n > 0) {
+    // HIMUT_NORM_SWEEP=store takes the older sweep through a column store in HBM (capture + evaluate, in passes)
+    const char* sweep = getenv("HIMUT_NORM_SWEEP");
+    const bool tiled = !(sweep && strcmp(sweep, "store") == 0);
+    if (c->n > 0 && T.n > 0 && tiled) {
+        A.X = PosIndex{}; A.colstore = nullptr; A.p_lo = 0; A.p_hi = 0;
+        hipLaunchKernelGGL(k_norm_tile, dim3(ex, (unsigned)T.n), dim3(256), 0, st, A, D, c->d_callable.as<uint32_t>(),
+                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk);
+    } else if (c->n > 0 && T.n > 0) {
         for (int64_t p_lo = 0; p_lo < (int64_t)maxend; p_lo += NORM_PASS) {
             const int64_t p_hi = std::min<int64_t>(p_lo + NORM_PASS, maxend);
             bool any = false;
@@ -1034,8 +1041,9 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
             A.X = X; A.colstore = c->d_colstore.as<uint16_t>(); A.p_lo = p_lo; A.p_hi = p_hi;
             hipLaunchKernelGGL(k_norm_eval, dim3(ex, (unsigned)T.n), dim3(256), 0, st, A);
         }
-        hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
     }
+    if (c->n > 0 && T.n > 0)
+        hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
     HCHECK(hipEventRecord(c->ev[EV_FINAL], st));
     c->h_tri.assign(2 * ntri + 16, 0ULL);
     Scalars hs;

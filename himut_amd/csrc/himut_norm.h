@@ -266,6 +266,179 @@ struct NormArgs {
     int* err;
 };
 
+// The per-position state, the per-cell update and the classification of a position are shared by the two sweeps
+// (k_norm_eval over the column store, k_norm_tile over cells built in LDS) as text, so that both compile to the same
+// register-resident code (normcounts.py:243-402; comments in k_norm_eval's history: gtlib.py:72-174 for the sums).
+#define NORM_POS_STATE() \
+        uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}; \
+        double S[3][4]; \
+_Pragma("unroll") \
+        for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; } \
+        double R0 = 0.0, R1 = 0.0, R2 = 0.0; \
+        uint32_t nref = 0; \
+        uint32_t tri_sum = 0, h0 = 0, h1 = 0; \
+        bool bq0 = false;
+
+#define NORM_CELL(V, HP) \
+            { \
+                const uint32_t cell = (V) & 7u; \
+                if ((V) & CELL_INS) cnt[4]++; \
+                if (cell < 4) { \
+                    const uint32_t q = (V) >> 8; \
+                    if (q == 0) bq0 = true; \
+                    const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q]; \
+                    if ((int)cell == ref) { \
+                        nref++; \
+                        R0 = R0 + vh; R1 = R1 + vt; R2 = R2 + ve; \
+                    } else { \
+_Pragma("unroll") \
+                        for (int b = 0; b < 4; b++) { \
+                            if ((int)cell == b) { \
+                                cnt[b]++; \
+                                S[0][b] = S[0][b] + vh; \
+                                S[1][b] = S[1][b] + vt; \
+                                S[2][b] = S[2][b] + ve; \
+                            } \
+                        } \
+                    } \
+                    uint32_t counts_here = ((V) >> 4) & 1u; \
+                    if (phase) { \
+                        const uint32_t hp = (HP); \
+                        if (hp == HAP_0) h0++; else if (hp == HAP_1) h1++; else counts_here = 0; \
+                    } \
+                    tri_sum += counts_here; \
+                } else if (cell == CELL_DEL) cnt[5]++; \
+                else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE; \
+            }
+
+#define NORM_CLASSIFY() \
+        if (ref < 0 || tri_sum == 0) continue; \
+_Pragma("unroll") \
+        for (int b = 0; b < 4; b++) if (b == ref) { cnt[b] = nref; S[0][b] = R0; S[1][b] = R1; S[2][b] = R2; } \
+        if (phase && !((int64_t)h0 >= A.P.p.min_hap_count && (int64_t)h1 >= A.P.p.min_hap_count)) { \
+            atomicAdd(&s_log[1], tri_sum); \
+            atomicAdd(&s_log[2], tri_sum); \
+            continue; \
+        } \
+        if (bq0) { bad |= 1 << HIMUT_ERR_BQ0; continue; } \
+        int slot = 1; \
+        double best = 0.0, second = 0.0; \
+        int ibest = 0; \
+_Pragma("unroll") \
+        for (int g = 0; g < 10; g++) { \
+            const int b1 = (int)HIMUT_GT_B1(g), b2 = (int)HIMUT_GT_B2(g); \
+            double acc = 0.0; \
+_Pragma("unroll") \
+            for (int b = 0; b < 4; b++) { \
+                double term; \
+                if (b1 == b2 && b == b1) term = S[0][b]; \
+                else if (b1 != b2 && (b == b1 || b == b2)) term = S[1][b]; \
+                else term = S[2][b]; \
+                acc = acc + term; \
+            } \
+            acc = acc + s_prior[gt_state_of(b1, b2, ref)]; \
+            const double pl = -10.0 * acc; \
+            if (g == 0) { best = pl; ibest = 0; } \
+            else if (pl < best) { second = best; best = pl; ibest = g; } \
+            else if (g == 1 || pl < second) second = pl; \
+        } \
+        const double gqf = second - best; \
+        const int gq = gqf < 99.0 ? (int)gqf : 99; \
+        const int state = gt_state_of((int)HIMUT_GT_B1(ibest), (int)HIMUT_GT_B2(ibest), ref); \
+        const uint32_t depth = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[5]; \
+        uint32_t ref_count = 0; \
+_Pragma("unroll") \
+        for (int b = 0; b < 4; b++) if (b == ref) ref_count = cnt[b]; \
+        if (state == 1) slot = 3; \
+        else if (state == 2) slot = 4; \
+        else if (state == 3) slot = 5; \
+        else { \
+            atomicAdd(&s_log[6], tri_sum); \
+            if (cnt[5] != 0 || cnt[4] != 0) slot = 7; \
+            else if ((int64_t)depth > A.P.p.md_threshold) slot = 8; \
+            else if (depth == ref_count) { \
+                if (gq < A.P.p.min_gq) slot = 10; \
+                else if ((int64_t)ref_count < A.P.p.min_ref_count) slot = 9; \
+                else slot = 13; \
+            } else { \
+                bool filtered = false; \
+                uint32_t ac[3] = {0, 0, 0}; \
+                const int32_t tpos = (int32_t)rpos + 1; \
+                const SiteSets& St = A.S; \
+                const bool site_maybe = !A.non_human && (int64_t)tpos < St.nposbits && ((St.posbits[tpos >> 5] >> (tpos & 31)) & 1u); \
+_Pragma("unroll") \
+                for (int a = 0; a < 3; a++) { \
+                    if (filtered) continue; \
+                    const int aidx = A.alt_order[ref * 3 + a]; \
+                    uint32_t c = 0; \
+_Pragma("unroll") \
+                    for (int b = 0; b < 4; b++) if (b == aidx) c = cnt[b]; \
+                    ac[a] = c; \
+                    if (c == 0 || !site_maybe) continue; \
+                    const uint64_t key = ((uint64_t)(uint32_t)tpos << 4) | ((uint64_t)ref << 2) | (uint64_t)aidx; \
+                    if (key_in(St.pon, St.npon, key)) { filtered = true; slot = 11; } \
+                    else if (key_in(St.com, St.ncom, key)) { filtered = true; slot = 12; } \
+                } \
+                if (!filtered) { \
+                    int bi = 0; \
+                    if (ac[1] > ac[bi]) bi = 1; \
+                    if (ac[2] > ac[bi]) bi = 2; \
+                    const int aidx = A.alt_order[ref * 3 + bi]; \
+                    double b2best = 0.0, b2second = 0.0; \
+_Pragma("unroll") \
+                    for (int g = 0; g < 10; g++) { \
+                        const int b1 = (int)HIMUT_GT_B1(g), b2 = (int)HIMUT_GT_B2(g); \
+                        double acc = 0.0; \
+_Pragma("unroll") \
+                        for (int b = 0; b < 4; b++) { \
+                            if (b == aidx) continue; \
+                            double term; \
+                            if (b1 == b2 && b == b1) term = S[0][b]; \
+                            else if (b1 != b2 && (b == b1 || b == b2)) term = S[1][b]; \
+                            else term = S[2][b]; \
+                            acc = acc + term; \
+                        } \
+                        acc = acc + s_prior[gt_state_of(b1, b2, ref)]; \
+                        const double pl = acc * -10.0; \
+                        if (g == 0) b2best = pl; \
+                        else if (pl < b2best) { b2second = b2best; b2best = pl; } \
+                        else if (g == 1 || pl < b2second) b2second = pl; \
+                    } \
+                    const double g2 = b2second - b2best; \
+                    const int gq2 = g2 < 99.0 ? (int)g2 : 99; \
+                    uint32_t alt_count = ac[bi]; \
+                    if (gq2 < A.P.p.min_gq) slot = 10; \
+                    else if (!((int64_t)ref_count >= A.P.p.min_ref_count && (int64_t)alt_count >= A.P.p.min_alt_count)) slot = 9; \
+                    else slot = 13; \
+                } \
+            } \
+        } \
+        atomicAdd(&s_log[1], tri_sum); \
+        atomicAdd(&s_log[slot], tri_sum); \
+        if (slot == 13) { \
+            int t0 = 'N', t1 = 'N', t2 = 'N'; \
+            if (rpos - 1 >= 0 && rpos + 2 <= A.reflen) { \
+                t0 = A.refseq[rpos - 1]; t1 = refc; t2 = A.refseq[rpos + 1]; \
+                if (t1 == 'A' || t1 == 'G') { \
+                    const int a0 = t2, a2 = t0; \
+                    t0 = a0 == 'A' ? 'T' : a0 == 'T' ? 'A' : a0 == 'G' ? 'C' : a0 == 'C' ? 'G' : 'N'; \
+                    t1 = t1 == 'A' ? 'T' : 'C'; \
+                    t2 = a2 == 'A' ? 'T' : a2 == 'T' ? 'A' : a2 == 'G' ? 'C' : a2 == 'C' ? 'G' : 'N'; \
+                } \
+            } \
+            auto acgt = [](int c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }; \
+            const int i0 = acgt(t0), i2 = acgt(t2); \
+            if (i0 >= 0 && i2 >= 0 && (t1 == 'C' || t1 == 'T')) { \
+                const int k = i0 * 8 + (t1 == 'T' ? 4 : 0) + i2; \
+                atomicAdd(&s_ccs[k], tri_sum); \
+                atomicAdd(&s_ref[k], 1u); \
+            } else { \
+                const int64_t k = ((int64_t)A.cls[t0] * A.K + A.cls[t1]) * A.K + A.cls[t2]; \
+                atomicAdd(&A.ccs_tri[k], (unsigned long long)tri_sum); \
+                atomicAdd(&A.ref_tri[k], 1ULL); \
+            } \
+        }
+
 constexpr int NE_TILES = 16;     // 256-position tiles per workgroup
 
 __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
@@ -294,14 +467,7 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
         const int32_t lo = bt.lo;
         const uint16_t* col = A.colstore + ((int64_t)bt.boff + (int64_t)(u - bt.ufirst));
         const bool edge = rpos <= cs_;
-        uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
-        double S[3][4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) { S[0][b] = 0.0; S[1][b] = 0.0; S[2][b] = 0.0; }
-        double R0 = 0.0, R1 = 0.0, R2 = 0.0;     // the three sums of the reference allele
-        uint32_t nref = 0;
-        uint32_t tri_sum = 0, h0 = 0, h1 = 0;
-        bool bq0 = false;
+        NORM_POS_STATE()
         const bool phase = A.P.p.phase != 0;
         const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
         // eight slots of the column are in flight at a time (their addresses do not depend on each other)
@@ -312,168 +478,176 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t v = vv[k];
-                const uint32_t cell = v & 7u;
                 if ((v & 15u) == CELL_EMPTY) continue;
                 if (edge && !(A.R.tend[lo + (int32_t)(i0 + k)] > cs_)) continue;   // not fetched by this chunk (normcounts.py:289)
-                if (v & CELL_INS) cnt[4]++;
-                if (cell < 4) {
-                    const uint32_t q = v >> 8;
-                    if (q == 0) bq0 = true;
-                    const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q];
-                    if ((int)cell == ref) {            // nearly every cell: the reference allele has registers of its own
-                        nref++;
-                        R0 = R0 + vh; R1 = R1 + vt; R2 = R2 + ve;
-                    } else {
+                NORM_CELL(v, A.H.hap[pairbase + lo + (int32_t)(i0 + k)])
+            }
+        }
+        NORM_CLASSIFY()
+    }
+    __syncthreads();
+    if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
+    if (tid < 32 && (s_ccs[tid] || s_ref[tid])) {
+        const int cl[4] = {A.cA, A.cC, A.cG, A.cT};
+        const int64_t k = ((int64_t)cl[tid >> 3] * A.K + ((tid & 4) ? A.cT : A.cC)) * A.K + cl[tid & 3];
+        atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
+        atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
+    }
+    if (bad) atomicOr(A.err, bad);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_norm_tile: the same sweep without a column store.  A workgroup takes tiles of 256 positions of one chunk; the
+// reads that can cover a tile (the window index of its one or two 256-position blocks) are its rows.  Rows are
+// handled NT_ROWS at a time: the four waves build the rows' cells in LDS -- a lane owns four consecutive positions
+// of a row, finds them in the read's segment list, and loads the four qualities, the four packed bases and the
+// four callable bits with one unaligned load each -- then every thread runs down its own column in read order.
+// Nothing is written to HBM except the counters.
+constexpr int NT_ROWS = 48;
+constexpr int NT_RPW = NT_ROWS / 4;    // rows per wave and batch
+
+__global__ void __launch_bounds__(256) k_norm_tile(NormArgs A, Derived D, const uint32_t* callable, const int32_t* winlo,
+                                                   const int32_t* winhi, int64_t nblk) {
+    __shared__ double s_lut[3 * 256];
+    __shared__ double s_prior[4];
+    __shared__ unsigned int s_log[16];
+    __shared__ unsigned int s_ccs[32], s_ref[32];
+    __shared__ __align__(16) uint16_t s_cells[NT_ROWS][256];
+    __shared__ int32_t s_tend[NT_ROWS];
+    __shared__ uint32_t s_hap[NT_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
+    for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = A.lut->t[i >> 8][i & 255];
+    if (tid < 4) s_prior[tid] = A.lut->prior[tid];
+    if (tid < 16) s_log[tid] = 0;
+    if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
+    __syncthreads();
+    const int chunk = blockIdx.y;
+    const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
+    const bool phase = A.P.p.phase != 0;
+    const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
+    const Reads& R = A.R;
+    int bad = 0;
+    for (int t = 0; t < NE_TILES; t++) {
+        const int64_t base = (int64_t)cs_ + ((int64_t)blockIdx.x * NE_TILES + t) * 256;
+        if (base >= ce_) break;                                   // the same for every thread
+        const int64_t rpos = base + tid;
+        bool valid = rpos < ce_;
+        if (valid && (rpos < 0 || rpos >= A.reflen)) { bad |= 1 << HIMUT_ERR_ARG; valid = false; }   // IndexError in the reference
+        const int refc = valid ? (int)A.refseq[rpos] : 'N';
+        const int ref = char2allele(refc);
+        const bool edge = rpos <= cs_;
+        NORM_POS_STATE()
+        // rows: the reads of the window index of the blocks under the tile
+        const int64_t b0 = min(max(base, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min((base + 255) >> WIN_SHIFT, nblk - 1);
+        const int32_t lo = winlo[b0], hi = winhi[b1];
+        const int32_t P0 = (int32_t)base + 4 * lane;              // this lane's four positions of every row
+        for (int32_t r0 = lo; r0 < hi; r0 += NT_ROWS) {
+            const int nb = min(NT_ROWS, hi - r0);
+            // ---- the wave's rows, one per lane for the part that is a chain of dependent loads: read header, first
+            //      segment that reaches the tile (binary search), the four segments from there on
+            const int myrow = wv + 4 * lane;                      // rows wv, wv + 4, ... of the batch
+            const bool rowlane = lane < NT_RPW && myrow < nb;
+            ReadMeta M;
+            M.tstart = 0; M.tend = 0; M.nseg = 0; M.flags = RF_SECONDARY; M.segbase = 0; M.qoff = 0;
+            if (rowlane) M = D.meta[r0 + myrow];
+            const bool live_row = rowlane && !(M.flags & RF_SECONDARY) && M.nseg > 0 && M.tstart < base + 256 && M.tend >= base;
+            int j0 = 0;
+            if (live_row) {                                       // last segment that starts at or before the tile
+                int a = 0, e = M.nseg;
+                while (a < e) { const int m = (a + e) >> 1; if (D.segs[M.segbase + m].t0 <= (int32_t)base) a = m + 1; else e = m; }
+                j0 = max(a - 1, 0);
+            }
+            int4 sg[4];
 #pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            if ((int)cell == b) {
-                                cnt[b]++;
-                                S[0][b] = S[0][b] + vh;
-                                S[1][b] = S[1][b] + vt;
-                                S[2][b] = S[2][b] + ve;
+            for (int k = 0; k < 4; k++) {
+                sg[k] = make_int4(0x7fffffff, 0, 0, 0);
+                if (live_row && j0 + k < M.nseg) sg[k] = *reinterpret_cast<const int4*>(D.segs + M.segbase + j0 + k);
+            }
+            if (rowlane) {
+                s_tend[myrow] = M.tend;
+                uint32_t hp = HAP_NONE;
+                if (phase && live_row && M.tstart < ce_ && M.tend > cs_) hp = A.H.hap[pairbase + r0 + myrow];   // fetched by the chunk
+                s_hap[myrow] = hp;
+            }
+            // ---- one row at a time, four positions per lane
+            for (int l = 0; l < NT_RPW; l++) {
+                const int row = wv + 4 * l;
+                if (row >= nb) break;
+                const bool rlive = lane_val((int)live_row, l) != 0;
+                uint32_t cell[4] = {CELL_EMPTY, CELL_EMPTY, CELL_EMPTY, CELL_EMPTY};
+                if (rlive) {
+                    const int ns = lane_val(M.nseg, l), jf = lane_val(j0, l);
+                    const int64_t segbase = ((int64_t)lane_val((int)(M.segbase >> 32), l) << 32) | (uint32_t)lane_val((int)M.segbase, l);
+                    const int64_t qoff = ((int64_t)lane_val((int)(M.qoff >> 32), l) << 32) | (uint32_t)lane_val((int)M.qoff, l);
+                    for (int j = jf; j < ns; j++) {
+                        int4 sv;
+                        const int k = j - jf;
+                        if (k < 4) {
+                            const int4 c0 = sg[0], c1 = sg[1], c2 = sg[2], c3 = sg[3];
+                            const int4 c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                            sv = make_int4(lane_val(c.x, l), lane_val(c.y, l), lane_val(c.z, l), lane_val(c.w, l));
+                        } else {
+                            const Seg g = D.segs[segbase + j];
+                            sv = make_int4(uni(g.t0), uni(g.q0), uni(g.len), uni((int)g.flags));
+                        }
+                        const int32_t t0 = sv.x, q0 = sv.y, len = sv.z;
+                        const uint32_t fl = (uint32_t)sv.w;
+                        if (t0 >= base + 256) break;
+                        const int32_t span = len > 0 ? len : ((fl & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
+                        const int32_t a = max(P0, t0), e = min(P0 + 4, t0 + span);
+                        if (a >= e) continue;
+                        if (fl & SEG_DEL) {
+#pragma unroll
+                            for (int x = 0; x < 4; x++)
+                                if (P0 + x >= a && P0 + x < e) cell[x] = CELL_DEL | ((P0 + x == t0 && (fl & SEG_INS)) ? CELL_INS : 0u);
+                        } else if (len == 0) {
+#pragma unroll
+                            for (int x = 0; x < 4; x++) if (P0 + x == t0) cell[x] = CELL_EMPTY | CELL_INS;
+                        } else {
+                            // up to four consecutive query bases from K on: qualities, packed bases (high nibble first) and
+                            // callable bits, each with one unaligned load (the buffers carry slack behind the last read)
+                            const int64_t K = qoff + q0 + (a - t0);
+                            uint32_t qv, sb;
+                            __builtin_memcpy(&qv, R.bq + K, 4);
+                            __builtin_memcpy(&sb, R.seq + (K >> 1), 4);
+                            const uint64_t cw = (uint64_t)callable[K >> 5] | ((uint64_t)callable[(K >> 5) + 1] << 32);
+                            const uint32_t cb = (uint32_t)(cw >> (K & 31));
+                            // nibble of base K + y: byte (K + y) >> 1, high half when K + y is even
+                            const uint32_t odd = (uint32_t)(K & 1);
+#pragma unroll
+                            for (int x = 0; x < 4; x++) {
+                                const int y = P0 + x - a;                                   // index among the loaded bases
+                                if (y >= 0 && P0 + x < e) {
+                                    const uint32_t kk = (uint32_t)y + odd;                  // nibble index from the first loaded byte
+                                    const uint32_t byte = (sb >> (8 * (kk >> 1))) & 0xffu;
+                                    const int nib = (kk & 1) ? (int)(byte & 15u) : (int)(byte >> 4);
+                                    uint32_t val = (uint32_t)nib2allele(nib) | (((qv >> (8 * y)) & 0xffu) << 8) | (((cb >> y) & 1u) << 4);
+                                    if (P0 + x == t0 && (fl & SEG_INS)) val |= CELL_INS;
+                                    cell[x] = val;
+                                }
                             }
                         }
                     }
-                    uint32_t counts_here = (v >> 4) & 1u;
-                    if (phase) {       // rpos2hap2count over match and substitution bases; only phased reads are callable
-                        const uint32_t hp = A.H.hap[pairbase + lo + (int32_t)(i0 + k)];
-                        if (hp == HAP_0) h0++; else if (hp == HAP_1) h1++; else counts_here = 0;
-                    }
-                    tri_sum += counts_here;
-                } else if (cell == CELL_DEL) cnt[5]++;
-                else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE;           // normcounts.py:126
-            }
-        }
-        if (ref < 0 || tri_sum == 0) continue;                                  // normcounts.py:318-321
-#pragma unroll
-        for (int b = 0; b < 4; b++) if (b == ref) { cnt[b] = nref; S[0][b] = R0; S[1][b] = R1; S[2][b] = R2; }
-        if (phase && !((int64_t)h0 >= A.P.p.min_hap_count && (int64_t)h1 >= A.P.p.min_hap_count)) {
-            atomicAdd(&s_log[1], tri_sum);                                      // is_rpos_phased (normcounts.py:198-205,324-328)
-            atomicAdd(&s_log[2], tri_sum);
-            continue;
-        }
-        if (bq0) { bad |= 1 << HIMUT_ERR_BQ0; continue; }
-        int slot = 1;   // which counter takes tri_sum besides num_bases; 13 = callable
-        // get_germ_gt (gtlib.py:72-135)
-        double best = 0.0, second = 0.0;
-        int ibest = 0;
-#pragma unroll
-        for (int g = 0; g < 10; g++) {
-            const int b1 = (int)HIMUT_GT_B1(g), b2 = (int)HIMUT_GT_B2(g);
-            double acc = 0.0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                double term;
-                if (b1 == b2 && b == b1) term = S[0][b];
-                else if (b1 != b2 && (b == b1 || b == b2)) term = S[1][b];
-                else term = S[2][b];
-                acc = acc + term;
-            }
-            acc = acc + s_prior[gt_state_of(b1, b2, ref)];
-            const double pl = -10.0 * acc;
-            if (g == 0) { best = pl; ibest = 0; }
-            else if (pl < best) { second = best; best = pl; ibest = g; }
-            else if (g == 1 || pl < second) second = pl;
-        }
-        const double gqf = second - best;
-        const int gq = gqf < 99.0 ? (int)gqf : 99;
-        const int state = gt_state_of((int)HIMUT_GT_B1(ibest), (int)HIMUT_GT_B2(ibest), ref);
-        const uint32_t depth = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[5];
-        uint32_t ref_count = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) if (b == ref) ref_count = cnt[b];
-        if (state == 1) slot = 3;
-        else if (state == 2) slot = 4;
-        else if (state == 3) slot = 5;
-        else {
-            atomicAdd(&s_log[6], tri_sum);                                      // num_homref_bases
-            if (cnt[5] != 0 || cnt[4] != 0) slot = 7;
-            else if ((int64_t)depth > A.P.p.md_threshold) slot = 8;
-            else if (depth == ref_count) {
-                if (gq < A.P.p.min_gq) slot = 10;
-                else if ((int64_t)ref_count < A.P.p.min_ref_count) slot = 9;
-                else slot = 13;
-            } else {
-                // the alternative alleles in the order python's set gives them (normcounts.py:367-385)
-                bool filtered = false;
-                uint32_t ac[3] = {0, 0, 0};
-                const int32_t tpos = (int32_t)rpos + 1;
-                const SiteSets& St = A.S;
-                const bool site_maybe = !A.non_human && (int64_t)tpos < St.nposbits && ((St.posbits[tpos >> 5] >> (tpos & 31)) & 1u);
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    if (filtered) continue;
-                    const int aidx = A.alt_order[ref * 3 + a];
-                    uint32_t c = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) if (b == aidx) c = cnt[b];
-                    ac[a] = c;
-                    if (c == 0 || !site_maybe) continue;
-                    const uint64_t key = ((uint64_t)(uint32_t)tpos << 4) | ((uint64_t)ref << 2) | (uint64_t)aidx;
-                    if (key_in(St.pon, St.npon, key)) { filtered = true; slot = 11; }
-                    else if (key_in(St.com, St.ncom, key)) { filtered = true; slot = 12; }
                 }
-                if (!filtered) {
-                    int bi = 0;
-                    if (ac[1] > ac[bi]) bi = 1;
-                    if (ac[2] > ac[bi]) bi = 2;
-                    const int aidx = A.alt_order[ref * 3 + bi];
-                    // get_germ_gq(alt, ...): the same ten sums without the alternative allele (gtlib.py:138-174)
-                    double b2best = 0.0, b2second = 0.0;
-#pragma unroll
-                    for (int g = 0; g < 10; g++) {
-                        const int b1 = (int)HIMUT_GT_B1(g), b2 = (int)HIMUT_GT_B2(g);
-                        double acc = 0.0;
-#pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            if (b == aidx) continue;
-                            double term;
-                            if (b1 == b2 && b == b1) term = S[0][b];
-                            else if (b1 != b2 && (b == b1 || b == b2)) term = S[1][b];
-                            else term = S[2][b];
-                            acc = acc + term;
-                        }
-                        acc = acc + s_prior[gt_state_of(b1, b2, ref)];
-                        const double pl = acc * -10.0;
-                        if (g == 0) b2best = pl;
-                        else if (pl < b2best) { b2second = b2best; b2best = pl; }
-                        else if (g == 1 || pl < b2second) b2second = pl;
-                    }
-                    const double g2 = b2second - b2best;
-                    const int gq2 = g2 < 99.0 ? (int)g2 : 99;
-                    uint32_t alt_count = ac[bi];
-                    if (gq2 < A.P.p.min_gq) slot = 10;
-                    else if (!((int64_t)ref_count >= A.P.p.min_ref_count && (int64_t)alt_count >= A.P.p.min_alt_count)) slot = 9;
-                    else slot = 13;
+                uint2 packed;
+                packed.x = cell[0] | (cell[1] << 16);
+                packed.y = cell[2] | (cell[3] << 16);
+                *reinterpret_cast<uint2*>(&s_cells[row][4 * lane]) = packed;
+            }
+            __syncthreads();
+            // ---- every thread down its column, in read order
+            if (valid) {
+                for (int i = 0; i < nb; i++) {
+                    const uint32_t v = s_cells[i][tid];
+                    if ((v & 15u) == CELL_EMPTY) continue;
+                    if (edge && !(s_tend[i] > cs_)) continue;                               // not fetched by this chunk (normcounts.py:289)
+                    NORM_CELL(v, s_hap[i])
                 }
             }
+            __syncthreads();
         }
-        atomicAdd(&s_log[1], tri_sum);
-        atomicAdd(&s_log[slot], tri_sum);
-        if (slot == 13) {
-            // get_tri_context (normcounts.py:49-63)
-            int t0 = 'N', t1 = 'N', t2 = 'N';
-            if (rpos - 1 >= 0 && rpos + 2 <= A.reflen) {
-                t0 = A.refseq[rpos - 1]; t1 = refc; t2 = A.refseq[rpos + 1];
-                if (t1 == 'A' || t1 == 'G') {
-                    const int a0 = t2, a2 = t0;
-                    t0 = a0 == 'A' ? 'T' : a0 == 'T' ? 'A' : a0 == 'G' ? 'C' : a0 == 'C' ? 'G' : 'N';
-                    t1 = t1 == 'A' ? 'T' : 'C';
-                    t2 = a2 == 'A' ? 'T' : a2 == 'T' ? 'A' : a2 == 'G' ? 'C' : a2 == 'C' ? 'G' : 'N';
-                }
-            }
-            auto acgt = [](int c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
-            const int i0 = acgt(t0), i2 = acgt(t2);
-            if (i0 >= 0 && i2 >= 0 && (t1 == 'C' || t1 == 'T')) {
-                const int k = i0 * 8 + (t1 == 'T' ? 4 : 0) + i2;
-                atomicAdd(&s_ccs[k], tri_sum);
-                atomicAdd(&s_ref[k], 1u);
-            } else {
-                const int64_t k = ((int64_t)A.cls[t0] * A.K + A.cls[t1]) * A.K + A.cls[t2];
-                atomicAdd(&A.ccs_tri[k], (unsigned long long)tri_sum);
-                atomicAdd(&A.ref_tri[k], 1ULL);
-            }
-        }
+        if (!valid) continue;
+        NORM_CLASSIFY()
     }
     __syncthreads();
     if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
