@@ -281,12 +281,18 @@ _Pragma("unroll") \
 
 #define NORM_CELL(V, HP) \
             { \
+                const uint32_t q_ = (V) >> 8; \
+                NORM_CELL_L(V, HP, s_lut[q_], s_lut[256 + q_], s_lut[512 + q_]) \
+            }
+
+#define NORM_CELL_L(V, HP, VH, VT, VE) \
+            { \
                 const uint32_t cell = (V) & 7u; \
                 if ((V) & CELL_INS) cnt[4]++; \
                 if (cell < 4) { \
                     const uint32_t q = (V) >> 8; \
                     if (q == 0) bq0 = true; \
-                    const double vh = s_lut[q], vt = s_lut[256 + q], ve = s_lut[512 + q]; \
+                    const double vh = (VH), vt = (VT), ve = (VE); \
                     if ((int)cell == ref) { \
                         nref++; \
                         R0 = R0 + vh; R1 = R1 + vt; R2 = R2 + ve; \
@@ -309,6 +315,44 @@ _Pragma("unroll") \
                     tri_sum += counts_here; \
                 } else if (cell == CELL_DEL) cnt[5]++; \
                 else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE; \
+            }
+
+// The same update without a branch on the common path (the tile sweep's inner loop): a cell that is skipped or is
+// not the reference allele adds +0.0 to the reference allele's sums, which leaves them bit for bit as they were (they
+// start at +0.0 and only negative terms are added, so they are never -0.0); the other alleles, rare, keep the branch.
+#define NORM_CELL_BF(V, USE, HP, VH, VT, VE) \
+            { \
+                const uint32_t cell = (V) & 7u; \
+                const bool use_ = (USE); \
+                const bool base_ = use_ && cell < 4; \
+                const bool isref_ = base_ && (int)cell == ref; \
+                cnt[4] += (use_ && ((V) & CELL_INS)) ? 1u : 0u; \
+                cnt[5] += (use_ && cell == CELL_DEL) ? 1u : 0u; \
+                if (use_ && cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE; \
+                const uint32_t q = (V) >> 8; \
+                bq0 = bq0 || (base_ && q == 0); \
+                nref += isref_ ? 1u : 0u; \
+                const double vh = (VH), vt = (VT), ve = (VE); \
+                R0 = R0 + (isref_ ? vh : 0.0); R1 = R1 + (isref_ ? vt : 0.0); R2 = R2 + (isref_ ? ve : 0.0); \
+                if (base_ && !isref_) { \
+_Pragma("unroll") \
+                    for (int b = 0; b < 4; b++) { \
+                        if ((int)cell == b) { \
+                            cnt[b]++; \
+                            S[0][b] = S[0][b] + vh; \
+                            S[1][b] = S[1][b] + vt; \
+                            S[2][b] = S[2][b] + ve; \
+                        } \
+                    } \
+                } \
+                uint32_t counts_here = base_ ? (((V) >> 4) & 1u) : 0u; \
+                if (phase) { \
+                    const uint32_t hp = (HP); \
+                    h0 += (base_ && hp == HAP_0) ? 1u : 0u; \
+                    h1 += (base_ && hp == HAP_1) ? 1u : 0u; \
+                    if (hp != HAP_0 && hp != HAP_1) counts_here = 0; \
+                } \
+                tri_sum += counts_here; \
             }
 
 #define NORM_CLASSIFY() \
@@ -575,7 +619,28 @@ __global__ void __launch_bounds__(256) k_norm_tile(NormArgs A, Derived D, const 
                 if (row >= nb) break;
                 const bool rlive = lane_val((int)live_row, l) != 0;
                 uint32_t cell[4] = {CELL_EMPTY, CELL_EMPTY, CELL_EMPTY, CELL_EMPTY};
-                if (rlive) {
+                // nearly every row: one gapless segment spans the whole tile -- four bases straight from the three loads
+                const int32_t f_t0 = lane_val(sg[0].x, l), f_len = lane_val(sg[0].z, l);
+                const bool whole = rlive && !((uint32_t)lane_val(sg[0].w, l) & SEG_DEL) && f_t0 <= (int32_t)base &&
+                                   (int64_t)f_t0 + f_len >= base + 256;
+                if (whole) {
+                    const int64_t qoff = ((int64_t)lane_val((int)(M.qoff >> 32), l) << 32) | (uint32_t)lane_val((int)M.qoff, l);
+                    const int64_t K = qoff + lane_val(sg[0].y, l) + (P0 - f_t0);
+                    uint32_t qv, sb;
+                    __builtin_memcpy(&qv, R.bq + K, 4);
+                    __builtin_memcpy(&sb, R.seq + (K >> 1), 4);
+                    const uint64_t cw = (uint64_t)callable[K >> 5] | ((uint64_t)callable[(K >> 5) + 1] << 32);
+                    const uint32_t cb = (uint32_t)(cw >> (K & 31));
+                    // base K + y sits in byte (K + y) >> 1, high half when K + y is even: bring the four nibbles to bits 0..15
+                    const uint32_t sw = __builtin_bswap32(sb);                 // bytes in nibble order
+                    const uint32_t n4 = (K & 1) ? (sw >> 12) & 0xffffu : sw >> 16;   // base y at bits 12 - 4y .. 15 - 4y
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const int nib = (int)((n4 >> (12 - 4 * x)) & 15u);
+                        cell[x] = (uint32_t)nib2allele(nib) | (((qv >> (8 * x)) & 0xffu) << 8) | (((cb >> x) & 1u) << 4);
+                    }
+                    if (f_t0 == (int32_t)base && ((uint32_t)lane_val(sg[0].w, l) & SEG_INS) && lane == 0) cell[0] |= CELL_INS;
+                } else if (rlive) {
                     const int ns = lane_val(M.nseg, l), jf = lane_val(j0, l);
                     const int64_t segbase = ((int64_t)lane_val((int)(M.segbase >> 32), l) << 32) | (uint32_t)lane_val((int)M.segbase, l);
                     const int64_t qoff = ((int64_t)lane_val((int)(M.qoff >> 32), l) << 32) | (uint32_t)lane_val((int)M.qoff, l);
@@ -637,11 +702,26 @@ __global__ void __launch_bounds__(256) k_norm_tile(NormArgs A, Derived D, const 
             __syncthreads();
             // ---- every thread down its column, in read order
             if (valid) {
-                for (int i = 0; i < nb; i++) {
-                    const uint32_t v = s_cells[i][tid];
-                    if ((v & 15u) == CELL_EMPTY) continue;
-                    if (edge && !(s_tend[i] > cs_)) continue;                               // not fetched by this chunk (normcounts.py:289)
-                    NORM_CELL(v, s_hap[i])
+                // four rows at a time: the cells, then the three table values of each (EMPTY cells read entry 0), are
+                // loaded before any of them is used, so that the LDS latency is paid once per four cells
+                for (int i0 = 0; i0 < nb; i0 += 4) {
+                    uint32_t v4[4];
+                    double th[4], tt[4], te[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v4[k] = i0 + k < nb ? (uint32_t)s_cells[i0 + k][tid] : (uint32_t)CELL_EMPTY;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t q = (v4[k] >> 8) & 255u;
+                        th[k] = s_lut[q]; tt[k] = s_lut[256 + q]; te[k] = s_lut[512 + q];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t v = v4[k];
+                        const int ri = min(i0 + k, nb - 1);
+                        // an EMPTY cell, or a read this chunk did not fetch (normcounts.py:289), adds nothing
+                        const bool use = (v & 15u) != CELL_EMPTY && !(edge && !(s_tend[ri] > cs_));
+                        NORM_CELL_BF(v, use, s_hap[ri], th[k], tt[k], te[k])
+                    }
                 }
             }
             __syncthreads();

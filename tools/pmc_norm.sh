@@ -1,0 +1,17 @@
+set -e
+export TMPDIR=/tmp
+out=gpurun_out
+for c in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" "SQ_INSTS_BRANCH SQ_WAIT_ANY"; do
+  tag=$(echo $c | tr ' ' '_')
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmcT_$tag -- python3 tools/bench_normcounts.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmcT_$tag.log 2>&1 || echo "failed $c"
+done
+python3 - <<'PY'
+import csv, glob, collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmcT_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"].split("(")[0].replace("void ","")
+        if "k_norm_tile" in k or "k_callable" in k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,v in acc.items():
+    print(k+" "+" ".join("%s=%.4g"%(c,sum(x)/len(x)) for c,x in sorted(v.items())))
+PY
