@@ -71,8 +71,9 @@ def main():
            # SURVEY 8d convention for the dense sweep: 1.5 B in + 2 B cell written + 2 B cell read per read base
            "roofline": {"bound": "hbm", "achieved": st["read_bases"] * 5.5 / (np.mean(ms) * 1e-3) / 1e9, "peak": 8000.0,
                         "unit": "GB/s", "frac": st["read_bases"] * 5.5 / (np.mean(ms) * 1e-3) / 1e9 / 8000.0,
-                        "note": "whole pass, algorithmic 5.5 B per read base (qualities read twice, packed bases once, "
-                                "one 2-byte cell written and read)"}}
+                        "note": "whole pass against the SURVEY's 5.5 B per read base (qualities twice, packed bases once, one "
+                                "2-byte cell written and read); the tiled sweep keeps the cells in LDS and is bound by "
+                                "instructions per cell, not by these bytes (DESIGN.md section 8)"}}
     if not a.no_cpu_baseline:
         from oracle import oracle as O
         nch = max(1, int(a.cpu_sample_mb * 1e6 / 200000))
