@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
 constexpr int NT_ROWS = 48;
 constexpr int NT_RPW = NT_ROWS / 4;    // rows per wave and batch
 
-__global__ void __launch_bounds__(256) k_norm_tile(NormArgs A, Derived D, const uint32_t* callable, const int32_t* winlo,
+__global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, const uint32_t* callable, const int32_t* winlo,
                                                    const int32_t* winhi, int64_t nblk) {
     __shared__ double s_lut[3 * 256];
     __shared__ double s_prior[4];
