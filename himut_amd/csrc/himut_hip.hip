@@ -939,7 +939,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     c->d_winlo.reserve((size_t)nblk * 4 + 64);
     c->d_winhi.reserve((size_t)nblk * 4 + 64);
     if (c->n > 0 && T.n > 0) {
-        hipLaunchKernelGGL(k_read_live, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, C, c->params,
+        hipLaunchKernelGGL(k_read_live, dim3(blocks_for(c->n, 16)), dim3(256), 0, st, R, D, C, c->params,
                            c->d_live.as<uint8_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
         if (phase && T.npairs > 0) {
             hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);

@@ -8,7 +8,7 @@
 // genotypes every position and bins it.  The contig is swept in passes of NORM_PASS
 // positions so that the column store stays a few GB and 32-bit slot offsets suffice.
 //
-//   k_read_live    thread per read: read filters (normcounts.py:302-309), cs-vs-SEQ check, num_ccs
+//   k_read_live    sixteen lanes per read: read filters (normcounts.py:302-309), cs-vs-SEQ check, num_ccs
 //   k_callable     wave per read: one bit per query base (the mismatch-window / trim / BQ rules)
 //   k_fill_bits    the bitmap: ones at the chunk positions of the current pass
 //   k_norm_eval    thread per (chunk, position): pile, genotype, classification, histograms
@@ -33,7 +33,10 @@ __global__ void __launch_bounds__(256) k_pair_ccs(Chunks C, Phase H, Reads R, co
 
 __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C, Params P, uint8_t* live, uint8_t* ccs_flag,
                                                    int* err) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // sixteen lanes per read: the substitution check runs down the mismatch list sixteen entries at a time (a noisy
+    // read has hundreds); the rest is lane 0 of the group
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int gl = threadIdx.x & 15;
     if (r >= R.n) return;
     const ReadMeta M = D.meta[r];
     uint8_t lv = 0;
@@ -42,7 +45,7 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
         const int nm = D.nmis[r];
         const uint32_t* mq = D.mq + M.segbase;
         int bad = 0;
-        for (int e = 0; e < nm; e++) {
+        for (int e = gl; e < nm; e += 16) {
             const uint32_t v = mq[e];
             if (v & 16u) {
                 const int qa = nib2allele(nib_at(R.seq, M.qoff + (v >> 5)));
@@ -51,6 +54,7 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
             }
         }
         if (bad) set_err(err, bad);
+        if (gl != 0) return;
         const int32_t qlen = R.qlen[r];
         bool ok = (M.flags & RF_IDENT_OK) != 0;
         if ((double)D.bqsum[r] / (double)qlen < (double)P.p.min_qv) ok = false;
@@ -64,7 +68,7 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
         }
         if (ok) { lv = 1; if (!P.p.phase) ccs_flag[R.qid[r]] = 1; }
     }
-    live[r] = lv;
+    if (gl == 0) live[r] = lv;
 }
 
 // ---------------------------------------------------------------------------------------
