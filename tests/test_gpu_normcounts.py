@@ -37,6 +37,21 @@ def test_normcounts_golden(worker, case):
     assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
 
 
+@pytest.mark.parametrize("case", ["norm_dense", "norm_phase"])
+def test_normcounts_golden_column_store_sweep(worker, case, monkeypatch):
+    """The earlier sweep (cells through a column store in HBM, HIMUT_NORM_SWEEP=store) is kept for comparison with
+    the tiled one: the same golden vectors."""
+    from himut_amd import normcounts
+    monkeypatch.setenv("HIMUT_NORM_SWEEP", "store")
+    batch, exp, p, refseq, pon, com = load_norm_case(case)
+    _configure(worker, p, util.phase_of(exp) is not None)
+    ccs, rf, log = normcounts.norm_contig(worker, batch, util.chunks_of(exp), refseq, pon, com,
+                                          exp["non_human_sample"], exp["alt_order"], phase_sets=util.phase_of(exp))
+    assert log == exp["log"]
+    assert ccs == {k: int(v) for k, v in exp["ccs_tri2count"].items()}
+    assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
+
+
 @pytest.mark.parametrize("seed,length,chunks", [
     (31, 300_000, None),                                     # reference chunking, two chunks
     (32, 120_000, [(500, 40_000), (40_000, 41_000), (90_000, 119_000)]),   # gaps and a tiny chunk
