@@ -1,17 +1,20 @@
 // Device code of the normcounts sweep: himut's `normcounts.get_callable_tricounts`
 // (src/himut/normcounts.py:206-421, with or without --phase) on the machinery of the call path.
 //
-// Every reference position of the chunks is a "candidate": the position bitmap is all
-// ones inside the chunks, k_stream_capture<true> transposes every (read, position) cell into
-// the read-major column store -- now with one more bit per cell: "this base counts as
-// callable for its read" (update_tri2count, normcounts.py:66-110) -- and k_norm_eval
-// genotypes every position and bins it.  The contig is swept in passes of NORM_PASS
-// positions so that the column store stays a few GB and 32-bit slot offsets suffice.
+// Every reference position of the chunks is genotyped from its pile column and, when callable, binned by
+// trinucleotide context.  A pile cell is the 16-bit value of the call path (CELL_* code, CELL_INS, BQ) with one
+// more bit: "this base counts as callable for its read" (update_tri2count, normcounts.py:66-110).
 //
 //   k_read_live    sixteen lanes per read: read filters (normcounts.py:302-309), cs-vs-SEQ check, num_ccs
 //   k_callable     wave per read: one bit per query base (the mismatch-window / trim / BQ rules)
-//   k_fill_bits    the bitmap: ones at the chunk positions of the current pass
-//   k_norm_eval    thread per (chunk, position): pile, genotype, classification, histograms
+//   k_norm_tile    workgroup per 256-position tile of a chunk: the cells of the reads over the tile are built in
+//                  LDS, 48 rows at a time, and every thread runs down its column (pile, genotype, classification,
+//                  histograms) -- the sweep in use
+//   k_fill_bits, k_stream_capture<true>, k_norm_eval
+//                  the earlier sweep (HIMUT_NORM_SWEEP=store): the position bitmap is all ones inside the chunks,
+//                  the capture kernel transposes every (read, position) cell into the read-major column store in
+//                  HBM, in passes of NORM_PASS positions, and k_norm_eval (thread per (chunk, position)) reads it
+//                  back.  Kept for comparison; both evaluate a position with the same text (NORM_* macros).
 #pragma once
 
 #include "himut_kernels.h"
