@@ -335,13 +335,13 @@ _Pragma("unroll") \
                 const bool isref_ = base_ && (int)cell == ref; \
                 cnt[4] += (use_ && ((V) & CELL_INS)) ? 1u : 0u; \
                 cnt[5] += (use_ && cell == CELL_DEL) ? 1u : 0u; \
-                if (use_ && cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE; \
                 const uint32_t q = (V) >> 8; \
                 bq0 = bq0 || (base_ && q == 0); \
                 nref += isref_ ? 1u : 0u; \
                 const double vh = (VH), vt = (VT), ve = (VE); \
                 R0 = R0 + (isref_ ? vh : 0.0); R1 = R1 + (isref_ ? vt : 0.0); R2 = R2 + (isref_ ? ve : 0.0); \
-                if (base_ && !isref_) { \
+                if (use_ && !isref_ && cell <= CELL_OTHER) {        /* rare: another allele, or a base outside ATGC */ \
+                    if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE; \
 _Pragma("unroll") \
                     for (int b = 0; b < 4; b++) { \
                         if ((int)cell == b) { \
@@ -587,6 +587,7 @@ __global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, con
         const int refc = valid ? (int)A.refseq[rpos] : 'N';
         const int ref = char2allele(refc);
         const bool edge = rpos <= cs_;
+        const bool any_edge = base <= cs_;                       // only the chunk's first tile has such positions
         NORM_POS_STATE()
         // rows: the reads of the window index of the blocks under the tile
         const int64_t b0 = min(max(base, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min((base + 255) >> WIN_SHIFT, nblk - 1);
@@ -726,7 +727,7 @@ __global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, con
                         const uint32_t v = v4[k];
                         const int ri = min(i0 + k, nb - 1);
                         // an EMPTY cell, or a read this chunk did not fetch (normcounts.py:289), adds nothing
-                        const bool use = (v & 15u) != CELL_EMPTY && !(edge && !(s_tend[ri] > cs_));
+                        const bool use = (v & 15u) != CELL_EMPTY && !(any_edge && edge && !(s_tend[ri] > cs_));
                         NORM_CELL_BF(v, use, s_hap[ri], th[k], tt[k], te[k])
                     }
                 }
