@@ -260,7 +260,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:           # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(batch, chunks, params, pon, com, a.cpu_sample_mb)
         print(json.dumps(out), flush=True)
     w.close()
