@@ -256,6 +256,13 @@ def main():
                                               "start / end and the events around k_stream_capture only",
             "kernels": per_kernel,
             "setup_s": {"generate": t_gen, "h2d": t_h2d},
+            # the whole step against the SURVEY's own byte count (3.5 B per read base + 2 B per position +
+            # (1.5 D + 48) B per candidate site), device time of the timed steps
+            "roofline_step": (lambda by: {"bound": "hbm", "achieved": by / (timed["ms_total"] * 1e-3) / 1e9,
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": by / (timed["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "algorithmic_bytes_per_step": by, "convention": "SURVEY 8d"})(
+                (read_bases * 3.5 + positions * 2.0 + cand_sites * (1.5 * a.depth + 48.0)) / world),
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
