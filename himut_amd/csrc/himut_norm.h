@@ -362,6 +362,42 @@ _Pragma("unroll") \
                 tri_sum += counts_here; \
             }
 
+// The tile sweep's form of the update.  (TH, TT, TE) are the table values of the cell's quality if the cell is the
+// reference allele and +0.0 otherwise (the caller reads entry 256, a zero row, for those), so the reference allele's
+// sums need no select; the four small counters that every cell may touch travel as 16-bit fields of two words
+// (ACC1: insertions | deletions << 16, ACC2: reference bases | callable bases << 16).
+#define NORM_CELL_Z(V, USE, ISREF, HP, TH, TT, TE, ACC1, ACC2) \
+            { \
+                const uint32_t cell = (V) & 7u; \
+                const bool use_ = (USE), isref_ = (ISREF); \
+                const bool base_ = use_ && cell < 4; \
+                const uint32_t q = (V) >> 8; \
+                bq0 = bq0 || (base_ && q == 0); \
+                R0 = R0 + (TH); R1 = R1 + (TT); R2 = R2 + (TE); \
+                if (use_ && !isref_ && cell <= CELL_OTHER) {        /* rare: another allele, or a base outside ATGC */ \
+                    if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE; \
+                    const double vh = s_lut[q], vt = s_lut[257 + q], ve = s_lut[514 + q]; \
+_Pragma("unroll") \
+                    for (int b = 0; b < 4; b++) { \
+                        if ((int)cell == b) { \
+                            cnt[b]++; \
+                            S[0][b] = S[0][b] + vh; \
+                            S[1][b] = S[1][b] + vt; \
+                            S[2][b] = S[2][b] + ve; \
+                        } \
+                    } \
+                } \
+                uint32_t callable_ = base_ ? (((V) >> 4) & 1u) : 0u; \
+                if (phase) { \
+                    const uint32_t hp = (HP); \
+                    h0 += (base_ && hp == HAP_0) ? 1u : 0u; \
+                    h1 += (base_ && hp == HAP_1) ? 1u : 0u; \
+                    if (hp != HAP_0 && hp != HAP_1) callable_ = 0; \
+                } \
+                ACC1 += (use_ ? (((V) >> 3) & 1u) : 0u) | ((use_ && cell == CELL_DEL) ? 0x10000u : 0u); \
+                ACC2 += (isref_ ? 1u : 0u) | (callable_ << 16); \
+            }
+
 #define NORM_CLASSIFY() \
         if (ref < 0 || tri_sum == 0) continue; \
 _Pragma("unroll") \
@@ -559,7 +595,7 @@ constexpr int NT_RPW = NT_ROWS / 4;    // rows per wave and batch
 
 __global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, const uint32_t* callable, const int32_t* winlo,
                                                    const int32_t* winhi, int64_t nblk) {
-    __shared__ double s_lut[3 * 256];
+    __shared__ double s_lut[3 * 257];         // three tables of 256 qualities + a zero entry each (index 256)
     __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
     __shared__ unsigned int s_ccs[32], s_ref[32];
@@ -567,7 +603,8 @@ __global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, con
     __shared__ int32_t s_tend[NT_ROWS];
     __shared__ uint32_t s_hap[NT_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
-    for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = A.lut->t[i >> 8][i & 255];
+    for (int i = tid; i < 3 * 256; i += 256) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 255];
+    if (tid < 3) s_lut[tid * 257 + 256] = 0.0;
     if (tid < 4) s_prior[tid] = A.lut->prior[tid];
     if (tid < 16) s_log[tid] = 0;
     if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
@@ -589,6 +626,7 @@ __global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, con
         const bool edge = rpos <= cs_;
         const bool any_edge = base <= cs_;                       // only the chunk's first tile has such positions
         NORM_POS_STATE()
+        uint32_t acc1 = 0, acc2 = 0;                              // 16-bit fields: insertions | deletions, reference | callable bases
         // rows: the reads of the window index of the blocks under the tile
         const int64_t b0 = min(max(base, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min((base + 255) >> WIN_SHIFT, nblk - 1);
         const int32_t lo = winlo[b0], hi = winhi[b1];
@@ -710,31 +748,37 @@ __global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, con
             __syncthreads();
             // ---- every thread down its column, in read order
             if (valid) {
-                // four rows at a time: the cells, then the three table values of each (EMPTY cells read entry 0), are
-                // loaded before any of them is used, so that the LDS latency is paid once per four cells
+                // four rows at a time: the cells, then the three table values of each (the zero row unless the cell is the
+                // reference allele), are loaded before any of them is used: the LDS latency is paid once per four cells
                 for (int i0 = 0; i0 < nb; i0 += 4) {
                     uint32_t v4[4];
                     double th[4], tt[4], te[4];
+                    bool use4[4], ref4[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) v4[k] = i0 + k < nb ? (uint32_t)s_cells[i0 + k][tid] : (uint32_t)CELL_EMPTY;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t q = (v4[k] >> 8) & 255u;
-                        th[k] = s_lut[q]; tt[k] = s_lut[256 + q]; te[k] = s_lut[512 + q];
-                    }
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const uint32_t v = v4[k];
                         const int ri = min(i0 + k, nb - 1);
                         // an EMPTY cell, or a read this chunk did not fetch (normcounts.py:289), adds nothing
-                        const bool use = (v & 15u) != CELL_EMPTY && !(any_edge && edge && !(s_tend[ri] > cs_));
-                        NORM_CELL_BF(v, use, s_hap[ri], th[k], tt[k], te[k])
+                        use4[k] = (v & 15u) != CELL_EMPTY && !(any_edge && edge && !(s_tend[ri] > cs_));
+                        ref4[k] = use4[k] && (int)(v & 7u) == ref;
+                        const uint32_t qe = ref4[k] ? (v >> 8) : 256u;      // the zero row for everything but the reference allele
+                        th[k] = s_lut[qe]; tt[k] = s_lut[257 + qe]; te[k] = s_lut[514 + qe];
                     }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        NORM_CELL_Z(v4[k], use4[k], ref4[k], s_hap[min(i0 + k, nb - 1)], th[k], tt[k], te[k], acc1, acc2)
                 }
             }
             __syncthreads();
+            if (((r0 - lo) / NT_ROWS & 511) == 511) {             // a pile tens of thousands of reads deep: empty the 16-bit fields
+                cnt[4] += acc1 & 0xffffu; cnt[5] += acc1 >> 16; nref += acc2 & 0xffffu; tri_sum += acc2 >> 16;
+                acc1 = 0; acc2 = 0;
+            }
         }
         if (!valid) continue;
+        cnt[4] += acc1 & 0xffffu; cnt[5] += acc1 >> 16; nref += acc2 & 0xffffu; tri_sum += acc2 >> 16;
         NORM_CLASSIFY()
     }
     __syncthreads();
