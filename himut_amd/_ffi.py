@@ -37,7 +37,7 @@ class RunStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_double) for k in ("ms_total", "ms_parse", "ms_bqsum", "ms_hap", "ms_emit", "ms_index",
                                                "ms_capture", "ms_eval", "ms_finalize")] + \
                [(k, ctypes.c_int64) for k in ("n_reads", "read_bases", "positions", "n_unique_positions", "n_candidates",
-                                              "n_records", "column_slots")]
+                                              "n_records", "column_slots", "reran")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -113,7 +113,7 @@ def lib():
     for name in EXPORTS:
         if name not in ("himut_destroy", "himut_last_error"):
             getattr(L, name).restype = ctypes.c_int
-    if L.himut_abi_version() != 1:
+    if L.himut_abi_version() != 2:
         raise ImportError("libhimut_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -147,6 +147,7 @@ const char* err_text(int code) {
         case HIMUT_ERR_BQ0: return "ValueError: math domain error (BQ 0 in a candidate column, gtlib.py:64)";
         case HIMUT_ERR_COVER: return "KeyError: hetSNP position missing from tpos2qbase (haplib.py:51)";
         case HIMUT_ERR_BQ_RANGE: return "base quality out of range";
+        case HIMUT_ERR_DEPTH: return "pile too deep: the contig's candidate columns need more than 2^32 column-store slots";
     }
     return "device error";
 }
@@ -328,12 +329,12 @@ inline void stage_event(himut_ctx* c, int ev, int level, hipStream_t st) {
 }
 
 // side_work: work for the second stream, done while the quality stream + cs decode run
-template <class F>
+template <bool WITH_BQ, class F>
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, F side_work) {
     hipStream_t st = c->stream;
     // the side stream takes the work that needs nothing from the decode (it starts behind EV_START: the
     // previous run on this context is over by then)
-    hipLaunchKernelGGL(k_parse_cs, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err, c->d_ccs.as<uint8_t>());
+    hipLaunchKernelGGL(k_parse_cs<WITH_BQ>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err, c->d_ccs.as<uint8_t>());
     HCHECK(hipStreamWaitEvent(c->side, c->ev[EV_START], 0));
     side_work(c->side);
     HCHECK(hipEventRecord(c->ev[EV_SIDE], c->side));
@@ -342,8 +343,8 @@ void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc
     HCHECK(hipStreamWaitEvent(st, c->ev[EV_SIDE], 0));
     stage_event(c, EV_PARSE, 2, st);
 }
-void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {
-    run_parse_stage(c, R, D, sc, [](hipStream_t) {});
+void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {   // with the quality sums
+    run_parse_stage<true>(c, R, D, sc, [](hipStream_t) {});
 }
 
 void alloc_derived(himut_ctx* c) {
@@ -362,10 +363,15 @@ void alloc_derived(himut_ctx* c) {
 }
 
 // One pass of the scan.  spec: the candidate and column-slot buffers keep the capacities of an earlier run
-// (cap_cand, cap_slots) and every kernel behind the candidate count takes the count from device memory, so
-// the host launches the whole run without waiting in the middle; *overflow is set if a count did not fit
-// (the caller runs again with exact sizes).  Otherwise the host waits for the counts where it needs them
-// and sizes the buffers with 25 % of headroom for the runs that follow.
+// (cap_cand, cap_slots) and every kernel behind a count takes the count from device memory, so the host
+// launches the whole run without waiting in the middle; *overflow is set if a count did not fit (the caller
+// runs again with exact sizes).  Otherwise the host waits for the counts where it needs them and sizes the
+// buffers with 25 % of headroom for the runs that follow.
+//
+// Order: cs decode -> bitmap of the substitution positions of the reads that pass the cheap filters ->
+// column windows / offsets -> k_stream_capture (every quality and base byte of the contig exactly once: the
+// column store AND the whole-read quality sums) -> k_propose (the read filters now have the quality mean) ->
+// candidates out of the mask -> k_eval_columns -> finalisation.
 int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     *overflow = false;
     if (!c->have_params) return fail(c, HIMUT_ERR_ARG, "himut_set_params has not been called");
@@ -405,17 +411,29 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     c->d_tilecnt.reserve((size_t)mtiles * 4 + 64);
     c->d_tileoff2.reserve((size_t)mtiles * 4 + 64);
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
-    {   // scratch of the three scans whose lengths the host knows now: sized before anything is queued (growing a
+    int32_t maxend = 0;
+    for (int32_t e : c->cend) maxend = std::max(maxend, e);
+    const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
+    // bitmap of column positions: probed at every position a read covers, so it spans reads as well as chunks
+    int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
+    maxpos = std::max(maxpos, maxend);
+    const int64_t nwords = ((int64_t)maxpos >> 5) + 2;
+    size_t scan_tiles = 0, scan2 = 0, scan3 = 0;
+    auto popc_in = [&]() { return rocprim::make_transform_iterator(c->d_posbits_c.as<uint32_t>(), PopcWord()); };
+    {   // buffers and scan scratch whose sizes the host knows now: sized before anything is queued (growing a
         // buffer in the middle of a run would free it under the kernels already queued on it)
-        int32_t mp = c->h_prefmax.empty() ? 0 : c->h_prefmax.back(), me = 0;
-        for (int32_t e : c->cend) { mp = std::max(mp, e); me = std::max(me, e); }
-        size_t a = 0, b = 0, d = 0;
+        c->d_winlo.reserve((size_t)nblk * 4 + 64);
+        c->d_winhi.reserve((size_t)nblk * 4 + 64);
+        c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
+        c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
+        c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
+        c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
         uint32_t* nul = nullptr;
-        HCHECK(rocprim::exclusive_scan(nullptr, a, nul, nul, 0u, (size_t)std::max<unsigned>(mtiles, 1u), rocprim::plus<uint32_t>(), st));
-        HCHECK(rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator(nul, PopcWord()), nul, 0u,
-                                       (size_t)(((int64_t)mp >> 5) + 3), rocprim::plus<uint32_t>(), st));
-        HCHECK(rocprim::exclusive_scan(nullptr, d, nul, nul, 0u, (size_t)(((int64_t)me >> WIN_SHIFT) + 2), rocprim::plus<uint32_t>(), st));
-        c->d_tmp2.reserve(std::max(std::max(a, b), d) + 256);
+        HCHECK(rocprim::exclusive_scan(nullptr, scan_tiles, nul, nul, 0u, (size_t)std::max<unsigned>(mtiles, 1u), rocprim::plus<uint32_t>(), st));
+        HCHECK(rocprim::exclusive_scan(nullptr, scan2, rocprim::make_transform_iterator(nul, PopcWord()), nul, 0u,
+                                       (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
+        HCHECK(rocprim::exclusive_scan(nullptr, scan3, nul, nul, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), st));
+        c->d_tmp2.reserve(std::max(std::max(scan_tiles, scan2), scan3) + 256);
     }
 
     Reads R = make_reads(c);
@@ -423,23 +441,14 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     Chunks C = make_chunks(c, T.n);
     Phase H = make_phase(c);
     Scalars* sc = c->d_scalars.as<Scalars>();
+    Scalars& hs = *reinterpret_cast<Scalars*>(c->h_scalars);
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
-    // window index for the column kernel, and the empty mask: neither needs the cs decode, so both
-    // run behind the quality sum on the second stream
-    int32_t maxend = 0;
-    for (int32_t e : c->cend) maxend = std::max(maxend, e);
-    const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
-    c->d_winlo.reserve((size_t)nblk * 4 + 64);
-    c->d_winhi.reserve((size_t)nblk * 4 + 64);
-    // bitmap of candidate positions: probed at every position a read covers, so it spans reads as well as chunks
-    int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
-    for (int32_t e : c->cend) maxpos = std::max(maxpos, e);
-    const int64_t nwords = ((int64_t)maxpos >> 5) + 2;
-    c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
+    // window index for the column kernel, the empty position bitmap and the empty mask: none needs the cs
+    // decode, so they run beside it on the second stream
     if (c->n > 0)
-        run_parse_stage(c, R, D, sc, [&](hipStream_t side) {
+        run_parse_stage<false>(c, R, D, sc, [&](hipStream_t side) {
             HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, side));
             if (clear_mask) {
                 HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, side));
@@ -458,18 +467,60 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     if (phase && T.npairs > 0)
         hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
     stage_event(c, EV_HAP, 2, st);
-    if (c->n > 0)
+
+    // ---- columns: positions -> rank -> per 256-position block the read window and the offset of its columns
+    size_t slot_cap = 0;
+    PosIndex X;
+    X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
+    X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
+    if (c->n > 0) {
+        hipLaunchKernelGGL(k_mark_positions, dim3(blocks_for(c->n, 16)), dim3(256), 0, st, R, D, c->params,
+                           c->d_posbits_c.as<uint32_t>(), nwords);
+        // rank[w] for w = 0 .. nwords (the last entry is the number of column positions); the bit counts are
+        // taken on the fly: the scan reads the bitmap through a transform iterator
+        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, popc_in(), c->d_posrank.as<uint32_t>(), 0u,
+                                       (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
+        // per 256-position block: slots = column positions x reads of the window, then their offsets
+        hipLaunchKernelGGL(k_block_slots, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
+                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, c->d_blkslots.as<uint32_t>(),
+                           (unsigned long long*)nullptr);
+        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
+                                       (size_t)nblk, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
+                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_blkoff.as<uint32_t>(), nblk,
+                           c->d_blktab.as<BlockTab>(), &sc->err);
+        size_t slot_reserve = (size_t)c->cap_slots;
+        slot_cap = (size_t)c->cap_slots;
+        if (!spec) {
+            uint32_t last_off = 0, last_n = 0;
+            HCHECK(hipMemcpyAsync(&last_off, c->d_blkoff.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
+            HCHECK(hipMemcpyAsync(&last_n, c->d_blkslots.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
+            HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+            HCHECK(hipStreamSynchronize(st));
+            if (hs.err) return check_device_err(c, hs.err);
+            slot_cap = (size_t)last_off + last_n;
+            slot_reserve = slot_cap + slot_cap / 4 + 4096;
+        }
+        c->d_colstore.reserve(slot_reserve * 2 + 256);
+        if (slot_cap) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, slot_cap, st));
+        CaptureArgs G;
+        G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)slot_cap;
+        G.r_begin = 0; G.r_end = c->n; G.callable = nullptr; G.bqsum = c->d_bqsum.as<uint32_t>(); G.err = &sc->err;
+        stage_event(c, EV_INDEX, 1, st);
+        hipLaunchKernelGGL(k_stream_capture<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
+        stage_event(c, EV_GATHER, 1, st);
+        // ---- proposals (the read filters know the quality mean now) -> mask
         hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, 16)), dim3(256), 0, st, R, D, C, H, c->params,
                            c->d_mask.as<uint32_t>(), c->d_any.as<uint32_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
+    } else {
+        stage_event(c, EV_INDEX, 1, st);
+        stage_event(c, EV_GATHER, 1, st);
+    }
     // the candidates = the set bits of the mask: bits per tile, then a scan
-    size_t scan_tiles = 0;
     uint32_t last_tcnt = 0, last_toff = 0;
     if (anyw > 0) {
         hipLaunchKernelGGL(k_mask_count, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
                            c->d_tilecnt.as<uint32_t>(), c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
-        HCHECK(rocprim::exclusive_scan(nullptr, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
-                                       (size_t)mtiles, rocprim::plus<uint32_t>(), st));
-        c->d_tmp2.reserve(scan_tiles + 256);
         HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
                                        (size_t)mtiles, rocprim::plus<uint32_t>(), st));
         if (!spec) {
@@ -477,10 +528,8 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
             HCHECK(hipMemcpyAsync(&last_toff, c->d_tileoff2.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
         }
     }
-    stage_event(c, EV_EMIT, 2, st);
 
     // number of candidate evaluations -> record capacity
-    Scalars& hs = *reinterpret_cast<Scalars*>(c->h_scalars);
     int64_t ncap = c->cap_cand, nreserve = c->cap_cand;       // grid / scan extent, buffer capacity (records)
     if (!spec) {
         HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
@@ -494,7 +543,6 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     const unsigned long long* ncand_dev = &sc->ncand;
 
     size_t sort_tmp = 0, scan_tmp = 0;
-    size_t slot_cap = 0;
     if (ncap > 0) {
         // candidates in the order of the final records (tpos, chunk, ref, alt)
         c->d_keys.reserve((size_t)nreserve * 8); c->d_keys2.reserve((size_t)nreserve * 8);
@@ -504,68 +552,21 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         HCHECK(rocprim::exclusive_scan(nullptr, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
                                        (size_t)ncap, rocprim::plus<uint32_t>(), st));
         if (c->chunks_in_order) {
+            c->d_tmp.reserve(scan_tmp + 256);
             hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
                                c->d_tileoff2.as<uint32_t>(), C, c->d_cands2.as<Cand>(), c->d_keys2.as<uint64_t>(), ncap, &sc->ncand,
-                               c->d_posbits_c.as<uint32_t>());
-            c->d_tmp.reserve(scan_tmp + 256);
-        } else {
-            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
-                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(), c->d_keys.as<uint64_t>(), ncap, &sc->ncand,
                                (uint32_t*)nullptr);
+        } else {
             HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
             c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
+            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
+                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(), c->d_keys.as<uint64_t>(), ncap, &sc->ncand,
+                               (uint32_t*)nullptr);
             HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
         }
-        // rank index of the position bitmap + per unique position window / column offset
-        c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
-        c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
-        c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
-        if (!c->chunks_in_order)    // the in-order emit sweep has set the bits already
-            hipLaunchKernelGGL(k_candpos_set, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, c->d_cands2.as<Cand>(), ncand_dev, ncap,
-                               c->d_posbits_c.as<uint32_t>());
-        // rank[w] for w = 0 .. nwords (the last entry is the number of unique candidate positions)
-        // (the bit counts are taken on the fly: the scan reads the bitmap through a transform iterator)
-        auto popc_in = rocprim::make_transform_iterator(c->d_posbits_c.as<uint32_t>(), PopcWord());
-        size_t scan2 = 0, scan3 = 0;
-        HCHECK(rocprim::exclusive_scan(nullptr, scan2, popc_in, c->d_posrank.as<uint32_t>(), 0u,
-                                       (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
-        HCHECK(rocprim::exclusive_scan(nullptr, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
-                                       (size_t)nblk, rocprim::plus<uint32_t>(), st));
-        c->d_tmp2.reserve(std::max(std::max(scan2, scan3), scan_tiles) + 256);
-        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, popc_in, c->d_posrank.as<uint32_t>(), 0u,
-                                       (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
-        // per 256-position block: slots = candidate positions x reads of the window, then their offsets
-        hipLaunchKernelGGL(k_block_slots, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
-                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, c->d_blkslots.as<uint32_t>(),
-                           (unsigned long long*)nullptr);
-        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
-                                       (size_t)nblk, rocprim::plus<uint32_t>(), st));
-        hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
-                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_blkoff.as<uint32_t>(), nblk,
-                           c->d_blktab.as<BlockTab>());
-        size_t slot_reserve = (size_t)c->cap_slots;
-        slot_cap = (size_t)c->cap_slots;
-        if (!spec) {
-            uint32_t last_off = 0, last_n = 0;
-            HCHECK(hipMemcpyAsync(&last_off, c->d_blkoff.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
-            HCHECK(hipMemcpyAsync(&last_n, c->d_blkslots.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
-            HCHECK(hipStreamSynchronize(st));
-            slot_cap = (size_t)last_off + last_n;
-            slot_reserve = slot_cap + slot_cap / 4 + 4096;
-        }
-        c->d_colstore.reserve(slot_reserve * 2 + 256);
-        if (slot_cap) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, slot_cap, st));
-        PosIndex X;
-        X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
-        X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
-        CaptureArgs G;
-        G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)slot_cap;
-        G.r_begin = 0; G.r_end = c->n; G.callable = nullptr; G.err = &sc->err;
-        stage_event(c, EV_INDEX, 1, st);
-        hipLaunchKernelGGL(k_stream_capture<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
-        stage_event(c, EV_GATHER, 1, st);
+        stage_event(c, EV_EMIT, 2, st);
         EvalArgs A;
         A.P = c->params;
         A.S.pon = c->d_pon.as<uint64_t>(); A.S.npon = c->npon; A.S.com = c->d_com.as<uint64_t>(); A.S.ncom = c->ncom;
@@ -579,8 +580,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         if (phase) hipLaunchKernelGGL(k_eval_columns<true>, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, A);
         else hipLaunchKernelGGL(k_eval_columns<false>, dim3(blocks_for(ncap, 256)), dim3(256), 0, st, A);
     } else {
-        stage_event(c, EV_INDEX, 1, st);
-        stage_event(c, EV_GATHER, 1, st);
+        stage_event(c, EV_EMIT, 2, st);
     }
     stage_event(c, EV_SWEEP, 2, st);
 
@@ -608,13 +608,13 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
     HCHECK(hipStreamSynchronize(st));
     if (hs.err) return check_device_err(c, hs.err);
-    c->mask_clean = true;      // the emit sweep ran over every cell that was set (or nothing was set)
     const int64_t ncand = ncap > 0 ? (int64_t)hs.ncand : 0;
-    const int64_t nslots = ncap > 0 ? (int64_t)hs.reserved0 : 0;
+    const int64_t nslots = ncap > 0 ? (int64_t)hs.reserved0 : (int64_t)slot_cap;
     if (ncand > ncap || nslots > (int64_t)slot_cap) {   // only a run on kept capacities can get here
-        *overflow = true;
+        *overflow = true;                                // (mask cells past the capacity may still be set: not clean)
         return HIMUT_OK;
     }
+    c->mask_clean = true;      // the emit sweep ran over every cell that was set (or nothing was set)
     if (!spec && c->chunks_in_order) { c->cap_cand = nreserve; c->cap_slots = (int64_t)(slot_cap + slot_cap / 4 + 4096); }
     c->stats.column_slots = nslots;
     c->n_out = ncap > 0 ? (int64_t)hs.nrec : 0;
@@ -629,9 +629,9 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     if (c->timing >= 2) {
         S.ms_parse = ms(EV_START, EV_PARSE);
         S.ms_hap = ms(EV_PARSE, EV_HAP);
-        S.ms_emit = ms(EV_HAP, EV_EMIT);
-        S.ms_index = ms(EV_EMIT, EV_INDEX);
-        S.ms_eval = ms(EV_GATHER, EV_SWEEP);
+        S.ms_index = ms(EV_HAP, EV_INDEX);
+        S.ms_emit = ms(EV_GATHER, EV_EMIT);
+        S.ms_eval = ms(EV_EMIT, EV_SWEEP);
         S.ms_finalize = ms(EV_SWEEP, EV_FINAL);
     }
     S.n_reads = c->n;
@@ -649,6 +649,7 @@ int do_run(himut_ctx* c) {
     if (rc == HIMUT_OK && overflow) {
         c->cap_cand = c->cap_slots = 0;
         rc = do_run_once(c, false, &overflow);
+        c->stats.reran = 1;
     }
     return rc;
 }
@@ -1015,7 +1016,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
                                            (size_t)nblk, rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
                                c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_blkoff.as<uint32_t>(), nblk,
-                               c->d_blktab.as<BlockTab>());
+                               c->d_blktab.as<BlockTab>(), (int*)nullptr);
             uint32_t last_off = 0, last_n = 0;
             unsigned long long hs_total = 0;
             HCHECK(hipMemcpyAsync(&last_off, c->d_blkoff.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
@@ -1035,7 +1036,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
             X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
             CaptureArgs G;
             G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)nslots;
-            G.r_begin = rb; G.r_end = std::max(rb, re); G.callable = c->d_callable.as<uint32_t>(); G.err = &sc->err;
+            G.r_begin = rb; G.r_end = std::max(rb, re); G.callable = c->d_callable.as<uint32_t>(); G.bqsum = nullptr; G.err = &sc->err;
             if (re > rb)
                 hipLaunchKernelGGL(k_stream_capture<true>, dim3(blocks_for(re - rb, 4)), dim3(256), 0, st, G);
             A.X = X; A.colstore = c->d_colstore.as<uint16_t>(); A.p_lo = p_lo; A.p_hi = p_hi;

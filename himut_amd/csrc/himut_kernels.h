@@ -352,9 +352,11 @@ __device__ __forceinline__ uint32_t cs_pack4(uint32_t f) {                      
 }
 
 
-// The wave issues the first rows of its read's qualities (bq_issue) behind the first KB of the tag, decodes the
-// tag while they are in flight, then sums the qualities (bq_finish): waves in that phase are bound by HBM,
-// waves in the decode by VALU, and a CU holds both kinds at any time.
+// WITH_BQ (normcounts, edge counts): the wave also issues the first rows of its read's qualities (bq_issue)
+// behind the first KB of the tag, decodes the tag while they are in flight, then sums the qualities
+// (bq_finish): waves in that phase are bound by HBM, waves in the decode by VALU, and a CU holds both kinds at
+// any time.  The call path takes the sum from k_stream_capture, which streams the qualities anyway.
+template <bool WITH_BQ>
 __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
     __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     uint4 vcur;
     __builtin_memcpy(&vcur, cs + 16 * lane, 16);                   // himut_push_reads leaves 2 KB of slack behind the text
     BqAhead Q;
-    bq_issue(R, r, lane, Q);
+    if constexpr (WITH_BQ) bq_issue(R, r, lane, Q);
     for (int base = 0; base < n; base += PB) {
         const int nb = min(PB, n - base);
         // ---- text of this step into LDS, behind the last 32 bytes of the previous step (still in LDS)
@@ -555,7 +557,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
         }
         __builtin_amdgcn_wave_barrier();
     }
-    bq_finish(Q, r, lane, D.bqsum);
+    if constexpr (WITH_BQ) bq_finish(Q, r, lane, D.bqsum);
     // a reduction of the lanes' error codes
     {
         int b = bad;
@@ -658,6 +660,32 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
         }
     }
     H.hap[k] = hap;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_mark_positions: the bitmap of reference positions at which a column must be captured = every substitution of
+// every read that passes the filters known before the qualities have been streamed (identity, mapq, qlen:
+// caller.py:312-317).  A superset of the candidate positions -- the whole-read quality mean (caller.py:310), the
+// trim and mismatch-window filters and the chunk rules only take proposals away (k_propose, which runs behind
+// the capture and knows the mean by then) -- and nearly equal to them.  Sixteen lanes per read.
+__global__ void __launch_bounds__(256) k_mark_positions(Reads R, Derived D, Params P, uint32_t* posbits, int64_t nwords) {
+    const int gl = threadIdx.x & 15;
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (r >= R.n) return;
+    const ReadMeta M = D.meta[r];
+    const int32_t qlen = R.qlen[r];
+    const int mapq = R.mapq[r];
+    const int nm = D.nmis[r];
+    if ((M.flags & RF_SECONDARY) || !(M.flags & RF_IDENT_OK)) return;
+    if (mapq < P.p.min_mapq) return;
+    if (!(P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit)) return;
+    const int32_t* mis = D.mis + M.segbase;
+    const uint32_t* mq = D.mq + M.segbase;
+    for (int e = gl; e < nm; e += 16) {
+        const uint32_t v = mq[e];
+        const int32_t rpos = mis[e] - 1;
+        if ((v & 16u) && rpos >= 0 && (int64_t)(rpos >> 5) < nwords) atomicOr(posbits + (rpos >> 5), 1u << (rpos & 31));
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -987,14 +1015,22 @@ __global__ void __launch_bounds__(256) k_block_slots(const uint32_t* rank, int64
     }
 }
 
+// err (optional): HIMUT_ERR_DEPTH when the column store of the contig needs more than 2^32 slots (a block's
+// product or the running offset no longer fits the 32-bit fields) or a window holds more than 2^22 reads
 __global__ void __launch_bounds__(256) k_block_table(const uint32_t* rank, int64_t nwords, const int32_t* winlo,
-                                                     const int32_t* winhi, const uint32_t* boff, int64_t nblk, BlockTab* bt) {
+                                                     const int32_t* winhi, const uint32_t* boff, int64_t nblk, BlockTab* bt,
+                                                     int* err) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
     BlockTab t;
     const uint32_t u0 = rank[min(b * 8, nwords)], u1 = rank[min(b * 8 + 8, nwords)];
-    t.lo = winlo[b]; t.ncnt = (uint32_t)(winhi[b] - winlo[b]) | ((u1 - u0) << 22); t.boff = boff[b]; t.ufirst = u0;
+    const uint32_t nr = (uint32_t)(winhi[b] - winlo[b]);
+    t.lo = winlo[b]; t.ncnt = nr | ((u1 - u0) << 22); t.boff = boff[b]; t.ufirst = u0;
     bt[b] = t;
+    if (err) {
+        const unsigned long long s = ((unsigned long long)(u1 - u0) * nr + 15ULL) & ~15ULL;
+        if (nr > BT_N_MASK || s > 0xffffffffULL || (unsigned long long)boff[b] + s > 0xffffffffULL) set_err(err, HIMUT_ERR_DEPTH);
+    }
 }
 
 struct CaptureArgs {
@@ -1005,6 +1041,7 @@ struct CaptureArgs {
     int64_t nslots;
     int64_t r_begin, r_end;      // reads of this launch
     const uint32_t* callable;    // normcounts: one bit per query base (bit q of read r at word (qoff[r] + q) >> 5)
+    uint32_t* bqsum;             // call path: per read, the sum of the qualities of the whole query (bamlib.py:34-36)
     const int* err;              // a device error raised by an earlier kernel of the run: nothing is captured then
 };
 
@@ -1047,8 +1084,21 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     if (r64 >= A.r_end || uni(*A.err)) return;
     const int32_t r = (int32_t)r64;
     const ReadMeta Mv = A.D.meta[r];
-    const int32_t qstart = uni(R.qstart[r]), qlen = uni(R.qlen[r]);
-    if ((uni(Mv.flags) & RF_SECONDARY) || uni(Mv.nseg) <= 0) return;
+    const int32_t qlen = uni(R.qlen[r]);
+    if (uni(Mv.flags) & RF_SECONDARY) return;
+    if (uni(Mv.nseg) <= 0) {                 // nothing aligned (an empty cs tag): only the quality sum is wanted
+        if constexpr (!NORM) {
+            if (A.bqsum) {
+                const uint8_t* q = R.bq + uni(Mv.qoff);
+                uint32_t sum = 0;
+                for (int32_t i = lane; i < qlen; i += 64) sum += q[i];
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+                if (lane == 0) A.bqsum[r] = sum;
+            }
+        }
+        return;
+    }
     const Seg* gsegs = A.D.segs + uni(Mv.segbase);
     const int ns = uni(Mv.nseg);
     const int64_t qo = uni(Mv.qoff);
@@ -1060,8 +1110,11 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     uint2* list = s_list[wv];
     const bool all_lds = ns <= CSG;     // the whole segment list fits the LDS window
 
-    const int32_t c0 = qstart & ~(CWQ - 1);
+    // the windows start at query offset 0, soft clip included: the quality mean of the read filter is over the
+    // whole query (a window in front of the aligned part has an empty reference range)
+    const int32_t c0 = 0;
     const int nwin = ((max(qlen, 1) - 1 - c0) >> 11) + 1;
+    uint32_t qsum = 0;     // this lane's share of the sum of the read's qualities
     const int32_t qpad = (qlen + 31) & ~31;
 
     // a load inside a rarely taken branch is waited for inside that branch, so that the join behind it
@@ -1151,6 +1204,29 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
         *reinterpret_cast<uint4*>(wsq + lane * 16) = sq;
         lbt[lane] = btv;                                   // lane = entry * 4 + field
         if (NORM) wcb[lane] = cbv;
+        if constexpr (!NORM) {
+            // np.mean(bq_int_lst) of caller.py:310 / bamlib.py:34-36: the bytes are here anyway.  A window behind the
+            // read (k >= nwin) holds a reloaded copy of the last one; bytes behind qlen are masked off
+            if (k < nwin) {
+                if (cq + CWQ <= qlen) {
+                    qsum = __builtin_amdgcn_sad_u8(ba.x, 0u, qsum); qsum = __builtin_amdgcn_sad_u8(ba.y, 0u, qsum);
+                    qsum = __builtin_amdgcn_sad_u8(ba.z, 0u, qsum); qsum = __builtin_amdgcn_sad_u8(ba.w, 0u, qsum);
+                    qsum = __builtin_amdgcn_sad_u8(bb.x, 0u, qsum); qsum = __builtin_amdgcn_sad_u8(bb.y, 0u, qsum);
+                    qsum = __builtin_amdgcn_sad_u8(bb.z, 0u, qsum); qsum = __builtin_amdgcn_sad_u8(bb.w, 0u, qsum);
+                } else {
+                    const uint32_t wa[4] = {ba.x, ba.y, ba.z, ba.w}, wb_[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ra = qlen - (cq + lane * 16 + 4 * i), rb = ra - 1024;   // bytes of the word inside the read
+                        uint32_t xa = wa[i], xb = wb_[i];
+                        if (ra < 4) xa = ra <= 0 ? 0u : (xa & (0xffffffffu >> (8 * (4 - ra))));
+                        if (rb < 4) xb = rb <= 0 ? 0u : (xb & (0xffffffffu >> (8 * (4 - rb))));
+                        qsum = __builtin_amdgcn_sad_u8(xa, 0u, qsum);
+                        qsum = __builtin_amdgcn_sad_u8(xb, 0u, qsum);
+                    }
+                }
+            }
+        }
         // the window's bitmap words move to registers of their own: the ones they arrived in are reloaded next
         uint32_t mylo, myhi;
         asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mylo), "=&v"(myhi) : "v"(s1.x), "v"(s1.y));
@@ -1373,6 +1449,13 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
         window(ba1, bb1, sq1, s11, bt1r, cb1, k + 1);
         if constexpr (CPD > 2) window(ba2, bb2, sq2, s12, bt2r, cb2, k + 2);
         if constexpr (CPD > 3) window(ba3, bb3, sq3, s13, bt3r, cb3, k + 3);
+    }
+    if constexpr (!NORM) {
+        if (A.bqsum) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) qsum += __shfl_down(qsum, d, 64);
+            if (lane == 0) A.bqsum[r] = qsum;
+        }
     }
 #undef CAP_ISSUE
 #undef CAP_SEGWIN

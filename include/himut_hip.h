@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HIMUT_ABI_VERSION 1
+#define HIMUT_ABI_VERSION 2
 
 typedef struct himut_ctx himut_ctx;
 
@@ -56,7 +56,9 @@ enum {
     HIMUT_ERR_CHUNK = 6,        /* chunk with start > end (pysam raises) */
     HIMUT_ERR_COVER = 7,        /* KeyError in tpos2qbase (haplib.py:51) */
     HIMUT_ERR_BQ_RANGE = 8,     /* BQ >= 126: not representable in the pile cell */
-    HIMUT_ERR_NOMEM = 9
+    HIMUT_ERR_NOMEM = 9,
+    HIMUT_ERR_DEPTH = 10        /* the contig's candidate columns need more than 2^32 column-store slots (or one
+                                   256-position window holds more than 2^22 reads): split the contig's chunk list */
 };
 
 /* FILTER column values (caller.py:349-621, vcflib.py:189-209) */
@@ -133,13 +135,16 @@ typedef struct himut_record {
  * recorded: see himut_set_stage_timing. */
 typedef struct himut_run_stats {
     double ms_total;
-    double ms_parse;            /* k_parse_cs: whole-read BQ stream (qv) + cs decode, one wave per read */
-    double ms_bqsum;            /* 0: the quality stream is the first phase of k_parse_cs (kept for ABI layout) */
+    double ms_parse;            /* k_parse_cs: cs decode, one wave per read (+ k_window_index and the fills beside it) */
+    double ms_bqsum;            /* 0: the quality sum is taken inside k_stream_capture (kept for ABI layout) */
     double ms_hap;              /* k_read_hap (phase only) */
-    double ms_emit;             /* k_propose (read filters, proposals -> mask), mask bit count + scan, k_window_index */
-    double ms_index;            /* k_mask_emit (+ sort when chunks are out of order), position bitmap + rank,
-                                   column windows / offsets */
-    double ms_capture;          /* k_stream_capture: streams every read once, fills the column store */
+    double ms_emit;             /* k_propose (read filters, proposals -> mask), mask bit count + scan, k_mask_emit
+                                   (+ sort when chunks are out of order): runs BEHIND the capture, which supplies
+                                   the whole-read quality sums the read filter needs */
+    double ms_index;            /* k_mark_positions (bitmap of substitution positions) + rank, column windows /
+                                   offsets, column-store fill: runs in front of the capture */
+    double ms_capture;          /* k_stream_capture: streams every read once, fills the column store, sums the
+                                   qualities of every read */
     double ms_eval;             /* k_eval_columns: counts, ordered likelihood sums, genotype, filters */
     double ms_finalize;         /* cross-chunk som_seen / counters / compaction */
     int64_t n_reads;
@@ -149,6 +154,9 @@ typedef struct himut_run_stats {
     int64_t n_candidates;       /* evaluated candidates before the cross-chunk pass */
     int64_t n_records;
     int64_t column_slots;       /* column-store slots (unique candidate positions x reads in their windows) */
+    int64_t reran;              /* 1 when the run was repeated with exact buffer sizes because a count exceeded the
+                                   capacities kept from the previous run: ms_* then describe the second pass only
+                                   and the wall time of himut_run covers both */
 } himut_run_stats;
 
 int himut_abi_version(void);

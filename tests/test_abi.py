@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     lib.himut_abi_version.restype = ctypes.c_int
-    assert lib.himut_abi_version() == 1
+    assert lib.himut_abi_version() == 2
 
 
 def test_ffi_export_list_matches_header():
