@@ -99,7 +99,7 @@ struct himut_ctx {
     // derived
     DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs, d_order;
     // run state
-    DevBuf d_mask, d_any, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
+    DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2, d_logpart;
     // normcounts
     DevBuf d_refseq, d_live, d_callable, d_tri;
@@ -113,7 +113,7 @@ struct himut_ctx {
     // through without a host round trip in the middle (0 = not known yet)
     int64_t cap_cand = 0, cap_slots = 0;
     int timing = 1;                          // himut_set_stage_timing: 0 total only, 1 + the column capture, 2 every stage
-    bool mask_clean = false;                 // d_mask / d_any hold zeros only (k_mask_emit leaves them so)
+    bool mask_clean = false;                 // d_mask holds zeros only (k_mask_emit leaves it so)
     void* h_scalars = nullptr;               // pinned landing zone of the scalars block
     std::vector<himut_record> h_recs;
     bool h_recs_valid = false;
@@ -330,11 +330,13 @@ inline void stage_event(himut_ctx* c, int ev, int level, hipStream_t st) {
 
 // side_work: work for the second stream, done while the quality stream + cs decode run
 template <bool WITH_BQ, class F>
-void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, F side_work) {
+void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, F side_work, uint32_t* posbits = nullptr,
+                     int64_t nposwords = 0) {
     hipStream_t st = c->stream;
     // the side stream takes the work that needs nothing from the decode (it starts behind EV_START: the
     // previous run on this context is over by then)
-    hipLaunchKernelGGL(k_parse_cs<WITH_BQ>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err, c->d_ccs.as<uint8_t>());
+    hipLaunchKernelGGL(k_parse_cs<WITH_BQ>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err,
+                       c->d_ccs.as<uint8_t>(), posbits, nposwords);
     HCHECK(hipStreamWaitEvent(c->side, c->ev[EV_START], 0));
     side_work(c->side);
     HCHECK(hipEventRecord(c->ev[EV_SIDE], c->side));
@@ -400,13 +402,12 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     alloc_derived(c);
     const int64_t n4 = ((int64_t)T.positions * 2 + 15) / 16;     // the mask in 16-byte pieces (8 positions each)
     const size_t mask_bytes = (size_t)n4 * 16;
-    const int64_t anyw = ((int64_t)T.positions + 31) / 32;        // summary bitmap: one bit per mask cell
+    const int64_t anyw = ((int64_t)T.positions + 31) / 32;        // the mask sweeps take 32 cells per thread
     const unsigned mtiles = blocks_for(anyw, 256);
-    const void* mask_was = c->d_mask.p; const void* any_was = c->d_any.p;
+    const void* mask_was = c->d_mask.p;
     c->d_mask.reserve(mask_bytes + 64);
-    c->d_any.reserve((size_t)anyw * 4 + 64);
     // the emit sweep zeroes what the propose kernel set: a buffer that went through a whole run is clean
-    const bool clear_mask = !c->mask_clean || mask_was != c->d_mask.p || any_was != c->d_any.p;
+    const bool clear_mask = !c->mask_clean || mask_was != c->d_mask.p;
     c->mask_clean = false;
     c->d_tilecnt.reserve((size_t)mtiles * 4 + 64);
     c->d_tileoff2.reserve((size_t)mtiles * 4 + 64);
@@ -445,23 +446,20 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
-    // window index for the column kernel, the empty position bitmap and the empty mask: none needs the cs
-    // decode, so they run beside it on the second stream
+    // the cs decode sets the bits of the column positions: the bitmap is empty before it starts
+    HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
+    // window index for the column kernel and the empty mask: neither needs the cs decode, so they run beside
+    // it on the second stream
     if (c->n > 0)
         run_parse_stage<false>(c, R, D, sc, [&](hipStream_t side) {
-            HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, side));
-            if (clear_mask) {
-                HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, side));
-                HCHECK(hipMemsetAsync(c->d_any.p, 0, c->d_any.cap, side));
-            }
+            if (clear_mask) HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, side));
+            HCHECK(hipMemsetAsync(c->d_tilecnt.p, 0, (size_t)mtiles * 4, side));
             hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, side, R, nblk,
                                c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>());
-        });
+        }, c->d_posbits_c.as<uint32_t>(), nwords);
     else {
-        if (clear_mask) {
-            HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, st));
-            HCHECK(hipMemsetAsync(c->d_any.p, 0, c->d_any.cap, st));
-        }
+        if (clear_mask) HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, st));
+        HCHECK(hipMemsetAsync(c->d_tilecnt.p, 0, (size_t)mtiles * 4, st));
         stage_event(c, EV_PARSE, 2, st);
     }
     if (phase && T.npairs > 0)
@@ -474,8 +472,6 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
     X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
     if (c->n > 0) {
-        hipLaunchKernelGGL(k_mark_positions, dim3(blocks_for(c->n, 16)), dim3(256), 0, st, R, D, c->params,
-                           c->d_posbits_c.as<uint32_t>(), nwords);
         // rank[w] for w = 0 .. nwords (the last entry is the number of column positions); the bit counts are
         // taken on the fly: the scan reads the bitmap through a transform iterator
         HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, popc_in(), c->d_posrank.as<uint32_t>(), 0u,
@@ -510,8 +506,8 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         hipLaunchKernelGGL(k_stream_capture<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
         stage_event(c, EV_GATHER, 1, st);
         // ---- proposals (the read filters know the quality mean now) -> mask
-        hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, 16)), dim3(256), 0, st, R, D, C, H, c->params,
-                           c->d_mask.as<uint32_t>(), c->d_any.as<uint32_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
+        hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, PROP_READS)), dim3(PROP_READS * 16), 0, st, R, D, C, H, c->params,
+                           c->d_mask.as<uint32_t>(), c->d_tilecnt.as<uint32_t>(), c->d_ccs.as<uint8_t>());
     } else {
         stage_event(c, EV_INDEX, 1, st);
         stage_event(c, EV_GATHER, 1, st);
@@ -519,8 +515,6 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     // the candidates = the set bits of the mask: bits per tile, then a scan
     uint32_t last_tcnt = 0, last_toff = 0;
     if (anyw > 0) {
-        hipLaunchKernelGGL(k_mask_count, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
-                           c->d_tilecnt.as<uint32_t>(), c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
         HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
                                        (size_t)mtiles, rocprim::plus<uint32_t>(), st));
         if (!spec) {
@@ -553,16 +547,16 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
                                        (size_t)ncap, rocprim::plus<uint32_t>(), st));
         if (c->chunks_in_order) {
             c->d_tmp.reserve(scan_tmp + 256);
-            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
-                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands2.as<Cand>(), c->d_keys2.as<uint64_t>(), ncap, &sc->ncand,
-                               (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(), (int64_t)T.positions,
+                               c->d_mask.as<uint16_t>(), c->d_tileoff2.as<uint32_t>(), C, c->d_cands2.as<Cand>(),
+                               c->d_keys2.as<uint64_t>(), ncap, &sc->ncand, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
         } else {
             HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
             c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
-            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_any.as<uint32_t>(), anyw, c->d_mask.as<uint16_t>(),
-                               c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(), c->d_keys.as<uint64_t>(), ncap, &sc->ncand,
-                               (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(), (int64_t)T.positions,
+                               c->d_mask.as<uint16_t>(), c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(),
+                               c->d_keys.as<uint64_t>(), ncap, &sc->ncand, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
             HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
         }
@@ -601,7 +595,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
                            c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), nblk, &sc->nrec, &sc->reserved0,
                            c->d_logpart.as<uint32_t>(), (int64_t)nb, sc->log);
     }
-    if (c->n > 0 && anyw <= 0)   // no mask sweep ran: count the flagged reads here
+    if (c->n > 0 && ncap <= 0)   // no mask sweep ran: count the flagged reads here
         hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
     HCHECK(hipEventRecord(c->ev[EV_FINAL], st));
 

@@ -356,10 +356,23 @@ __device__ __forceinline__ uint32_t cs_pack4(uint32_t f) {                      
 // behind the first KB of the tag, decodes the tag while they are in flight, then sums the qualities
 // (bq_finish): waves in that phase are bound by HBM, waves in the decode by VALU, and a CU holds both kinds at
 // any time.  The call path takes the sum from k_stream_capture, which streams the qualities anyway.
+//
+// posbits (call path; else null): the bitmap of reference positions at which a column must be captured = every
+// substitution of every read that passes the filters known before the qualities have been streamed (identity,
+// mapq, qlen: caller.py:312-317).  A superset of the candidate positions -- the whole-read quality mean
+// (caller.py:310), the trim and mismatch-window filters and the chunk rules only take proposals away (k_propose,
+// which runs behind the capture and knows the mean by then) -- and nearly equal to them.  The wave keeps the
+// positions of its read in LDS and sets the bits once the identity is known (a read with more substitutions than
+// the list holds sets them as it goes: a superset is all that is asked for); the atomics cost the decode nothing,
+// it is bound by instruction issue.
+constexpr int MARK_CAP = 128;
+
 template <bool WITH_BQ>
-__global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs) {
+__global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbits,
+                                                  int64_t nposwords) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
     __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
+    __shared__ int32_t s_mark[4][MARK_CAP];                      // substitution positions of the read (0-based)
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
@@ -383,6 +396,19 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     int32_t* mis = D.mis + sb;
     uint32_t* mq = D.mq + sb;
     const int32_t qlen = uni(R.qlen[r]);
+    int32_t* marks = s_mark[wv];
+    int nmark = 0;
+    const bool mark = posbits != nullptr && !(uni((int)R.mapq[r]) < P.p.min_mapq) &&
+                      (P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit);       // caller.py:312-317
+    auto flush_marks = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < nmark; i += 64) {
+            const int32_t p = marks[i];
+            if (p >= 0 && (int64_t)(p >> 5) < nposwords) atomicOr(posbits + (p >> 5), 1u << (p & 31));
+        }
+        nmark = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     // wave-uniform running state
     int t = M.tstart, q = uni(R.qstart[r]);
     int ns = 0, nm = 0, bad = 0;
@@ -518,6 +544,17 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
                 aa = char2allele(alt);
                 if (aa < 0) bad = HIMUT_ERR_BASE;                    // caller.py:62
                 if (ref != 'N') { ra = char2allele(ref); if (ra < 0) bad = HIMUT_ERR_BASE; }   // bamlib.py:188
+                // the base cs names must be the base SEQ holds (caller.py:62 takes it from cs, the pile from SEQ).  One
+                // random sector of SEQ per substitution: here it is fetched beside a decode that is bound by
+                // instruction issue, not by memory
+                if (ref != 'N' && !bad) {
+                    if (qk < 0 || qk >= qlen) bad = HIMUT_ERR_CS;
+                    else {
+                        const int qa = nib2allele(nib_at(R.seq, M.qoff + qk));
+                        if (qa > 3) bad = HIMUT_ERR_BASE;
+                        else if (qa != aa) bad = HIMUT_ERR_CS;
+                    }
+                }
             }
             const bool ismis = indel || (sub && ref != 'N');
             const int imis = wave_rank_incl(ismis);
@@ -525,6 +562,15 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
                 const int w = nm + imis - 1;
                 mis[w] = tk + 1;
                 mq[w] = sub ? (((uint32_t)qk << 5) | 16u | ((uint32_t)(ra & 3) << 2) | (uint32_t)(aa & 3)) : ((uint32_t)qk << 5);
+            }
+            if (mark) {
+                const bool mk = sub && ref != 'N';
+                const unsigned long long mb = __ballot(mk);
+                if (mb) {
+                    if (nmark + __popcll(mb) > MARK_CAP) flush_marks();
+                    if (mk) marks[nmark + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u))] = tk;
+                    nmark += __popcll(mb);
+                }
             }
             // identity counts (bamlib.py:47-63)
             match += (valid && (kind == ':' || kind == '=')) ? dt : 0;
@@ -576,12 +622,14 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { match += __shfl_xor(match, d, 64); mism += __shfl_xor(mism, d, 64); }
+    // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow in k_propose
+    const double ident = (double)match / (double)(match + mism);
+    const bool ident_ok = !bad && !(ident < P.p.min_sequence_identity);
+    if (mark && ident_ok && nmark > 0) flush_marks();
     if (lane == 0) {
         if (bad) { set_err(err, bad); ns = 0; nm = 0; }
-        // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow in k_read_filters
-        const double ident = (double)match / (double)(match + mism);
         uint8_t fl = 0;
-        if (!bad && !(ident < P.p.min_sequence_identity)) fl = RF_IDENT_OK;
+        if (ident_ok) fl = RF_IDENT_OK;
         if (has_long) fl |= RF_LONGCS;
         M.nseg = ns; M.flags = fl;
         D.nseg[r] = ns;
@@ -663,32 +711,6 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
 }
 
 // ---------------------------------------------------------------------------------------
-// k_mark_positions: the bitmap of reference positions at which a column must be captured = every substitution of
-// every read that passes the filters known before the qualities have been streamed (identity, mapq, qlen:
-// caller.py:312-317).  A superset of the candidate positions -- the whole-read quality mean (caller.py:310), the
-// trim and mismatch-window filters and the chunk rules only take proposals away (k_propose, which runs behind
-// the capture and knows the mean by then) -- and nearly equal to them.  Sixteen lanes per read.
-__global__ void __launch_bounds__(256) k_mark_positions(Reads R, Derived D, Params P, uint32_t* posbits, int64_t nwords) {
-    const int gl = threadIdx.x & 15;
-    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (r >= R.n) return;
-    const ReadMeta M = D.meta[r];
-    const int32_t qlen = R.qlen[r];
-    const int mapq = R.mapq[r];
-    const int nm = D.nmis[r];
-    if ((M.flags & RF_SECONDARY) || !(M.flags & RF_IDENT_OK)) return;
-    if (mapq < P.p.min_mapq) return;
-    if (!(P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit)) return;
-    const int32_t* mis = D.mis + M.segbase;
-    const uint32_t* mq = D.mq + M.segbase;
-    for (int e = gl; e < nm; e += 16) {
-        const uint32_t v = mq[e];
-        const int32_t rpos = mis[e] - 1;
-        if ((v & 16u) && rpos >= 0 && (int64_t)(rpos >> 5) < nwords) atomicOr(posbits + (rpos >> 5), 1u << (rpos & 31));
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // k_propose: sixteen lanes per read, four reads per wave (a read has about ten mismatch entries and the chunk
 // look-up needs sixteen lanes: a whole wave per read would leave the kernel bound by the number of
 // resident waves times the latency of its dependent loads).  Applies the read filters (caller.py:310-317), checks
@@ -697,13 +719,37 @@ __global__ void __launch_bounds__(256) k_mark_positions(Reads R, Derived D, Para
 // both contains tpos (caller.py:104-108,325) and fetched the read (caller.py:299), sets the
 // (ref, alt) bit of the position in that chunk's mask -- the set() of caller.py:324.
 // The candidates are enumerated from the mask afterwards.
+//
+// Scattered atomics are what this kernel is made of (the chip does 20-30 of them per ns, each lane its own cache
+// line), and three in four of them repeat one that a neighbouring read has just made: the 15-30 reads over a
+// germline site propose the same (position, ref, alt).  A workgroup therefore takes 64 consecutive reads and keeps
+// the proposals it has made in a small LDS table (the key is swapped in; finding itself there, a proposal is
+// dropped), which leaves about one atomic per germline site and workgroup.  The table only ever drops exact
+// repeats, so the mask is the same set() as before.
+// The proposal that sets a mask bit for the first time also counts it in its tile of 8192 mask cells: the scan of
+// those counts is where k_mask_emit puts each tile's candidates.
 constexpr int EMIT_MAXC = 4;   // chunks of one read kept in registers
+constexpr int PROP_READS = 64; // reads per workgroup (16 lanes each)
+constexpr int PROP_TAB = 2048; // entries of the recent-proposal table
+constexpr int MASK_TILE_SHIFT = 13;
+constexpr int MASK_TILE_CELLS = 1 << MASK_TILE_SHIFT;
 
-__global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, Phase H, Params P, uint32_t* mask, uint32_t* anyb,
-                                                 uint8_t* ccs_flag, int* err) {
+__global__ void __launch_bounds__(PROP_READS * 16) k_propose(Reads R, Derived D, Chunks C, Phase H, Params P, uint32_t* mask,
+                                                             uint32_t* tilecnt, uint8_t* ccs_flag) {
+    __shared__ unsigned long long s_seen[PROP_TAB];
+    for (int i = threadIdx.x; i < PROP_TAB; i += PROP_READS * 16) s_seen[i] = ~0ull;
+    __syncthreads();
     const int gl = threadIdx.x & 15, gsh = (threadIdx.x & 48);      // lane in its group of 16, the group's first lane
-    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t r = (int64_t)blockIdx.x * PROP_READS + (threadIdx.x >> 4);
     if (r >= R.n) return;
+    // the (ref, alt) bit of a mask cell: 16 mask bits per position, two positions per 32-bit word
+    auto propose = [&](const int64_t cell, const int bit) {
+        const unsigned long long key = ((unsigned long long)cell << 4) | (unsigned long long)bit;
+        const uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53);        // 11 bits
+        if (atomicExch(&s_seen[h], key) == key) return;
+        const uint32_t m = (1u << bit) << ((cell & 1) ? 16 : 0);
+        if (!(atomicOr(mask + (cell >> 1), m) & m)) atomicAdd(tilecnt + (cell >> MASK_TILE_SHIFT), 1u);
+    };
     // cross-lane operations below stay inside the group: shuffles of width 16, the group's 16 bits of a ballot;
     // every branch around them is decided per read, i.e. uniform in the group
 #define GBALLOT(P) ((uint32_t)((__ballot(P) >> gsh) & 0xffffull))
@@ -773,12 +819,12 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
         else if (gl == 0) ccs_flag[qid] = 1;
     } else live = false;
 
+    if (!live) return;         // (the cs-vs-SEQ check of every substitution is k_parse_cs's)
     const int32_t* mis = D.mis + M.segbase;
     const uint32_t* mq = D.mq + M.segbase;
     const double trim_start = floor(P.p.min_trim * (double)qlen);        // bamlib.py:226
     const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);   // bamlib.py:227
     const int64_t w = P.p.mismatch_window_size;
-    int bad = 0;
     for (int e = gl; e < nm; e += 16) {
         const uint32_t v = mq[e];
         const int32_t tp1 = mis[e];
@@ -786,11 +832,6 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
         const int32_t mnext = e + 1 < nm ? mis[e + 1] : 0x7fffffff;
         if (!(v & 16u)) continue;                                             // substitutions only
         const int64_t q = v >> 5;
-        // the base cs names must be the base SEQ holds (caller.py:62 uses cs, the pile uses SEQ)
-        const int qa = nib2allele(nib_at(R.seq, M.qoff + q));
-        if (qa > 3) bad = HIMUT_ERR_BASE;
-        else if (qa != (int)(v & 3u)) bad = HIMUT_ERR_CS;
-        if (!live) continue;
         if ((double)q < trim_start || (double)q > trim_end) continue;          // bamlib.py:231-242
         {                                                                     // bamlib.py:245-282
             int64_t qs = q - w, qe = q + w, ur, dr;
@@ -808,72 +849,79 @@ __global__ void __launch_bounds__(256) k_propose(Reads R, Derived D, Chunks C, P
         if (!overflow) {
 #pragma unroll
             for (int k = 0; k < EMIT_MAXC; k++)
-                if (cc[k] >= 0 && cst[k] <= tp1 && tp1 <= cen[k]) {
-                    // 16 mask bits per position, two positions per 32-bit word
-                    const int64_t cell = cmo[k] + (tp1 - cst[k]);
-                    // the summary bit is set by whoever touches the cell first: far fewer atomics on the (much denser,
-                    // hence much more contended) summary words than one per proposal
-                    const int sh = (cell & 1) ? 16 : 0;
-                    const uint32_t old = atomicOr(mask + (cell >> 1), (1u << bit) << sh);
-                    if (!((old >> sh) & 0xffffu)) atomicOr(anyb + (cell >> 5), 1u << (cell & 31));
-                }
+                if (cc[k] >= 0 && cst[k] <= tp1 && tp1 <= cen[k]) propose(cmo[k] + (tp1 - cst[k]), bit);
         } else {
             for (int64_t jj = hi - 1; jj >= 0 && C.rec[jj].pmaxend > ts; jj--) {
                 const ChunkRec qr = C.rec[jj];
                 if (qr.end <= ts || !(qr.start <= tp1 && tp1 <= qr.end)) continue;
                 if (phase && H.hap[qr.pairbase + r] == HAP_NONE) continue;
-                const int64_t cell = qr.maskoff + (tp1 - qr.start);
-                const int sh = (cell & 1) ? 16 : 0;
-                const uint32_t old = atomicOr(mask + (cell >> 1), (1u << bit) << sh);
-                if (!((old >> sh) & 0xffffu)) atomicOr(anyb + (cell >> 5), 1u << (cell & 31));
+                propose(qr.maskoff + (tp1 - qr.start), bit);
             }
         }
     }
-    if (bad) set_err(err, bad);
 #undef GBALLOT
 }
 
 // ---------------------------------------------------------------------------------------
 // The candidate list = the set bits of the mask (16 bits per cell: one per (ref, alt)).  Cells
-// with a bit are few (one in ~150 at 30x), so k_propose also sets one bit per touched cell in a
-// summary bitmap and the two sweeps read that instead of the mask: bits per tile of 8192 cells
-// (a 32-bit summary word per thread), then -- after a scan of the tile counts -- the candidates
-// themselves, in mask order: chunk, position, then (ref, alt) in ASCII order.  The sort key of
-// a candidate == the sort key of its record: (tpos, chunk, ref, alt), natsorted order of the
-// reference's tuples (caller.py:622).  The emit sweep leaves mask and summary zeroed for the
-// next run.
-constexpr int MASK_TILE_CELLS = 8192;
+// with a bit are few (one in ~150 at 30x) and all of them sit at column positions, so the two
+// sweeps read the position bitmap (k_parse_cs) instead of the mask and look only at the cells of
+// marked positions: bits per tile of 8192 cells (32 cells per thread), then -- after a scan of
+// the tile counts -- the candidates themselves, in mask order: chunk, position, then (ref, alt)
+// in ASCII order.  The sort key of a candidate == the sort key of its record: (tpos, chunk, ref,
+// alt), natsorted order of the reference's tuples (caller.py:622).  The emit sweep leaves the
+// mask zeroed for the next run.
 
-// Also counts the reads k_propose flagged (num_ccs, caller.py:318-320): ccs[0 .. nreads), added to *nccs.
-__global__ void __launch_bounds__(256) k_mask_count(const uint32_t* anyb, int64_t nwords, const uint16_t* mask16, uint32_t* tilecnt,
-                                                    const uint8_t* ccs, int64_t nreads, unsigned long long* nccs) {
-    __shared__ int s_w[4], s_f[4];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int c = 0, f = 0;
-    uint32_t w = i < nwords ? anyb[i] : 0u;
-    while (w) { const int b = __ffs((int)w) - 1; w &= w - 1; c += __popc((uint32_t)mask16[i * 32 + b]); }
-    for (int64_t j = i; j < nreads; j += (int64_t)gridDim.x * 256) f += ccs[j];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { c += __shfl_xor(c, d, 64); f += __shfl_xor(f, d, 64); }
-    if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = c; s_f[threadIdx.x >> 6] = f; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        tilecnt[blockIdx.x] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
-        const int ft = s_f[0] + s_f[1] + s_f[2] + s_f[3];
-        if (ft) atomicAdd(nccs, (unsigned long long)ft);
+// where a thread of the sweeps stands in the chunk list
+struct CellCursor {
+    int64_t ck, cbeg, cend;   // chunk of the cell, its first cell, first cell of the next chunk
+    int32_t cstart;           // the chunk's start (tpos of cell cbeg)
+};
+
+// Summary word of the mask cells [32 i, 32 i + 32): bit b set when the cell's position (rpos = tpos - 1) is a
+// column position.  cur: the chunk of the tile's first cell on entry, of cell 32 i on return.
+__device__ __forceinline__ uint32_t cell_summary(const Chunks& C, const uint32_t* posbits, int64_t i, int64_t ncells, CellCursor& cur) {
+    const int64_t c0 = i * 32;
+    if (c0 >= ncells) return 0u;
+    while (c0 >= cur.cend) { cur.ck++; cur.cbeg = cur.cend; cur.cend = C.maskoff[cur.ck + 1]; cur.cstart = C.start[cur.ck]; }
+    if (c0 + 32 <= cur.cend) {                       // the 32 cells lie in one chunk: 32 consecutive positions
+        const int64_t rp = (int64_t)cur.cstart + (c0 - cur.cbeg) - 1;
+        if (rp < 0) return posbits[0] << 1;          // cell of tpos 0 (a chunk that starts at 0): no such position
+        const uint32_t lo = posbits[rp >> 5], hi = posbits[(rp >> 5) + 1];
+        const int sh = (int)(rp & 31);
+        return sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
     }
+    uint32_t w = 0;
+    CellCursor t = cur;
+    for (int b = 0; b < 32 && c0 + b < ncells; b++) {
+        const int64_t c = c0 + b;
+        while (c >= t.cend) { t.ck++; t.cbeg = t.cend; t.cend = C.maskoff[t.ck + 1]; t.cstart = C.start[t.ck]; }
+        const int64_t rp = (int64_t)t.cstart + (c - t.cbeg) - 1;
+        if (rp >= 0 && ((posbits[rp >> 5] >> (rp & 31)) & 1u)) w |= 1u << b;
+    }
+    return w;
 }
 
 // cap: capacity of cands / keys (the host may have sized them before the count was known: nothing is
 // written past it, and the true count lands in *total for the host to compare with cap)
-// posbits (optional): the bitmap of candidate positions (bit rpos = tpos - 1), zeroed by the host beforehand
-__global__ void __launch_bounds__(256) k_mask_emit(uint32_t* anyb, int64_t nwords, uint16_t* mask16, const uint32_t* tileoff, Chunks C,
-                                                   Cand* cands, uint64_t* keys, int64_t cap, unsigned long long* total,
-                                                   uint32_t* posbits) {
+// Also counts the reads k_propose flagged (num_ccs, caller.py:318-320): ccs[0 .. nreads), added to *nccs.
+__global__ void __launch_bounds__(256) k_mask_emit(const uint32_t* posbits, int64_t ncells, uint16_t* mask16, const uint32_t* tileoff,
+                                                   Chunks C, Cand* cands, uint64_t* keys, int64_t cap, unsigned long long* total,
+                                                   const uint8_t* ccs, int64_t nreads, unsigned long long* nccs) {
     __shared__ int s_w[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t w = i < nwords ? anyb[i] : 0u;
+    {
+        int f = 0;
+        for (int64_t j = i; j < nreads; j += (int64_t)gridDim.x * 256) f += ccs[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) f += __shfl_xor(f, d, 64);
+        if (lane == 0 && f) atomicAdd(nccs, (unsigned long long)f);
+    }
+    // the chunk of the tile's first cell comes with the tile; cells may run into the next chunks
+    const MaskTile mt = C.mtile[blockIdx.x];
+    CellCursor cur = {mt.ck0, mt.off0, mt.off1, mt.start0};
+    uint32_t w = cell_summary(C, posbits, i, ncells, cur);
     int c = 0;
     for (uint32_t x = w; x; x &= x - 1) c += __popc((uint32_t)mask16[i * 32 + (__ffs((int)x) - 1)]);
     const int incl = wave_incl_add(c, lane);
@@ -881,24 +929,21 @@ __global__ void __launch_bounds__(256) k_mask_emit(uint32_t* anyb, int64_t nword
     __syncthreads();
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         *total = (unsigned long long)tileoff[blockIdx.x] + (unsigned long long)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
-    if (!w) return;
-    anyb[i] = 0u;
+    if (!c) return;
     int64_t slot = (int64_t)tileoff[blockIdx.x] + (incl - c);
 #pragma unroll
     for (int k = 0; k < 4; k++) if (k < wv) slot += s_w[k];
-    // the chunk of the tile's first cell comes with the tile; cells may run into the next chunks
-    const MaskTile mt = C.mtile[blockIdx.x];
-    int64_t ck = mt.ck0;
-    int64_t cbeg = mt.off0, cend_ = mt.off1;
-    int32_t cstart = mt.start0;
+    int64_t ck = cur.ck;
+    int64_t cbeg = cur.cbeg, cend_ = cur.cend;
+    int32_t cstart = cur.cstart;
     while (w) {
         const int b = __ffs((int)w) - 1; w &= w - 1;
         const int64_t cell = i * 32 + b;
         const uint32_t m = mask16[cell];
+        if (!m) continue;
         mask16[cell] = 0;
         while (cell >= cend_) { ck++; cbeg = cend_; cend_ = C.maskoff[ck + 1]; cstart = C.start[ck]; }
         const int32_t tpos = cstart + (int32_t)(cell - cbeg);
-        if (posbits && tpos >= 1) atomicOr(posbits + ((tpos - 1) >> 5), 1u << ((tpos - 1) & 31));
 #pragma unroll
         for (int rk = 0; rk < 16; rk++) {   // (ref, alt) in ASCII order A C G T = alleles 0 3 2 1
             const int ra = (0x1230 >> (4 * (rk >> 2))) & 15, aa = (0x1230 >> (4 * (rk & 3))) & 15;
@@ -982,13 +1027,6 @@ __device__ __forceinline__ uint32_t pos_rank(const PosIndex& X, int32_t rpos) {
 __device__ __forceinline__ int64_t dev_count(const unsigned long long* n_dev, int64_t cap) {
     const unsigned long long n = *n_dev;
     return n < (unsigned long long)cap ? (int64_t)n : cap;
-}
-
-__global__ void __launch_bounds__(256) k_candpos_set(const Cand* cands, const unsigned long long* n_dev, int64_t cap, uint32_t* bits) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= dev_count(n_dev, cap)) return;
-    const int32_t rpos = cands[j].tpos - 1;
-    if (rpos >= 0) atomicOr(bits + (rpos >> 5), 1u << (rpos & 31));
 }
 
 __global__ void __launch_bounds__(256) k_word_popc(const uint32_t* bits, int64_t nwords, uint32_t* out) {
