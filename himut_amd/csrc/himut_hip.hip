@@ -113,7 +113,9 @@ struct himut_ctx {
     // through without a host round trip in the middle (0 = not known yet)
     int64_t cap_cand = 0, cap_slots = 0;
     int timing = 1;                          // himut_set_stage_timing: 0 total only, 1 + the column capture, 2 every stage
-    bool mask_clean = false;                 // d_mask holds zeros only (k_mask_emit leaves it so)
+    bool mask_clean = false;                 // d_mask and d_tilecnt hold zeros only (k_mask_emit leaves them so)
+    int64_t win_nblk = 0;                    // d_winlo / d_winhi hold the read windows of the pushed reads for this many
+                                             // 256-position blocks (0: not computed yet)
     void* h_scalars = nullptr;               // pinned landing zone of the scalars block
     std::vector<himut_record> h_recs;
     bool h_recs_valid = false;
@@ -409,32 +411,33 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     // the emit sweep zeroes what the propose kernel set: a buffer that went through a whole run is clean
     const bool clear_mask = !c->mask_clean || mask_was != c->d_mask.p;
     c->mask_clean = false;
+    const void* tcnt_was = c->d_tilecnt.p;
     c->d_tilecnt.reserve((size_t)mtiles * 4 + 64);
     c->d_tileoff2.reserve((size_t)mtiles * 4 + 64);
+    const bool clear_all = clear_mask || tcnt_was != c->d_tilecnt.p;
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
-    int32_t maxend = 0;
-    for (int32_t e : c->cend) maxend = std::max(maxend, e);
-    const int64_t nblk = ((int64_t)maxend >> WIN_SHIFT) + 2;
-    // bitmap of column positions: probed at every position a read covers, so it spans reads as well as chunks
+    // bitmap of column positions: probed at every position a read covers, so it spans reads as well as chunks; the
+    // read windows and the column offsets are kept per 256 positions of the same span
     int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
-    maxpos = std::max(maxpos, maxend);
-    const int64_t nwords = ((int64_t)maxpos >> 5) + 2;
-    size_t scan_tiles = 0, scan2 = 0, scan3 = 0;
-    auto popc_in = [&]() { return rocprim::make_transform_iterator(c->d_posbits_c.as<uint32_t>(), PopcWord()); };
+    for (int32_t e : c->cend) maxpos = std::max(maxpos, e);
+    const int64_t nblk = ((int64_t)maxpos >> WIN_SHIFT) + 2;
+    const int64_t nwords = nblk * 8;
+    size_t scan_tiles = 0, scan3 = 0;
+    BlockCount BC;
+    auto blk_in = [&]() { return rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), BC); };
     {   // buffers and scan scratch whose sizes the host knows now: sized before anything is queued (growing a
         // buffer in the middle of a run would free it under the kernels already queued on it)
         c->d_winlo.reserve((size_t)nblk * 4 + 64);
         c->d_winhi.reserve((size_t)nblk * 4 + 64);
         c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
-        c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
+        c->d_posrank.reserve((size_t)nblk * sizeof(uint2) + 256);          // the scan's output: (first rank, slot offset) per block
         c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
         c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
+        BC.bits = c->d_posbits_c.as<uint32_t>(); BC.winlo = c->d_winlo.as<int32_t>(); BC.winhi = c->d_winhi.as<int32_t>();
         uint32_t* nul = nullptr;
         HCHECK(rocprim::exclusive_scan(nullptr, scan_tiles, nul, nul, 0u, (size_t)std::max<unsigned>(mtiles, 1u), rocprim::plus<uint32_t>(), st));
-        HCHECK(rocprim::exclusive_scan(nullptr, scan2, rocprim::make_transform_iterator(nul, PopcWord()), nul, 0u,
-                                       (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
-        HCHECK(rocprim::exclusive_scan(nullptr, scan3, nul, nul, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), st));
-        c->d_tmp2.reserve(std::max(std::max(scan_tiles, scan2), scan3) + 256);
+        HCHECK(rocprim::exclusive_scan(nullptr, scan3, blk_in(), c->d_posrank.as<uint2>(), make_uint2(0u, 0u), (size_t)nblk, PlusU2(), st));
+        c->d_tmp2.reserve(std::max(scan_tiles, scan3) + 256);
     }
 
     Reads R = make_reads(c);
@@ -448,43 +451,49 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
     // the cs decode sets the bits of the column positions: the bitmap is empty before it starts
     HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
-    // window index for the column kernel and the empty mask: neither needs the cs decode, so they run beside
-    // it on the second stream
-    if (c->n > 0)
-        run_parse_stage<false>(c, R, D, sc, [&](hipStream_t side) {
-            if (clear_mask) HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, side));
-            HCHECK(hipMemsetAsync(c->d_tilecnt.p, 0, (size_t)mtiles * 4, side));
+    // The read windows per 256 positions depend on the pushed reads only (like a BAM index they are made once per
+    // batch: the first run after himut_push_reads).  That kernel and the fills of a mask that is not known to be
+    // empty need nothing from the cs decode: they run beside it on the second stream.  A context that has been
+    // through a run has neither to do, and the second stream stays idle.
+    const bool need_win = c->n > 0 && c->win_nblk != nblk;
+    auto side_work = [&](hipStream_t side) {
+        if (clear_all) {
+            HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, side));
+            HCHECK(hipMemsetAsync(c->d_tilecnt.p, 0, c->d_tilecnt.cap, side));
+        }
+        if (need_win)
             hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, side, R, nblk,
                                c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>());
-        }, c->d_posbits_c.as<uint32_t>(), nwords);
-    else {
-        if (clear_mask) HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, st));
-        HCHECK(hipMemsetAsync(c->d_tilecnt.p, 0, (size_t)mtiles * 4, st));
+    };
+    if (c->n > 0) {
+        if (clear_all || need_win)
+            run_parse_stage<false>(c, R, D, sc, side_work, c->d_posbits_c.as<uint32_t>(), nwords);
+        else {
+            hipLaunchKernelGGL(k_parse_cs<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err,
+                               c->d_ccs.as<uint8_t>(), c->d_posbits_c.as<uint32_t>(), nwords);
+            if (c->any_longcs)
+                hipLaunchKernelGGL(k_check_longcs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, &sc->err);
+            stage_event(c, EV_PARSE, 2, st);
+        }
+        c->win_nblk = nblk;
+    } else {
+        side_work(st);
         stage_event(c, EV_PARSE, 2, st);
     }
     if (phase && T.npairs > 0)
         hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
     stage_event(c, EV_HAP, 2, st);
 
-    // ---- columns: positions -> rank -> per 256-position block the read window and the offset of its columns
+    // ---- columns: per 256-position block the column positions and the read window -> one scan -> the block table
     size_t slot_cap = 0;
     PosIndex X;
-    X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
+    X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = nullptr; X.nwords = nwords;
     X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
     if (c->n > 0) {
-        // rank[w] for w = 0 .. nwords (the last entry is the number of column positions); the bit counts are
-        // taken on the fly: the scan reads the bitmap through a transform iterator
-        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, popc_in(), c->d_posrank.as<uint32_t>(), 0u,
-                                       (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
-        // per 256-position block: slots = column positions x reads of the window, then their offsets
-        hipLaunchKernelGGL(k_block_slots, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
-                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, c->d_blkslots.as<uint32_t>(),
-                           (unsigned long long*)nullptr);
-        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
-                                       (size_t)nblk, rocprim::plus<uint32_t>(), st));
-        hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
-                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_blkoff.as<uint32_t>(), nblk,
-                           c->d_blktab.as<BlockTab>(), &sc->err);
+        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, blk_in(), c->d_posrank.as<uint2>(), make_uint2(0u, 0u), (size_t)nblk,
+                                       PlusU2(), st));
+        hipLaunchKernelGGL(k_block_table2, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, BC, c->d_posrank.as<uint2>(), nblk,
+                           c->d_blktab.as<BlockTab>(), c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), &sc->err);
         size_t slot_reserve = (size_t)c->cap_slots;
         slot_cap = (size_t)c->cap_slots;
         if (!spec) {
@@ -512,7 +521,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         stage_event(c, EV_INDEX, 1, st);
         stage_event(c, EV_GATHER, 1, st);
     }
-    // the candidates = the set bits of the mask: bits per tile, then a scan
+    // the candidates = the set bits of the mask; k_propose counted them per tile: the scan places the tiles
     uint32_t last_tcnt = 0, last_toff = 0;
     if (anyw > 0) {
         HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
@@ -549,14 +558,14 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
             c->d_tmp.reserve(scan_tmp + 256);
             hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(), (int64_t)T.positions,
                                c->d_mask.as<uint16_t>(), c->d_tileoff2.as<uint32_t>(), C, c->d_cands2.as<Cand>(),
-                               c->d_keys2.as<uint64_t>(), ncap, &sc->ncand, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
+                               c->d_keys2.as<uint64_t>(), ncap, &sc->ncand, c->d_tilecnt.as<uint32_t>());
         } else {
             HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
             c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
             hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(), (int64_t)T.positions,
                                c->d_mask.as<uint16_t>(), c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(),
-                               c->d_keys.as<uint64_t>(), ncap, &sc->ncand, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
+                               c->d_keys.as<uint64_t>(), ncap, &sc->ncand, c->d_tilecnt.as<uint32_t>());
             HCHECK(rocprim::radix_sort_pairs(c->d_tmp.p, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
         }
@@ -586,7 +595,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         c->d_logpart.reserve((size_t)nb * 16 * 4 + 64);
         hipLaunchKernelGGL(k_finalize_flags, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
                            c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, ncand_dev, ncap, c->d_emit.as<uint32_t>(),
-                           c->d_logpart.as<uint32_t>());
+                           c->d_logpart.as<uint32_t>(), c->d_ccs.as<uint8_t>(), c->n);
         HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
                                        (size_t)ncap, rocprim::plus<uint32_t>(), st));
         hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), (const uint32_t*)nullptr,
@@ -613,7 +622,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     c->stats.column_slots = nslots;
     c->n_out = ncap > 0 ? (int64_t)hs.nrec : 0;
     for (int k = 0; k < 15; k++) c->log[k] = (int64_t)hs.log[k];
-    c->log[0] = (int64_t)hs.nccs;
+    if (ncap <= 0) c->log[0] = (int64_t)hs.nccs;     // (else counter 0 came with the others, k_finalize_flags)
 
     auto ms = [&](int a, int b) { float f = 0; (void)hipEventElapsedTime(&f, c->ev[a], c->ev[b]); return (double)f; };
     himut_run_stats& S = c->stats;
@@ -827,6 +836,7 @@ int himut_push_reads(himut_ctx* c, const himut_read_batch* b) {
         HCHECK(hipStreamSynchronize(st));
         c->have_reads = true;
         c->tables_valid = false;   // the chunk tables hold read windows
+        c->win_nblk = 0;
         c->h_recs_valid = false;
         return HIMUT_OK;
     });

@@ -904,20 +904,14 @@ __device__ __forceinline__ uint32_t cell_summary(const Chunks& C, const uint32_t
 
 // cap: capacity of cands / keys (the host may have sized them before the count was known: nothing is
 // written past it, and the true count lands in *total for the host to compare with cap)
-// Also counts the reads k_propose flagged (num_ccs, caller.py:318-320): ccs[0 .. nreads), added to *nccs.
+// tilecnt: the tile counts k_propose made (their scan is tileoff); zeroed here for the next run, like the mask.
 __global__ void __launch_bounds__(256) k_mask_emit(const uint32_t* posbits, int64_t ncells, uint16_t* mask16, const uint32_t* tileoff,
                                                    Chunks C, Cand* cands, uint64_t* keys, int64_t cap, unsigned long long* total,
-                                                   const uint8_t* ccs, int64_t nreads, unsigned long long* nccs) {
+                                                   uint32_t* tilecnt) {
     __shared__ int s_w[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    {
-        int f = 0;
-        for (int64_t j = i; j < nreads; j += (int64_t)gridDim.x * 256) f += ccs[j];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) f += __shfl_xor(f, d, 64);
-        if (lane == 0 && f) atomicAdd(nccs, (unsigned long long)f);
-    }
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = 0;
     // the chunk of the tile's first cell comes with the tile; cells may run into the next chunks
     const MaskTile mt = C.mtile[blockIdx.x];
     CellCursor cur = {mt.ck0, mt.off0, mt.off1, mt.start0};
@@ -1017,9 +1011,58 @@ struct PosIndex {
     int64_t nblk;
 };
 
+// Rank of a position among the column positions = the block's first rank (BlockTab) + the set bits of the block's
+// eight bitmap words in front of it (one 32-byte sector).
+__device__ __forceinline__ uint32_t pos_rank_in_block(const uint32_t* bits, int32_t rpos) {
+    const uint4* wp = reinterpret_cast<const uint4*>(bits + (((int64_t)rpos >> 8) << 3));
+    const uint4 a = wp[0], b = wp[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const int wi = (rpos >> 5) & 7;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t m = k < wi ? 0xffffffffu : (k == wi ? ((1u << (rpos & 31)) - 1u) : 0u);
+        c += (uint32_t)__popc(w[k] & m);
+    }
+    return c;
+}
 __device__ __forceinline__ uint32_t pos_rank(const PosIndex& X, int32_t rpos) {
-    const int64_t w = rpos >> 5;
-    return X.rank[w] + (uint32_t)__popc(X.bits[w] & ((1u << (rpos & 31)) - 1u));
+    return X.bt[rpos >> 8].ufirst + pos_rank_in_block(X.bits, rpos);
+}
+
+// Column positions and column-store slots per 256-position block, taken straight from the bitmap and the read
+// windows: the input of ONE scan whose two sums are each block's first rank and its slot offset.
+struct BlockCount {
+    const uint32_t* bits;
+    const int32_t *winlo, *winhi;
+    __host__ __device__ uint2 operator()(int64_t b) const {
+        const uint4* wp = reinterpret_cast<const uint4*>(bits + (b << 3));
+        const uint4 x = wp[0], y = wp[1];
+        const uint32_t cnt = (uint32_t)(__builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w) +
+                                        __builtin_popcount(y.x) + __builtin_popcount(y.y) + __builtin_popcount(y.z) + __builtin_popcount(y.w));
+        const unsigned long long s = ((unsigned long long)cnt * (unsigned long long)(uint32_t)(winhi[b] - winlo[b]) + 15ULL) & ~15ULL;
+        return make_uint2(cnt, (uint32_t)s);      // every block starts on a 32-byte boundary of the column store
+    }
+};
+struct PlusU2 {
+    __host__ __device__ uint2 operator()(const uint2& a, const uint2& b) const { return make_uint2(a.x + b.x, a.y + b.y); }
+};
+
+// BlockTab from that scan (first rank, slot offset).  Also leaves the slot offsets / counts as plain arrays (the run's
+// totals).  err: HIMUT_ERR_DEPTH when the column store of the contig needs more than 2^32 slots (a block's product or
+// the running offset no longer fits the 32-bit fields) or a window holds more than 2^22 reads.
+__global__ void __launch_bounds__(256) k_block_table2(BlockCount F, const uint2* scan, int64_t nblk, BlockTab* bt, uint32_t* blkoff,
+                                                      uint32_t* blkslots, int* err) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const uint2 c = F(b), o = scan[b];
+    const uint32_t nr = (uint32_t)(F.winhi[b] - F.winlo[b]);
+    BlockTab t;
+    t.lo = F.winlo[b]; t.ncnt = nr | (c.x << 22); t.boff = o.y; t.ufirst = o.x;
+    bt[b] = t;
+    blkoff[b] = o.y; blkslots[b] = c.y;
+    const unsigned long long s = ((unsigned long long)c.x * nr + 15ULL) & ~15ULL;
+    if (nr > BT_N_MASK || s > 0xffffffffULL || (unsigned long long)o.y + s > 0xffffffffULL) set_err(err, HIMUT_ERR_DEPTH);
 }
 
 // The kernels behind the candidate count take it from device memory (*n_dev, clamped to the capacity the
@@ -1187,7 +1230,9 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
     uint32_t bt0r, bt1r, bt2r, bt3r;
     uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
     CAP_ISSUE(ba0, bb0, sq0, s10, bt0r, cb0, 0, tstart);
-    const uint32_t rk0 = uni(X.rank[min((int64_t)(tstart >> 5), X.nwords)]);
+    // rank of the first column position at or behind tstart: the block's first rank + the bits in front of tstart
+    const uint32_t rk0 = uni(X.bt[min((int64_t)(tstart >> 8), X.nblk - 1)].ufirst) +
+                         uni(pos_rank_in_block(X.bits, (int32_t)min((int64_t)tstart, (X.nblk << 8) - 1) & ~31));
     __builtin_amdgcn_wave_barrier();
 
     // end of window kk in reference coordinates: the first position whose query offset is >= c
@@ -2004,13 +2049,21 @@ __global__ void __launch_bounds__(256) k_resolve_seen(himut_record* recs, const 
 // counters (caller.py:625-641) + output flags in sorted order
 // emit[] is written for the whole capacity (zeros past the count), so that its scan can run over the capacity.
 // Counters: one ballot per counter and wave, one shared-memory add per wave, one global add per block.
+// Counter 0 (num_ccs, caller.py:318-320) = the reads k_propose flagged: ccs[0 .. nreads).
 __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, const uint64_t* keys, const uint32_t* vals,
                                                         const unsigned long long* n_dev, int64_t cap, uint32_t* emit,
-                                                        uint32_t* logpart) {
+                                                        uint32_t* logpart, const uint8_t* ccs, int64_t nreads) {
     __shared__ unsigned int s_log[16];
     if (threadIdx.x < 16) s_log[threadIdx.x] = 0;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        unsigned int f = 0;
+        for (int64_t j = i; j < nreads; j += (int64_t)gridDim.x * 256) f += ccs[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) f += __shfl_xor(f, d, 64);
+        if ((threadIdx.x & 63) == 0 && f) atomicAdd(&s_log[0], f);
+    }
     const int64_t n = dev_count(n_dev, cap);
     if (i >= n && i < cap) emit[i] = 0;
     int slot = -1, slot2 = -1;     // the counters this record adds to (besides num_sbs, slot 1)
