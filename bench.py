@@ -23,19 +23,24 @@ CHR20_LEN = 64_444_167
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # algorithmic HBM bytes per unit of work, per kernel (DESIGN.md "Kernels and their rooflines")
 STAGE_KERNEL = {"ms_parse": "k_parse_cs", "ms_emit": "k_propose",
-                "ms_capture": "k_stream_capture", "ms_eval": "k_eval_columns"}
+                "ms_capture": "k_stream_capture", "ms_eval": "k_eval_columns"}   # a stage's dominant kernel
 
 
 def algorithmic_bytes(stage, st, cs_bytes):
+    """Bytes the design has to move per launch, from the run's own counts."""
     rb, pos, cand, slots = st["read_bases"], st["positions"], st["n_candidates"], st["column_slots"]
     if stage == "ms_capture":    # every quality byte + every packed base once, one 2-byte slot per pile cell kept
         return rb * 1.5 + slots * 2.0
-    if stage == "ms_parse":      # every quality byte once; cs text in, ~16 B per cs operation out (segments + mismatch list)
-        return rb * 1.0 + cs_bytes * 1.0 + cs_bytes / 4.0 * 16.0
-    if stage == "ms_emit":       # mismatch list in, mask word + candidate out per candidate
-        return cs_bytes / 4.0 * 8.0 + cand * 16.0
+    if stage == "ms_parse":      # cs text in, ~16 B per cs operation out (segments + mismatch list), one bitmap word per mark
+        return cs_bytes * 1.0 + cs_bytes / 4.0 * 16.0
+    if stage == "ms_emit":       # mismatch list in, mask word per candidate; the two sweeps read the position bitmap
+        return cs_bytes / 4.0 * 8.0 + cand * 16.0 + pos / 8.0
     if stage == "ms_eval":       # column slots in, one 64-byte record out
         return slots * 2.0 + cand * 64.0
+    if stage == "ms_index":      # position bitmap in, block table + empty column store out
+        return pos / 8.0 + pos / 256.0 * 16.0 + slots * 2.0
+    if stage == "ms_finalize":   # records in and out, keys in
+        return cand * (64.0 * 2 + 8.0)
     return 0.0
 
 
@@ -52,47 +57,77 @@ def parse():
 
 
 def make_side_sets(sample, seed):
-    """PoN / common-SNP key arrays of the size BASELINE configs[1] describes
-    (common = half the germline SNPs + 1e-4/bp decoys, PoN = 1e-4/bp random)."""
+    from himut_amd import genome
+    return genome.side_sets(sample, seed)
+
+
+def _sub_batch(batch, i0, i1):
+    """Reads i0 .. i1 of a batch as a batch of their own (views: seq / bq / cs stay whole, offsets are absolute)."""
     import numpy as np
-    from himut_amd import caller
-    rs = np.random.RandomState(seed)
-    L = sample.batch.length
-    keep = rs.rand(sample.snp_pos.shape[0]) < 0.5
-    common = [(int(p) + 1, chr(r), chr(a)) for p, r, a in zip(sample.snp_pos[keep], sample.snp_ref[keep], sample.snp_alt[keep])]
-    n_decoy = int(1e-4 * L)
-    pos = rs.randint(1, L + 1, size=2 * n_decoy)
-    ra = rs.randint(0, 4, size=(2 * n_decoy, 2))
-    decoys = [(int(p), "ACGT"[i], "ACGT"[j]) for p, (i, j) in zip(pos, ra) if i != j]
-    h = len(decoys) // 2
-    return caller.site_keys(decoys[:h]), caller.site_keys(common + decoys[h:])
+    from himut_amd.readbatch import ReadBatch
+    return ReadBatch(name=batch.name, length=batch.length, tstart=batch.tstart[i0:i1], tend=batch.tend[i0:i1],
+                     qstart=batch.qstart[i0:i1], qlen=batch.qlen[i0:i1], mapq=batch.mapq[i0:i1], flag=batch.flag[i0:i1],
+                     qid=np.arange(i1 - i0, dtype=np.int32), qoff=batch.qoff[i0:i1], cs_off=batch.cs_off[i0:i1 + 1],
+                     seq=batch.seq, bq=batch.bq, cs=batch.cs, tp=batch.tp[i0:i1])
 
 
 def cpu_baseline(batch, chunks, params, pon, com, sample_mb):
-    """The CPU oracle (a C restatement of the reference algorithm, "port") timed
-    on one host core over a bounded prefix of the same workload."""
+    """The CPU oracle (a C restatement of the reference algorithm, "port") timed on the host: one thread over a bounded
+    prefix of the workload, then one thread per chunk range on every core the process may use over the whole contig
+    (SURVEY 8d(2)).  The reference's own Python figure travels as a constant: the reference cannot run here."""
     import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
-    from himut_amd.readbatch import ReadBatch
+    assert np.array_equal(batch.qid, np.arange(batch.n))      # synthetic reads have unique names
     limit = int(sample_mb * 1e6)
-    sub_chunks = [c for c in chunks if c[1] <= limit]
-    if not sub_chunks:
-        sub_chunks = chunks[:1]
-    end = sub_chunks[-1][1]
-    n = int(np.searchsorted(batch.tstart, end, side="left"))
-    tot = int(batch.qoff[n - 1] + ((int(batch.qlen[n - 1]) + 31) & ~31)) if n else 0
-    sub = ReadBatch(name=batch.name, length=batch.length, tstart=batch.tstart[:n], tend=batch.tend[:n],
-                    qstart=batch.qstart[:n], qlen=batch.qlen[:n], mapq=batch.mapq[:n], flag=batch.flag[:n],
-                    qid=batch.qid[:n], qoff=batch.qoff[:n], cs_off=batch.cs_off[:n + 1], seq=batch.seq[:tot // 2],
-                    bq=batch.bq[:tot], cs=batch.cs[:int(batch.cs_off[n])], tp=batch.tp[:n])
+    sub_chunks = [c for c in chunks if c[1] <= limit] or chunks[:1]
+    n = int(np.searchsorted(batch.tstart, sub_chunks[-1][1], side="left"))
     t0 = time.perf_counter()
-    recs, log = O.call(sub, sub_chunks, params, 1 / (10 ** 3), pon, com)
+    recs, log = O.call(_sub_batch(batch, 0, n), sub_chunks, params, 1 / (10 ** 3), pon, com)
     dt = time.perf_counter() - t0
     span = sum(e - s + 1 for s, e in sub_chunks)
-    return {"value": span / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "port",
-            "sample": "first {} reference chunks ({:.1f} Mb, {} reads) of the same contig, oracle/himut_oracle.c "
-                      "single thread, {:.1f} s; candidate sites/s {:.0f}".format(len(sub_chunks), span / 1e6, n, dt,
-                                                                              log[1] / dt)}
+    out = {"value": span / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "port",
+           "sample": "first {} reference chunks ({:.1f} Mb, {} reads) of the same contig, oracle/himut_oracle.c "
+                     "single thread, {:.1f} s; candidate sites/s {:.0f}".format(len(sub_chunks), span / 1e6, n, dt, log[1] / dt)}
+    # all cores: the contig's chunk list cut into one range per core, one oracle call per thread (ctypes drops the GIL)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64, len(chunks)))
+    cuts = [round(k * len(chunks) / cores) for k in range(cores + 1)]
+
+    def work(k):
+        cs = chunks[cuts[k]:cuts[k + 1]]
+        if not cs:
+            return 0
+        i0 = int(np.searchsorted(batch.tstart, cs[0][0] - 30_000, side="left"))       # reads are <= 25 kb
+        i1 = int(np.searchsorted(batch.tstart, cs[-1][1], side="left"))
+        _r, lg = O.call(_sub_batch(batch, i0, i1), cs, params, 1 / (10 ** 3), pon, com)
+        return lg[1]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as pool:
+        cand = sum(pool.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    span = sum(e - s + 1 for s, e in chunks)
+    out["all_cores"] = {"value": span / 1e6 / dt, "unit": "Mbp/s", "cores": cores, "host_cpu_count": os.cpu_count(),
+                        "kind": "port", "candidate_sites_per_sec": cand / dt,
+                        "sample": "the whole contig ({:.1f} Mb, {} chunks), one oracle thread per chunk range on {} "
+                                  "cores, {:.1f} s".format(span / 1e6, len(chunks), cores, dt)}
+    ref = os.path.join(ROOT, "tests", "golden", "config1_reference.json")
+    if os.path.exists(ref):
+        try:
+            t = json.load(open(ref))
+            if t.get("reference_seconds"):
+                out["reference_python"] = {"value": t["length"] / 1e6 / t["reference_seconds"], "unit": "Mbp/s",
+                                           "cores": 1, "kind": "reference",
+                                           "sample": "sjin09/himut caller.get_somatic_substitutions on BASELINE config 1 "
+                                                     "(1 Mb, 30x), build container, {:.1f} s (tests/golden/"
+                                                     "config1_reference.py); a constant carried here, the reference "
+                                                     "cannot travel to the GPU box".format(t["reference_seconds"])}
+        except Exception:
+            pass
+    return out
 
 
 def main():
@@ -123,10 +158,11 @@ def main():
     names = ["chr{}".format(20 + k) for k in range(world)]   # one chr20-sized contig per rank
     cfg = synth.SynthConfig(seed=2 + rank, contig_len=a.contig_len, depth=a.depth, name=names[rank])
     sample = synth.generate(cfg)
-    batch = sample.batch
+    batch = batch_keep = sample.batch
     chunks = [(c[1], c[2]) for c in hutil.chunkloci((batch.name, 0, batch.length))]
     ql, qu, md = bamlib.get_thresholds({batch.name: batch}, [batch.name], {batch.name: batch.length})
     pon, com = make_side_sets(sample, 100 + rank)
+    cs_bytes = int(batch.cs.shape[0])
     params = dict(min_qv=30, min_mapq=60, qlen_lower_limit=ql, qlen_upper_limit=qu, min_sequence_identity=0.99,
                   min_gq=20, min_bq=93, min_trim=0.01, max_mismatch_count=0, mismatch_window_size=20, md_threshold=md,
                   min_ref_count=3, min_alt_count=1, min_hap_count=3)
@@ -182,7 +218,7 @@ def main():
     for _ in range(a.steps):
         step()
         st = ctx.stats()
-        for k in ("ms_total", "ms_capture"):
+        for k in ("ms_total", "ms_capture", "reran"):
             stage_ms.setdefault(k, []).append(st[k])
     gathered = ex.drain() if ex is not None else None
     barrier()
@@ -206,11 +242,25 @@ def main():
 
     st = ctx.stats()
     log = ctx.log()
+    reran_steps = int(sum(stage_ms.get("reran", [0])))
     totals = torch.tensor([st["positions"], log[1], st["read_bases"], st["n_records"]], dtype=torch.float64,
                           device=red_dev)
     if use_ex:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     positions, cand_sites, read_bases, n_records = [float(x) for x in totals.tolist()]
+
+    # ---- BASELINE configs[2]: the whole synthetic GRCh38, strong scaling (N > 1; HIMUT_BENCH_GENOME=1 forces it on
+    # one rank, HIMUT_BENCH_GENOME_SCALE divides the contig lengths for rehearsals)
+    genome_strong = None
+    if world > 1 or os.environ.get("HIMUT_BENCH_GENOME") == "1":
+        from himut_amd import genome
+        w.close()
+        w = None
+        del sample, batch_keep
+        if world > 1:
+            batch = None          # (only the single-rank run goes on to the CPU baseline, which needs the reads)
+        genome_strong = genome.run_genome(rank, world, local_rank, scale=float(os.environ.get("HIMUT_BENCH_GENOME_SCALE", "1")),
+                                          depth=a.depth, steps=max(1, min(a.steps, 3)), backend=backend)
 
     if rank == 0:
         if gathered is not None:   # every step's exchange delivered every rank's records
@@ -224,20 +274,26 @@ def main():
         timed = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         dom = max(STAGE_KERNEL, key=lambda k: avg[k])           # the dominant kernel of the step
         dom_ms = timed[dom] if dom in timed else avg[dom]       # the column capture: measured inside the timed region
-        cs_bytes = int(batch.cs.shape[0])
         alg_bytes = algorithmic_bytes(dom, st, cs_bytes)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         per_kernel = {STAGE_KERNEL[k]: {"ms": avg[k], "alg_GBps": algorithmic_bytes(k, st, cs_bytes) / (avg[k] * 1e-3) / 1e9}
                       for k in STAGE_KERNEL}
-        traffic = None
+        # HBM traffic from the PMC counters: not collected in this run (counters need their own rocprofv3 passes) but
+        # read from the committed summary of the same workload, profiles/pmc_traffic.json (profiles/collect.sh)
+        traffic, traffic_step, traffic_source = None, None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 t = json.load(open(tp))
                 if t.get("contig_len") == a.contig_len and t.get("depth") == a.depth:
                     traffic = t.get(STAGE_KERNEL[dom])
+                    traffic_step = t.get("step_total")
+                    traffic_source = "profiles/pmc_traffic.json (" + str(t.get("collected", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")) + ")"
             except Exception:
                 traffic = None
+        all_stages = ("ms_parse", "ms_index", "ms_capture", "ms_emit", "ms_eval", "ms_finalize")
+        moved = sum(algorithmic_bytes(k, st, cs_bytes) for k in all_stages)
+        step_s = timed["ms_total"] * 1e-3
         out = {
             "metric": "Mbp scanned/sec at 30x CCS (himut call pileup scan)", "value": mbp_s, "unit": "Mbp/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -256,21 +312,33 @@ def main():
                                               "start / end and the events around k_stream_capture only",
             "kernels": per_kernel,
             "setup_s": {"generate": t_gen, "h2d": t_h2d},
-            # the whole step against the SURVEY's own byte count (3.5 B per read base + 2 B per position +
-            # (1.5 D + 48) B per candidate site), device time of the timed steps
-            "roofline_step": (lambda by: {"bound": "hbm", "achieved": by / (timed["ms_total"] * 1e-3) / 1e9,
-                                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": by / (timed["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                          "algorithmic_bytes_per_step": by, "convention": "SURVEY 8d"})(
-                (read_bases * 3.5 + positions * 2.0 + cand_sites * (1.5 * a.depth + 48.0)) / world),
+            # The whole step, two ways.  "moved": the bytes this design has to move (sum of the per-kernel algorithmic
+            # bytes of DESIGN.md section 4) over the step's device time -- the achieved-bandwidth figure; beside it the
+            # same with the PMC counter bytes of the committed profile.  "survey_convention": the SURVEY's own count
+            # (3.5 B per read base + 2 B per position + (1.5 D + 48) B per candidate site), which prices
+            # a dense two-pass pile this design does not build: a throughput in the survey's unit, not a bandwidth.
+            "roofline_step": {
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "device_ms": timed["ms_total"],
+                "moved": {"bytes_per_step": moved, "achieved": moved / step_s / 1e9, "frac": moved / step_s / 1e9 / HBM_PEAK_GBS,
+                          "counter_bytes_per_step": traffic_step,
+                          "counter_frac": (traffic_step / step_s / 1e9 / HBM_PEAK_GBS) if traffic_step else None},
+                "survey_convention": (lambda by: {"bytes_per_step": by, "achieved": by / step_s / 1e9,
+                                                  "frac": by / step_s / 1e9 / HBM_PEAK_GBS})(
+                    (read_bases * 3.5 + positions * 2.0 + cand_sites * (1.5 * a.depth + 48.0)) / world)},
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
+            # steps of the timed region in which himut_run repeated itself with exact buffer sizes (a count exceeded the
+            # capacities kept from the run before): 0 expected after the warm-up
+            "reran_steps": reran_steps,
         }
+        if genome_strong is not None:
+            out["genome_strong"] = genome_strong
         if not a.no_cpu_baseline and world == 1:           # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(batch, chunks, params, pon, com, a.cpu_sample_mb)
         print(json.dumps(out), flush=True)
-    w.close()
+    if w is not None:
+        w.close()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -67,19 +67,45 @@ def broadcast_ints(values, src=0):
     return [int(x) for x in t.tolist()]
 
 
+def _gather_device():
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _p2p(ops):
+    """Starts a batch of point-to-point transfers (each peer talks to rank 0 over its own xGMI link: no ring, no
+    padding to a common size); returns the requests."""
+    import torch.distributed as dist
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def _wait_all(reqs, dev):
+    for r in reqs:
+        r.wait()
+    if dev.type == "cuda":
+        # on RCCL wait() orders torch's current stream only; the library copies into / out of these buffers on a
+        # stream of its own, so the host itself has to see the transfers finished
+        import torch
+        torch.cuda.current_stream().synchronize()
+
+
 def gather_contig_results(local, contig_names, rank, world, device_buffers=None, materialize=True):
     """local: {contig: (records structured array, log list of 15)} for the
     contigs this rank scanned.  ``device_buffers``: optional {contig:
     (ctx, n_records)} to copy records device-to-device instead of from the host
     array (nccl path).  Returns on rank 0 {contig: (records, log)} for every
     contig, in natural contig order; None elsewhere.  With ``materialize=False`` rank 0
-    gets the raw (table, per-rank buffers) still on the gather device (no host copy)."""
+    gets the raw (table, per-rank buffers) still on the gather device (no host copy).
+
+    One small all-reduce tells every rank the record count and the counters of every contig; then each rank sends
+    its records -- its contigs back to back in natural order, exactly as many bytes as it has -- straight to rank 0
+    (``isend`` / ``irecv``; RCCL has no gatherv, and a padded gather would move world x the largest share)."""
     import torch
     import torch.distributed as dist
     names = natsorted(list(contig_names))
     index = {c: i for i, c in enumerate(names)}
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _gather_device()
     # 1. per contig: owner's record count and counters (all-reduce of a table that is zero elsewhere)
     table = torch.zeros((len(names), 17), dtype=torch.int64, device=dev)
     for c, (recs, log) in local.items():
@@ -92,9 +118,8 @@ def gather_contig_results(local, contig_names, rank, world, device_buffers=None,
     per_rank = [0] * world
     for i in range(len(names)):
         per_rank[int(tab[i, 1])] += int(tab[i, 0])
-    cap = max(max(per_rank), 1)
-    # 2. one fixed-size send per rank: its contigs' records back to back, in natural order
-    send = torch.zeros(cap * REC, dtype=torch.uint8, device=dev)
+    # 2. this rank's records back to back, in natural contig order
+    send = torch.zeros(max(per_rank[rank], 1) * REC, dtype=torch.uint8, device=dev)
     if dev.type == "cuda":
         # the library copies into `send` on its own stream: the zero fill (torch's stream) must be done first
         torch.cuda.current_stream().synchronize()
@@ -112,10 +137,13 @@ def gather_contig_results(local, contig_names, rank, world, device_buffers=None,
             raw = np.ascontiguousarray(local[c][0]).view(np.uint8).reshape(-1)
             send[off * REC:(off + n) * REC] = torch.from_numpy(raw.copy()).to(dev)
         off += n
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-    dist.gather(send, recv, dst=0)
+    # 3. exact-size transfers to rank 0
     if rank != 0:
+        if per_rank[rank]:
+            _wait_all(_p2p([dist.P2POp(dist.isend, send[:per_rank[rank] * REC], 0)]), dev)
         return None
+    recv = [send] + [torch.empty(max(per_rank[r], 1) * REC, dtype=torch.uint8, device=dev) for r in range(1, world)]
+    _wait_all(_p2p([dist.P2POp(dist.irecv, recv[r][:per_rank[r] * REC], r) for r in range(1, world) if per_rank[r]]), dev)
     if not materialize:
         return tab, recv
     out = {}
@@ -131,72 +159,118 @@ def gather_contig_results(local, contig_names, rank, world, device_buffers=None,
 
 
 class RecordExchange:
-    """The same final exchange, pipelined: the gather of one contig's records to rank 0 runs while the next
-    contig is scanned.  Every rank sends a fixed-size buffer per submit (``cap_records`` records, agreed once
-    with ``plan``), `depth` of them in flight; the record counts and the 15 counters travel in one small
-    all-gather when the exchange is drained."""
+    """The same final exchange, pipelined: the records of one finished contig travel to rank 0 while the next
+    contig is scanned.  A run is a sequence of ROUNDS (round k = the k-th contig of every rank; a rank with fewer
+    contigs sends nothing in the later rounds).  The sizes are agreed once (``plan``: per round and rank the record
+    count of a rehearsal pass + 25 %), so every transfer is a point-to-point message of its own size from the
+    owner to rank 0 -- each peer on its own xGMI link, nothing padded to the largest share.  ``depth`` passes over
+    the rounds may be in flight (buffers per round and pass); the record counts and the 15 counters travel in one
+    small all-gather when the exchange is drained."""
 
-    def __init__(self, rank, world, cap_records, depth=2):
+    def __init__(self, rank, world, caps, depth=2, keep=False):
         import torch
         import torch.distributed as dist
-        self.rank, self.world, self.cap, self.depth = rank, world, int(cap_records), depth
-        backend = dist.get_backend()
-        self.dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        self.send = [torch.zeros(self.cap * REC, dtype=torch.uint8, device=self.dev) for _ in range(depth)]
-        self.recv = [[torch.empty_like(self.send[0]) for _ in range(world)] for _ in range(depth)] if rank == 0 else None
+        if isinstance(caps, (int, np.integer)):
+            caps = [[int(caps)] * world]
+        self.rank, self.world, self.depth = rank, world, depth
+        self.caps = [[int(x) for x in row] for row in caps]
+        self.rounds = len(self.caps)
+        self.dev = _gather_device()
+        nslot = self.rounds * depth
+        mk = lambda n: torch.zeros(max(int(n), 1) * REC, dtype=torch.uint8, device=self.dev)
+        # slot s serves round s % rounds.  Rank 0 keeps one landing buffer per slot and rank (its own records are
+        # copied straight there); the others keep one send buffer per slot
+        if rank == 0:
+            self.recv = [[mk(self.caps[s % self.rounds][r]) for r in range(world)] for s in range(nslot)]
+            self.send = None
+        else:
+            self.recv = None
+            self.send = [mk(self.caps[s % self.rounds][rank]) for s in range(nslot)]
         if self.dev.type == "cuda":
             torch.cuda.current_stream().synchronize()     # the zero fills are done before the library writes
-        self.handles = [None] * depth
+        self.reqs = [[] for _ in range(nslot)]
         self.meta = []          # per submit: [n, log[15]]
         self.k = 0
-        # one untimed gather brings the point-to-point channels up (RCCL sets them up on first use)
-        dist.gather(self.send[0], self.recv[0] if rank == 0 else None, dst=0)
-        if self.dev.type == "cuda":
-            torch.cuda.synchronize()
+        self.keep = keep        # rank 0: host copies of every completed submit in self.kept[k][rank] (tests)
+        self.kept = {}
+        self._pending = {}      # slot -> submit index whose transfers are in flight
+        # one untimed transfer per peer brings the point-to-point channels up (RCCL sets them up on first use)
+        tiny = torch.zeros(REC, dtype=torch.uint8, device=self.dev)
+        if rank == 0:
+            warm = [torch.empty_like(tiny) for _ in range(world)]
+            _wait_all(_p2p([dist.P2POp(dist.irecv, warm[r], r) for r in range(1, world)]), self.dev)
+        else:
+            _wait_all(_p2p([dist.P2POp(dist.isend, tiny, 0)]), self.dev)
 
     @staticmethod
     def plan(n_local):
-        """Collective: the capacity every rank must use = the largest record count of any rank (+25 %)."""
+        """Collective.  ``n_local``: this rank's record count per round (a list; an int = one round).  Returns the
+        capacities [round][rank] every rank must construct the exchange with (count + 25 %)."""
         import torch
         import torch.distributed as dist
-        backend = dist.get_backend()
-        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return int(t.item()) * 5 // 4 + 64
+        dev = _gather_device()
+        mine = [int(n_local)] if isinstance(n_local, (int, np.integer)) else [int(x) for x in n_local]
+        world = dist.get_world_size()
+        r = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        rounds = max(int(r.item()), 1)
+        t = torch.zeros(rounds, dtype=torch.int64, device=dev)
+        if mine:
+            t[:len(mine)] = torch.tensor(mine, dtype=torch.int64)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        cnt = np.stack([x.cpu().numpy() for x in allt], axis=1)         # [round][rank]
+        return [[int(n) * 5 // 4 + 64 if n > 0 else 0 for n in row] for row in cnt]
+
+    def _finish(self, slot):
+        if not self.reqs[slot] and slot not in self._pending:
+            return
+        _wait_all(self.reqs[slot], self.dev)
+        self.reqs[slot] = []
+        k = self._pending.pop(slot, None)
+        if self.keep and self.rank == 0 and k is not None:
+            # counts of the peers are not known before drain(): keep the whole landing buffers
+            self.kept[k] = [t.cpu().numpy().copy() for t in self.recv[slot]]
 
     def submit(self, n, log, ctx=None, records=None):
-        """Records of one finished contig: from the context's device buffer (ctx) or from a host array."""
+        """Records of one finished contig (this rank's contig of the current round; n = 0 with nothing to send):
+        from the context's device buffer (ctx) or from a host array."""
         import torch
         import torch.distributed as dist
-        if n > self.cap:
-            raise ValueError("RecordExchange: {} records exceed the planned capacity {}".format(n, self.cap))
-        slot = self.k % self.depth
-        if self.handles[slot] is not None:
-            self.handles[slot].wait()
+        rnd = self.k % self.rounds
+        slot = self.k % (self.rounds * self.depth)
+        cap = self.caps[rnd][self.rank]
+        if n > cap:
+            raise ValueError("RecordExchange: {} records exceed the planned capacity {}".format(n, cap))
+        self._finish(slot)          # the transfers that last used this slot's buffers are over
+        dst = self.recv[slot][0] if self.rank == 0 else self.send[slot]
         if n:
             if ctx is not None:
-                ctx.copy_records_to_device(self.send[slot].data_ptr(), self.cap)
+                ctx.copy_records_to_device(dst.data_ptr(), cap)
             else:
                 raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
-                self.send[slot][:n * REC] = torch.from_numpy(raw.copy()).to(self.dev)
-        self.handles[slot] = dist.gather(self.send[slot], self.recv[slot] if self.rank == 0 else None, dst=0,
-                                         async_op=True)
+                dst[:n * REC] = torch.from_numpy(raw.copy()).to(self.dev)
+                if self.dev.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
+        if self.rank == 0:
+            ops = [dist.P2POp(dist.irecv, self.recv[slot][r][:self.caps[rnd][r] * REC], r)
+                   for r in range(1, self.world) if self.caps[rnd][r] > 0]
+        else:
+            ops = [dist.P2POp(dist.isend, dst[:cap * REC], 0)] if cap > 0 else []
+        self.reqs[slot] = _p2p(ops)
+        self._pending[slot] = self.k
         self.meta.append([int(n)] + [int(x) for x in log])
         self.k += 1
 
     def drain(self, materialize_last=False):
-        """Waits for every gather in flight and exchanges the per-submit counts.  Rank 0 gets
+        """Waits for every transfer in flight and exchanges the per-submit counts.  Rank 0 gets
         (counts[world][submits][16], last) where ``last`` is {rank: records array} of the last submit when
         ``materialize_last``; other ranks get None."""
         import torch
         import torch.distributed as dist
-        for h in self.handles:
-            if h is not None:
-                h.wait()
-        self.handles = [None] * self.depth
-        if self.dev.type == "cuda":
-            torch.cuda.synchronize()
+        for slot in range(len(self.reqs)):
+            self._finish(slot)
+        # every rank has made the same number of submits (a collective sequence), so the tables have one shape
         m = torch.tensor(self.meta if self.meta else [[0] * 16], dtype=torch.int64, device=self.dev)
         allm = [torch.empty_like(m) for _ in range(self.world)]
         dist.all_gather(allm, m)
@@ -206,11 +280,19 @@ class RecordExchange:
         last = self.last_records(counts) if materialize_last else None
         return counts, last
 
+    def records_of(self, counts, k):
+        """Rank 0, with keep=True: {rank: records array} of submit k."""
+        out = {}
+        for r in range(self.world):
+            n = int(counts[r][k][0])
+            out[r] = self.kept[k][r][:n * REC].view(RECORD_DTYPE).copy()
+        return out
+
     def last_records(self, counts):
         """Rank 0: {rank: records array} of the last submit (host copy)."""
         if self.rank != 0 or self.k == 0:
             return None
-        slot = (self.k - 1) % self.depth
+        slot = (self.k - 1) % (self.rounds * self.depth)
         last = {}
         for r in range(self.world):
             n = int(counts[r][-1][0])

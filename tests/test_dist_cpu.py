@@ -38,19 +38,55 @@ if rank == 0:
         assert np.array_equal(recs, want), c
         assert log == wlog, c
     print("GATHER_OK", json.dumps(assign))
-# the pipelined exchange: three "contigs" per rank, two gathers in flight
-mine = [fake(c) for c in (["chr1", "chr10", "chrX"] if rank == 0 else ["chr2", "chrM", "chr10"])]
-cap = hdist.RecordExchange.plan(max(len(r) for r, _ in mine))
-ex = hdist.RecordExchange(rank, world, cap, depth=2)
-for recs, log in mine:
-    ex.submit(len(recs), log, records=recs)
+# the pipelined exchange: rounds of one "contig" per rank (rank 1 has one fewer), sizes planned per round and rank,
+# three passes over the rounds with two in flight; the contents of EVERY submit are checked, not only the counts
+names = ["chr1", "chr10", "chrX"] if rank == 0 else ["chr2", "chr10"]
+other = ["chr2", "chr10"] if rank == 0 else ["chr1", "chr10", "chrX"]
+mine = [fake(c) for c in names]
+caps = hdist.RecordExchange.plan([len(r) for r, _ in mine])
+assert len(caps) == 3 and all(len(row) == world for row in caps) and caps[2][1] == 0, caps
+ex = hdist.RecordExchange(rank, world, caps, depth=2, keep=True)
+PASSES = 3
+for p in range(PASSES):
+    for k in range(3):
+        if k < len(mine):
+            recs, log = mine[k]
+            recs = recs.copy(); recs["gq"] += p               # every pass sends different bytes
+            ex.submit(len(recs), log, records=recs)
+        else:
+            ex.submit(0, [0] * 15, records=None)
 out = ex.drain(materialize_last=True)
 if rank == 0:
     counts, last = out
-    assert [int(x[0]) for x in counts[0]] == [9, 4, 3] and [int(x[0]) for x in counts[1]] == [5, 0, 4]
+    assert [int(x[0]) for x in counts[0]] == [9, 4, 3] * PASSES and [int(x[0]) for x in counts[1]] == [5, 4, 0] * PASSES
     assert [int(v) for v in counts[1][0][1:]] == fake("chr2")[1]
-    assert np.array_equal(last[0], fake("chrX")[0]) and np.array_equal(last[1], fake("chr10")[0])
-    print("EXCHANGE_OK")
+    for p in range(PASSES):
+        for k in range(3):
+            got = ex.records_of(counts, p * 3 + k)
+            want0 = fake(names[k])[0]; want0["gq"] += p
+            assert np.array_equal(got[0], want0), (p, k)
+            if k < 2:
+                want1 = fake(other[k])[0]; want1["gq"] += p
+                assert np.array_equal(got[1], want1), (p, k)
+            else:
+                assert len(got[1]) == 0
+    assert np.array_equal(last[0]["tpos"], fake("chrX")[0]["tpos"]) and len(last[1]) == 0
+    # the one-round form the weak-scaling bench uses (an int capacity for every rank)
+print("EXCHANGE_OK" if rank == 0 else "")
+ex1 = hdist.RecordExchange(rank, world, hdist.RecordExchange.plan(9)[0][0], depth=2, keep=True)
+for p in range(4):
+    recs, log = fake("chr1" if rank == 0 else "chr2")
+    recs["gq"] += p
+    ex1.submit(len(recs), log, records=recs)
+out = ex1.drain()
+if rank == 0:
+    counts, _ = out
+    for p in range(4):
+        got = ex1.records_of(counts, p)
+        w0 = fake("chr1")[0]; w0["gq"] += p
+        w1 = fake("chr2")[0]; w1["gq"] += p
+        assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), p
+    print("EXCHANGE1_OK")
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -78,4 +114,4 @@ def test_gather_world_size_2_gloo(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    assert "GATHER_OK" in outs[0] and "EXCHANGE_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "EXCHANGE_OK" in outs[0] and "EXCHANGE1_OK" in outs[0], outs[0]
