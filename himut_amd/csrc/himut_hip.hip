@@ -97,7 +97,7 @@ struct himut_ctx {
     bool unique_qnames = true, any_longcs = false;
     DevBuf d_tstart, d_tend, d_qstart, d_qlen, d_mapq, d_flag, d_qid, d_qoff, d_csoff, d_seq, d_bq, d_cs, d_prefmax;
     // derived
-    DevBuf d_bqsum, d_nseg, d_nmis, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs, d_order;
+    DevBuf d_bqsum, d_nseg, d_nmis, d_nnsub, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs, d_order;
     // run state
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2, d_logpart;
@@ -190,7 +190,7 @@ Derived make_derived(himut_ctx* c) {
     Derived D;
     D.bqsum = c->d_bqsum.as<uint32_t>(); D.nseg = c->d_nseg.as<int32_t>(); D.nmis = c->d_nmis.as<int32_t>();
     D.segs = c->d_segs.as<Seg>(); D.mis = c->d_mis.as<int32_t>(); D.mq = c->d_mq.as<uint32_t>();
-    D.rflag = c->d_rflag.as<uint8_t>(); D.meta = c->d_meta.as<ReadMeta>();
+    D.rflag = c->d_rflag.as<uint8_t>(); D.meta = c->d_meta.as<ReadMeta>(); D.nnsub = c->d_nnsub.as<int32_t>();
     return D;
 }
 
@@ -357,6 +357,7 @@ void alloc_derived(himut_ctx* c) {
     c->d_bqsum.reserve((size_t)n * 4 + 64);
     c->d_nseg.reserve((size_t)n * 4 + 64);
     c->d_nmis.reserve((size_t)n * 4 + 64);
+    c->d_nnsub.reserve((size_t)n * 4 + 64);
     c->d_segs.reserve((size_t)segcap * sizeof(Seg));
     c->d_mis.reserve((size_t)segcap * 4);
     c->d_mq.reserve((size_t)segcap * 4);
@@ -385,8 +386,6 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     if (phase && !c->have_phase) return fail(c, HIMUT_ERR_ARG, "phase requested but himut_set_phase has not been called");
     if (phase && (int64_t)c->h_phoff.size() != (int64_t)c->cstart.size() + 1)
         return fail(c, HIMUT_ERR_ARG, "himut_set_phase chunk count differs from himut_set_chunks");
-    if (phase && !c->unique_qnames)
-        return fail(c, HIMUT_ERR_ARG, "phase mode needs unique query names (filter the BAM with -F 0x900 as the reference's README asks)");
     for (size_t k = 0; k < c->cstart.size(); k++)
         if (c->cstart[k] > c->cend[k]) return fail(c, HIMUT_ERR_CHUNK, "ValueError: invalid coordinates: chunk start > end");
     HCHECK(hipSetDevice(c->device));

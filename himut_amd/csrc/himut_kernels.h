@@ -99,6 +99,8 @@ struct Derived {
     uint32_t* mq;    // same base; per mismatch: qpos << 5 | (substitution ? 16 | ref << 2 | alt : 0)
     uint8_t* rflag;
     struct ReadMeta* meta;
+    int32_t* nnsub;  // substitutions whose reference base is N (cslib.py:54-56 keeps them out of the mismatch list): their
+                     // query offsets sit in mq[] from the TOP of the read's slots downwards, mq[top - k] = qpos << 5 | 8
 };
 
 // everything a pile row needs about its read, in one 32-byte load
@@ -384,7 +386,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     if (uni((int)R.flag[r]) & 0x100) {  // bamlib.py:17
         if (lane == 0) {
             M.flags = RF_SECONDARY;
-            D.rflag[r] = RF_SECONDARY; D.nseg[r] = 0; D.nmis[r] = 0; D.meta[r] = M;
+            D.rflag[r] = RF_SECONDARY; D.nseg[r] = 0; D.nmis[r] = 0; D.nnsub[r] = 0; D.meta[r] = M;
         }
         return;
     }
@@ -398,6 +400,8 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     const int32_t qlen = uni(R.qlen[r]);
     int32_t* marks = s_mark[wv];
     int nmark = 0;
+    int nN = 0;                                                          // substitutions with an N reference base
+    const int64_t top = (uni(R.cs_off[r + 1]) >> 1) - (cs0 >> 1);        // the read's last slot (an operation takes >= 2 bytes)
     const bool mark = posbits != nullptr && !(uni((int)R.mapq[r]) < P.p.min_mapq) &&
                       (P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit);       // caller.py:312-317
     auto flush_marks = [&]() {
@@ -563,6 +567,17 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
                 mis[w] = tk + 1;
                 mq[w] = sub ? (((uint32_t)qk << 5) | 16u | ((uint32_t)(ra & 3) << 2) | (uint32_t)(aa & 3)) : ((uint32_t)qk << 5);
             }
+            {   // a substitution whose reference base is N: no mismatch entry, but normcounts counts its base
+                const bool nsb = sub && ref == 'N';
+                const unsigned long long nb = __ballot(nsb);
+                if (nb) {
+                    if (nsb) {
+                        const int64_t k = nN + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nb, 0u));
+                        mq[top - k] = ((uint32_t)qk << 5) | 8u;
+                    }
+                    nN += __popcll(nb);
+                }
+            }
             if (mark) {
                 const bool mk = sub && ref != 'N';
                 const unsigned long long mb = __ballot(mk);
@@ -634,6 +649,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
         M.nseg = ns; M.flags = fl;
         D.nseg[r] = ns;
         D.nmis[r] = nm;
+        D.nnsub[r] = bad ? 0 : nN;
         D.rflag[r] = fl;
         D.meta[r] = M;
     }
@@ -1745,6 +1761,36 @@ __global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
             else if (!((int64_t)ref_count >= A.P.p.min_ref_count && (int64_t)alt_count >= A.P.p.min_alt_count)) status = HIMUT_ST_LOWDEPTH;
             else if ((int64_t)depth > A.P.p.md_threshold) status = HIMUT_ST_HIGHDEPTH;
             else if (PHASE) {  // caller.py:552-603 (unique query names: the voters are the pile's own rows)
+                if (!A.P.unique_qnames) {
+                    // Alignments that share a query name (supplementary alignments: the README asks for -F 0x900, the
+                    // reference does not insist).  The vote goes by NAME: every alignment over the base behind the
+                    // candidate (fetch(chrom, tpos, tpos + 1), caller.py:558) whose name is among the names of the
+                    // column's reference-allele reads votes with ITS haplotype, else one whose name is among the
+                    // alternative-allele reads' names gives its haplotype to the candidate.
+                    h0_ref = h1_ref = som0 = som1 = 0;
+                    const int32_t p1 = rpos + 1;
+                    const BlockTab b1 = A.X.bt[min((int64_t)(p1 >> 8), A.X.nblk - 1)];
+                    const uint32_t n1 = b1.ncnt & BT_N_MASK;
+                    for (uint32_t jj = 0; jj < n1; jj++) {
+                        const int64_t jr = (int64_t)b1.lo + jj;
+                        if (!(A.R.tstart[jr] <= p1 && A.R.tend[jr] > p1) || (A.D.rflag[jr] & RF_SECONDARY)) continue;
+                        const int32_t qj = A.R.qid[jr];
+                        bool in_wt = false, in_alt = false;
+                        for (uint32_t i = 0; i < n; i++) {
+                            const uint32_t v = (uint32_t)col[(int64_t)i * stride];
+                            const int cv = (int)(v & 7u);
+                            if ((v & 15u) == CELL_EMPTY || (cv != ref && cv != alt)) continue;
+                            if (edge && !(A.R.tend[lo + (int32_t)i] > cs_)) continue;      // not fetched by this chunk
+                            if (A.R.qid[lo + (int32_t)i] != qj) continue;
+                            if (cv == ref) in_wt = true; else in_alt = true;
+                        }
+                        if (!in_wt && !in_alt) continue;
+                        uint32_t hp = HAP_NONE;       // an alignment the chunk did not fetch spans none of its hetSNPs
+                        if (jr >= A.C.rlo[chunk] && jr < A.C.rhi[chunk]) hp = A.H.hap[A.C.pairoff[chunk] + (jr - A.C.rlo[chunk])];
+                        if (in_wt) { if (hp == HAP_0) h0_ref++; else if (hp == HAP_1) h1_ref++; }
+                        else { if (hp == HAP_0) som0 = 1; else if (hp == HAP_1) som1 = 1; }
+                    }
+                }
                 if ((int64_t)h0_ref >= A.P.p.min_hap_count && (int64_t)h1_ref >= A.P.p.min_hap_count && (som0 + som1) == 1) {
                     status = HIMUT_ST_PASS; ps = cs_;
                 } else status = HIMUT_ST_UNPHASED;

@@ -105,6 +105,11 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
     for (int k = lane; k < min(nm, CAL_NM); k += 64) { lmis[k] = gmis[k]; lmq[k] = gmq[k]; }
     if (lane < min(ns, 64)) lseg[lane] = *reinterpret_cast<const int4*>(gsegs + lane);
     __builtin_amdgcn_wave_barrier();
+    // substitutions with an N reference base (rare): not in the mismatch list, their bases always count, and each one
+    // starts a new match operation behind it (normcounts.py:75-110 walks the cs operations).  Query offsets, ascending.
+    const int nN = uni(D.nnsub[r]);
+    const int64_t top = (uni(R.cs_off[r + 1]) >> 1) - (uni(R.cs_off[r]) >> 1);
+    auto NQ = [&](int k) -> int32_t { return (int32_t)(gmq[top - k] >> 5); };
     auto MIS = [&](int k) -> int32_t { return k < CAL_NM ? lmis[k] : gmis[k]; };
     auto MQ = [&](int k) -> uint32_t { return k < CAL_NM ? lmq[k] : gmq[k]; };
     auto SEG = [&](int j) -> int4 { return j < 64 ? lseg[j] : *reinterpret_cast<const int4*>(gsegs + j); };
@@ -145,10 +150,17 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                 const int32_t a = max(sg.y, qa), b = min(sg.y + sg.z, qa + 32);     // query overlap
                 if (a >= b) continue;
                 const int32_t tlo = sg.x + (a - sg.y), thi = sg.x + (b - 1 - sg.y);  // 0-based reference positions
+                uint32_t nsub_bits = 0;      // N-reference substitutions among these bases; the last one in front of them
+                int32_t nsub_prev = -1;
+                for (int k = 0; k < nN; k++) {
+                    const int32_t q = NQ(k);
+                    if (q >= a && q < b) nsub_bits |= 1u << (q - qa);
+                    else if (q >= sg.y && q < a) nsub_prev = q;
+                }
                 // any list entry that could fall into a window of these bases?
                 const int k0 = lower(tlo - 2 * w - 1);
                 if (k0 >= nm || MIS(k0) > thi + 2 * w + 1) {
-                    word |= okq & (((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa));
+                    word |= (okq & (((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa))) | nsub_bits;
                     continue;
                 }
                 // the few entries near these bases, in registers (value, query offset | substitution flag)
@@ -172,6 +184,7 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                         const int32_t pq = (int32_t)(pv >> 5);
                         if ((pv & 16u) && pq >= sg.y && pq < a) osq = pq + 1;
                     }
+                    if (nsub_prev >= 0) osq = max(osq, nsub_prev + 1);
                 }
                 // Away from the read's ends every match operation has the window (w, w), so "how many entries see
                 // this base" is a sum of bit ranges: bit-sliced counters instead of a loop over the bases.
@@ -203,7 +216,7 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                             same &= ~(planes[pbit] ^ kb);
                         }
                     }
-                    word |= span & ((okq & ~gt) | sub);
+                    word |= (span & ((okq & ~gt) | sub)) | nsub_bits;
                     continue;
                 }
                 for (int32_t q = a; q < b; q++) {
@@ -214,7 +227,7 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                     for (int i = 0; i < NE; i++) if (ev[i] == t + 1 && (eq[i] & 16u) && (int32_t)(eq[i] >> 5) == q) is_sub = true;
                     if (overflow && !is_sub)
                         for (int kk = lower(t + 1); kk < nm && MIS(kk) == t + 1; kk++) { const uint32_t v = MQ(kk); if ((v & 16u) && (int32_t)(v >> 5) == q) is_sub = true; }
-                    if (is_sub) { word |= 1u << bit; osq = q + 1; continue; }
+                    if (is_sub || ((nsub_bits >> bit) & 1u)) { word |= 1u << bit; osq = q + 1; continue; }
                     int64_t qs = (int64_t)osq - w, qe = (int64_t)osq + w, ur, dr;      // bamlib.py:245-258
                     if (qs < 0) { ur = w + qs; dr = w - qs; }
                     else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - osq; }

@@ -135,11 +135,14 @@ def worker_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, phase_bl
 
 
 def norm_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, overrides=None, md_threshold=None,
-              qlen_limits=None, mutate_ref=None, non_human_sample=False, phase_block=0):
+              qlen_limits=None, mutate_ref=None, non_human_sample=False, phase_block=0, mutate_batch=None,
+              both_sets_at_multiallelic=False, do_save=True):
     """normcounts.get_callable_tricounts (non-phased) on a synthetic contig + its reference sequence."""
     ref = H.load_reference()
     s = synth.generate(cfg, want_ref=True)
     b = s.batch
+    if mutate_batch is not None:
+        mutate_batch(b)
     seq = bytes(s.ref).decode()
     if mutate_ref is not None:
         seq = mutate_ref(seq)
@@ -163,8 +166,26 @@ def norm_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, overrides=
         # sites where some read carries a non-reference base: candidates of the call worker seed the side files
         recs0, _ = H.run_reference_worker(bam, b.name, chunks, ql, qu, md, **(overrides or {}))
         hits = [(r[1], r[2], r[3]) for r in recs0 if len(r[3]) == 1]
-        synth.write_common_snps_vcf(common, s, seed=cfg.seed, extra_sites=hits[3::4])
-        synth.write_pon_vcf(pon, s, seed=cfg.seed, extra_sites=hits[::5])
+        extra_com, extra_pon = hits[3::4], hits[::5]
+        if both_sets_at_multiallelic:
+            # positions where the pile shows two alternative alleles: one goes to the panel of normals, the other to
+            # the common SNPs, so which filter counts the position (normcounts.py:367-383: the first alternative with
+            # reads, in the order python iterates set("ATGC").difference(ref)) depends on the interpreter's hash seed
+            from collections import defaultdict
+            by_pos = defaultdict(list)
+            for (p_, r_, a_) in hits:
+                by_pos[(p_, r_)].append(a_)
+            multi = sorted(k for k, v in by_pos.items() if len(set(v)) >= 2)
+            extra_com, extra_pon = [], []
+            for n_, (p_, r_) in enumerate(multi):
+                a1, a2 = sorted(set(by_pos[(p_, r_)]))[:2]
+                if n_ % 2:
+                    a1, a2 = a2, a1
+                extra_pon.append((p_, r_, a1))
+                extra_com.append((p_, r_, a2))
+            exp["multiallelic_positions"] = len(multi)
+        synth.write_common_snps_vcf(common, s, seed=cfg.seed, extra_sites=extra_com)
+        synth.write_pon_vcf(pon, s, seed=cfg.seed, extra_sites=extra_pon)
         exp["common_set"] = sorted([list(t) for t in ref.vcflib.load_common_snp(b.name, common)])
         exp["pon_set"] = sorted([list(t) for t in ref.vcflib.load_pon(b.name, pon)])
     phase_sets = None
@@ -185,7 +206,70 @@ def norm_case(case, cfg, chunks=None, tmpdir="/tmp", with_sets=False, overrides=
     exp["log"] = [int(x) for x in log]
     exp["alt_order"] = order
     print("   ", case, exp["log"], "keys", len(ccs))
-    save(case, exp, batch=b, extra_npz={"refseq": np.frombuffer(seq.encode("ascii"), np.uint8)})
+    if do_save:
+        save(case, exp, batch=b, extra_npz={"refseq": np.frombuffer(seq.encode("ascii"), np.uint8)})
+    exp["_batch"], exp["_seq"] = b, seq
+    return exp
+
+
+def nsub_batch(b, every=3):
+    """Rewrites the cs tags of every ``every``-th read so that its substitutions name the reference base as 'n'
+    (minimap2 writes that where the reference has an N): cslib.cs2subindel keeps such a substitution out of the
+    mismatch list (cslib.py:54-56) while update_tri2count still counts its base unconditionally (normcounts.py:97-109)."""
+    cs = b.cs
+    for r in range(0, b.n, every):
+        a, z = int(b.cs_off[r]), int(b.cs_off[r + 1])
+        seg = cs[a:z]
+        star = np.nonzero(seg == ord("*"))[0]
+        seg[star + 1] = ord("n")
+
+
+def dup_names_batch(b, every=7):
+    """Gives every ``every``-th read the query name of the read before it (a supplementary alignment, flag 0x800): the
+    phased vote of caller.py:552-603 goes by query NAME."""
+    for r in range(1, b.n, every):
+        b.qid[r] = b.qid[r - 1]
+        b.flag[r] |= 0x800
+
+
+def norm_order_case(tmpdir="/tmp"):
+    """normcounts where the panel of normals and the common SNPs both hold an alternative allele of the same
+    position, run under two PYTHONHASHSEED values: the two interpreters iterate set("ATGC").difference(ref) in
+    different orders, and the fixture keeps the expected outcome of each."""
+    import subprocess
+    variants = []
+    base = None
+    for seed in ("1", "2", "3", "4", "5", "6"):
+        out = os.path.join(tmpdir, "norm_order.{}.json".format(seed))
+        env = dict(os.environ, PYTHONHASHSEED=seed, HIMUT_GOLDEN_PART=out)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "norm_order_part"], env=env)
+        part = json.load(open(out))
+        if base is None:
+            base = part
+        key = json.dumps(part["alt_order"], sort_keys=True)
+        if all(json.dumps(v["alt_order"], sort_keys=True) != key for v in variants):
+            variants.append({k: part[k] for k in ("alt_order", "log", "ccs_tri2count", "ref_tri2count", "hashseed")})
+    assert len(variants) >= 2, "every hash seed tried gave the same set order"
+    pon_pop = {(v["log"][11], v["log"][12]) for v in variants}
+    assert len(pon_pop) >= 2, "the order never decided PoN vs common: " + str(pon_pop)
+    exp = {k: v for k, v in base.items() if k not in ("alt_order", "log", "ccs_tri2count", "ref_tri2count", "hashseed")}
+    exp["variants"] = variants
+    # inputs: regenerate in this process (identical: the generator is seeded)
+    full = norm_order_part(do_save=False)
+    save("norm_order", exp, batch=full["_batch"], extra_npz={"refseq": np.frombuffer(full["_seq"].encode("ascii"), np.uint8)})
+
+
+def norm_order_part(do_save=True):
+    exp = norm_case("norm_order", small_cfg(206, contig_len=20000, depth=70.0, name="chrD", som_rate=1e-3, snp_rate=4e-3,
+                                            sub_rate=2e-3, ins_rate=5e-4, del_rate=5e-4),
+                    with_sets=True, md_threshold=200, both_sets_at_multiallelic=True, do_save=False,
+                    overrides=dict(min_bq=40, min_gq=10, max_mismatch_count=2, mismatch_window_size=15, min_ref_count=2,
+                                   min_alt_count=1, min_sequence_identity=0.95))
+    exp["hashseed"] = os.environ.get("PYTHONHASHSEED", "")
+    part = os.environ.get("HIMUT_GOLDEN_PART")
+    if part and do_save:
+        with open(part, "w") as o:
+            json.dump({k: v for k, v in exp.items() if not k.startswith("_")}, o)
     return exp
 
 
@@ -583,6 +667,9 @@ def main():
     def want(name):
         return not only or name in only
 
+    if only == {"norm_order_part"}:        # one hash-seed variant of norm_order (norm_order_case runs these)
+        norm_order_part()
+        return
     if want("leaf_gtlib"):
         leaf_gtlib()
     if want("leaf_cs"):
@@ -673,6 +760,16 @@ def main():
     if want("norm_phase"):
         norm_case("norm_phase", small_cfg(205, contig_len=40000, snp_rate=3e-3, som_rate=3e-4, name="chr5"),
                   md_threshold=52, phase_block=12, with_sets=True)
+    if want("norm_nsub"):
+        # cs substitutions with an 'n' reference base against a FASTA that holds a real base there
+        norm_case("norm_nsub", small_cfg(207, contig_len=30000, name="chrN", sub_rate=1.5e-3, read_len_mean=1800, read_len_sd=500,
+                                         read_len_min=700), md_threshold=60, mutate_batch=nsub_batch,
+                  overrides=dict(max_mismatch_count=1, mismatch_window_size=20, min_trim=0.005))
+    if want("norm_order"):
+        norm_order_case()
+    if want("worker_phase_dup"):
+        worker_case("worker_phase_dup", small_cfg(111, contig_len=60000, snp_rate=3e-3, som_rate=4e-4, name="chr5"),
+                    phase_block=15, mutate=dup_names_batch, md_threshold=200)
     if want("norm_softmask"):
         # lower-case (soft-masked) and N stretches in the reference: skipped positions, odd trinucleotide keys
         def mask(seq):

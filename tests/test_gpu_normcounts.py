@@ -37,6 +37,20 @@ def test_normcounts_golden(worker, case):
     assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
 
 
+def test_normcounts_alt_order_variants(worker):
+    """norm_order (see test_oracle_golden): every order python gave set("ATGC").difference(ref) in the reference runs,
+    with the PoN / common counters that order produced."""
+    from himut_amd import normcounts
+    batch, exp, p, refseq, pon, com = load_norm_case("norm_order")
+    _configure(worker, p, False)
+    for v in exp["variants"]:
+        ccs, rf, log = normcounts.norm_contig(worker, batch, util.chunks_of(exp), refseq, pon, com,
+                                              exp["non_human_sample"], v["alt_order"])
+        assert log == v["log"], v["hashseed"]
+        assert {k: c for k, c in ccs.items() if c} == {k: int(c) for k, c in v["ccs_tri2count"].items() if c}
+        assert {k: c for k, c in rf.items() if c} == {k: int(c) for k, c in v["ref_tri2count"].items() if c}
+
+
 @pytest.mark.parametrize("case", ["norm_dense", "norm_phase"])
 def test_normcounts_golden_column_store_sweep(worker, case, monkeypatch):
     """The earlier sweep (cells through a column store in HBM, HIMUT_NORM_SWEEP=store) is kept for comparison with

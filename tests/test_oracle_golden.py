@@ -58,7 +58,7 @@ def test_cs_tuples():
                 assert (o[3], o[4]) == (t[1], t[2])
 
 
-NORM_CASES = ["norm_basic", "norm_sets", "norm_dense", "norm_softmask", "norm_phase"]
+NORM_CASES = ["norm_basic", "norm_sets", "norm_dense", "norm_softmask", "norm_phase", "norm_nsub"]
 
 
 def load_norm_case(case):
@@ -89,6 +89,22 @@ def test_normcounts_oracle_matches_reference(case):
         {k: v for k, v in exp["ccs_tri2count"].items() if v or k in O.TRI_LST}
     assert {k: v for k, v in rf.items() if v or k in O.TRI_LST} == \
         {k: v for k, v in exp["ref_tri2count"].items() if v or k in O.TRI_LST}
+
+
+def test_normcounts_alt_order_decides_pon_vs_common():
+    """norm_order: the panel of normals and the common SNPs each hold one alternative allele of the same positions; the
+    reference was run under several PYTHONHASHSEED values and each distinct order of set("ATGC").difference(ref)
+    (normcounts.py:367) gave its own PoN / common counters.  The oracle takes the order as an input and must
+    reproduce every variant."""
+    from oracle import oracle as O
+    batch, exp, p, refseq, pon, com = load_norm_case("norm_order")
+    assert len(exp["variants"]) >= 2 and len({(v["log"][11], v["log"][12]) for v in exp["variants"]}) >= 2
+    for v in exp["variants"]:
+        ccs, rf, log = O.normcounts(batch, util.chunks_of(exp), p, refseq, p["germline_snv_prior"], pon, com,
+                                    alt_order=v["alt_order"], non_human_sample=exp["non_human_sample"])
+        assert log == v["log"], v["hashseed"]
+        assert {k: c for k, c in ccs.items() if c} == {k: c for k, c in v["ccs_tri2count"].items() if c}
+        assert {k: c for k, c in rf.items() if c} == {k: c for k, c in v["ref_tri2count"].items() if c}
 
 
 EDGE_CASES = ["edges_basic", "edges_lowq"]
