@@ -47,7 +47,7 @@ EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_err
            "himut_set_gt_lut", "himut_set_chunks", "himut_set_site_set", "himut_set_phase", "himut_push_reads",
            "himut_run", "himut_get_records", "himut_get_log", "himut_get_stats", "himut_records_device",
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
-           "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing"]
+           "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing", "himut_sbs96_counts"]
 
 _lib = None
 
@@ -108,6 +108,8 @@ def lib():
     L.himut_get_normcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.himut_ref_tricounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.himut_set_stage_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.himut_sbs96_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p]
     L.himut_run_edges.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int64, ctypes.c_void_p]
     for name in EXPORTS:
@@ -258,6 +260,16 @@ class Context:
     def ref_tricounts(self):
         out = np.zeros(64, np.int64)
         self._check(self._L.himut_ref_tricounts(self._h, _ptr(out)))
+        return out
+
+    def sbs96_counts(self, pos0, ref, alt):
+        """99 bins (see himut_sbs96_counts) for the substitutions (0-based pos, ASCII ref / alt) of the contig whose
+        string was given to set_reference."""
+        pos0 = np.ascontiguousarray(pos0, np.int32)
+        ref = np.ascontiguousarray(ref, np.uint8)
+        alt = np.ascontiguousarray(alt, np.uint8)
+        out = np.zeros(99, np.int64)
+        self._check(self._L.himut_sbs96_counts(self._h, _ptr(pos0), _ptr(ref), _ptr(alt), int(pos0.shape[0]), _ptr(out)))
         return out
 
     def pile_counts(self, p0, p1):

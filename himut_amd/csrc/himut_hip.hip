@@ -1144,6 +1144,35 @@ int himut_ref_tricounts(himut_ctx* c, int64_t out[64]) {
     });
 }
 
+int himut_sbs96_counts(himut_ctx* c, const int32_t* pos0, const uint8_t* ref, const uint8_t* alt, int64_t n, int64_t out[99]) {
+    if (!c || !out || n < 0 || (n && (!pos0 || !ref || !alt))) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int {
+        if (c->reflen <= 0) return fail(c, HIMUT_ERR_ARG, "himut_set_reference has not been called");
+        HCHECK(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        const size_t nn = (size_t)std::max<int64_t>(n, 1);
+        c->d_tmp.reserve(nn * 4 + 256);
+        c->d_tmp2.reserve(nn * 2 + 99 * 8 + 512);
+        uint8_t* d_ref = c->d_tmp2.as<uint8_t>();
+        uint8_t* d_alt = d_ref + nn;
+        unsigned long long* d_out = reinterpret_cast<unsigned long long*>(c->d_tmp2.as<uint8_t>() + ((2 * nn + 255) & ~(size_t)255));
+        if (n) {
+            HCHECK(hipMemcpyAsync(c->d_tmp.p, pos0, (size_t)n * 4, hipMemcpyHostToDevice, st));
+            HCHECK(hipMemcpyAsync(d_ref, ref, (size_t)n, hipMemcpyHostToDevice, st));
+            HCHECK(hipMemcpyAsync(d_alt, alt, (size_t)n, hipMemcpyHostToDevice, st));
+        }
+        HCHECK(hipMemsetAsync(d_out, 0, 99 * 8, st));
+        if (n)
+            hipLaunchKernelGGL(k_sbs96, dim3(std::min<unsigned>(blocks_for(n, 256), 2048u)), dim3(256), 0, st, c->d_refseq.as<uint8_t>(),
+                               c->reflen, c->d_tmp.as<int32_t>(), d_ref, d_alt, n, d_out);
+        unsigned long long h[99];
+        HCHECK(hipMemcpyAsync(h, d_out, 99 * 8, hipMemcpyDeviceToHost, st));
+        HCHECK(hipStreamSynchronize(st));
+        for (int k = 0; k < 99; k++) out[k] = (int64_t)h[k];
+        return HIMUT_OK;
+    });
+}
+
 int himut_run_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human_sample) {
     if (!c || !alt_order) return HIMUT_ERR_ARG;
     return guarded(c, [&]() -> int { return do_normcounts(c, alt_order, non_human_sample); });

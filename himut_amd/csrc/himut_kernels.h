@@ -638,6 +638,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { match += __shfl_xor(match, d, 64); mism += __shfl_xor(mism, d, 64); }
     // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow in k_propose
+    if (!bad && match + mism == 0) bad = HIMUT_ERR_CS;     // an empty tag: ZeroDivisionError in the reference (bamlib.py:62)
     const double ident = (double)match / (double)(match + mism);
     const bool ident_ok = !bad && !(ident < P.p.min_sequence_identity);
     if (mark && ident_ok && nmark > 0) flush_marks();

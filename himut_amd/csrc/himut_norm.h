@@ -826,6 +826,42 @@ __global__ void __launch_bounds__(256) k_ref_tricounts(const uint8_t* seq, int64
 }
 
 // ---------------------------------------------------------------------------------------
+// k_sbs96: mutlib.get_sbs96 + the counting of load_sbs96_counts (mutlib.py:1998-2018, 2058-2102) over the resident
+// reference string: one thread per called single-base substitution (0-based position, ASCII ref / alt as the VCF
+// holds them).  A purine reference base is reported on the other strand, its neighbours through the
+// purine2pyrimidine table (anything outside ACGTN becomes N); a pyrimidine one takes its neighbours as the string
+// holds them.  out[0 .. 95]: class (substitution C>A C>G C>T T>A T>C T>G) * 16 + upstream * 4 + downstream with
+// A0 C1 G2 T3; out[96]: classes that contain an N (the reference drops them); out[97]: classes outside the 96 with no N
+// (KeyError in the reference: a lower-case neighbour of a pyrimidine, an alt outside ACGT); out[98]: position + 1
+// behind the string (IndexError).  Position 0 takes its upstream base from the END of the string, as python's seq[-1] does.
+__global__ void __launch_bounds__(256) k_sbs96(const uint8_t* seq, int64_t len, const int32_t* pos, const uint8_t* ref,
+                                               const uint8_t* alt, int64_t n, unsigned long long* out) {
+    __shared__ unsigned int s_h[99];
+    if (threadIdx.x < 99) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    auto code = [](int c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : 5; };   // 5: any other byte
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = pos[i];
+        if (p < 0 || p + 1 >= len) { atomicAdd(&s_h[98], 1u); continue; }
+        const int r = ref[i], a = alt[i];
+        const int before = seq[p > 0 ? p - 1 : len - 1], after = seq[p + 1];
+        int up, rf, al, dn;         // codes 0..3, 4 = N, 5 = a letter the class list does not have
+        if (r == 'A' || r == 'G') {
+            auto comp = [&](int c) { const int k = code(c); return k < 4 ? 3 - k : 4; };     // purine2pyrimidine.get(c, "N")
+            up = comp(after); dn = comp(before); rf = comp(r); al = comp(a);
+        } else {
+            up = code(before); dn = code(after); rf = code(r); al = code(a);
+        }
+        if (up == 4 || dn == 4 || rf == 4 || al == 4) { atomicAdd(&s_h[96], 1u); continue; }
+        if (up > 3 || dn > 3 || al > 3 || (rf != 1 && rf != 3) || al == rf) { atomicAdd(&s_h[97], 1u); continue; }
+        const int sub = (rf == 1 ? 0 : 3) + (al > rf ? al - 1 : al);       // C>A C>G C>T | T>A T>C T>G
+        atomicAdd(&s_h[sub * 16 + up * 4 + dn], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 99 && s_h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------
 // k_edges: phaselib.get_edges (phaselib.py:16-67).  One wave per read, lanes = the heterozygous SNPs the read
 // spans (tstart < pos <= tend).  Every lane finds its SNP's segment by binary search over the read's segment
 // list and reads the base and its quality (a deleted position has quality 0, cslib.py:153-170); every ordered

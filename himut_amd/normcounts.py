@@ -201,6 +201,45 @@ def load_sbs96_counts(vcf_file, refseq, chrom_lst):
     return counts
 
 
+def load_sbs96_counts_device(ctx_for, vcf_file, refseq, chrom_lst):
+    """load_sbs96_counts with the classification and the counting on the device (himut_sbs96_counts, k_sbs96): the VCF
+    text is parsed here, the PASS bi-allelic SNVs of every contig go to the device as three arrays and the contig's
+    string -- resident for the sweep anyway -- supplies the neighbours.  ``ctx_for(chrom)`` returns a context whose
+    reference is that contig's string.  Raises what the reference raises: KeyError for a contig the header does not
+    list or a class outside the 96, IndexError for a position at the end of the string."""
+    from .vcflib import VcfRecord
+    per_chrom = None
+    contigs = []
+    for line in _open_sbs(vcf_file):
+        if line.startswith("##"):
+            if line.startswith("##contig"):
+                contigs.append(line.strip().replace("##contig=<ID=", "").split(",")[0])
+            continue
+        if line.startswith("#CHROM"):
+            per_chrom = {t: ([], [], []) for t in contigs}
+            continue
+        v = VcfRecord(line)
+        if v.is_snp and v.is_pass:
+            p, r, a = per_chrom[v.chrom]            # KeyError for a contig the header does not list, as the reference
+            p.append(v.pos - 1); r.append(ord(v.ref)); a.append(ord(v.alt))
+    counts = {k: 0 for k in SBS96_LST}
+    subs = ("C>A", "C>G", "C>T", "T>A", "T>C", "T>G")
+    for chrom in chrom_lst:
+        p, r, a = per_chrom[chrom]
+        if not p:
+            continue
+        h = ctx_for(chrom).sbs96_counts(p, r, a)
+        if h[98]:
+            raise IndexError("string index out of range")
+        if h[97]:
+            raise KeyError("SBS96 class outside the 96 (a neighbour or alternative allele that is not A/C/G/T/N)")
+        for s6 in range(6):
+            for u in range(4):
+                for d in range(4):
+                    counts["{}[{}]{}".format("ACGT"[u], subs[s6], "ACGT"[d])] += int(h[s6 * 16 + u * 4 + d])
+    return counts
+
+
 def get_chrom_tricount(seq):
     """Trinucleotide counts of one contig (reflib.py:11-33): triplets whose FIRST base is N are skipped, purine
     centres are reverse-complemented.  Only the 32 pyrimidine-centred ACGT keys are kept (all the callers read)."""
@@ -357,7 +396,15 @@ def get_normcounts(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, comm
                                      max_mismatch_count, min_ref_count, min_alt_count, min_hap_count, common_snps,
                                      panel_of_normals, somatic_snv_prior, germline_snv_prior, germline_indel_prior,
                                      threads, phase, non_human_sample, reference_sample, out_file)
-    sbs2count = load_sbs96_counts(sbs_file, refseq, chrom_lst)
+    # SBS96 classes of the called substitutions, counted on the device against each contig's string
+    from . import caller
+
+    def ctx_for(chrom):
+        ctx = caller._worker_for(devices[0] if group is None else group[2]).ctx
+        chars, cls = tri_classes(refseq[chrom])
+        ctx.set_reference(refseq[chrom], cls, len(chars))
+        return ctx
+    sbs2count = load_sbs96_counts_device(ctx_for, sbs_file, refseq, chrom_lst)
     ref_tri2count = get_genome_tricounts(refseq, chrom_lst)
     dump_normcounts(sbs2count, ref_tri2count, ref, ccs, cmdline, out_file)
     dump_norm_log(chrom_lst, log, log_path)

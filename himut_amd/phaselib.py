@@ -147,7 +147,13 @@ def get_chrom_hblock(bam_file, vcf_file, region, region_list, min_bq, min_mapq, 
                      threads, version, out_file, devices=(0,)):
     """`himut phase` (phaselib.py:253-323): phases the hetSNPs of every target contig and writes the phased VCF.
     ``threads`` feeds the BAM ingest; contigs go through the device one after the other."""
+    import os
     from . import bamio, util, vcflib
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # `himut phase` is one process (its device work is the edge counts of one contig at a time); started under
+        # torch.distributed.run every rank would phase every contig and write the same file
+        raise RuntimeError("himut phase runs as a single process: start it without torch.distributed.run "
+                           "(WORLD_SIZE={})".format(os.environ["WORLD_SIZE"]))
     t0 = time.time() / 60
     print("phasing hetsnps with {} threads".format(threads))
     bam = bamio.BamFile(bam_file, threads=threads)

@@ -214,6 +214,14 @@ int himut_get_normcounts(himut_ctx* ctx, int64_t* ccs_tri, int64_t* ref_tri, int
  * last], letters A0 C1 G2 T3, purine centres already turned to the other strand (so 32 of the 64 bins fill). */
 int himut_ref_tricounts(himut_ctx* ctx, int64_t out[64]);
 
+/* ---- next row: mutlib.load_sbs96_counts / get_sbs96 (mutlib.py:1998-2018, 2058-2102) of the contig whose
+ * string was given to himut_set_reference.  pos0 / ref / alt: the PASS bi-allelic single-base substitutions of that
+ * contig as the VCF holds them (0-based position, ASCII).  out[sub * 16 + up * 4 + down] for the 96 classes (sub in the
+ * order C>A C>G C>T T>A T>C T>G, A0 C1 G2 T3, purine references read on the other strand); out[96] = classes that
+ * contain an N (the reference drops them), out[97] = classes outside the 96 without an N (KeyError in the reference),
+ * out[98] = position + 1 behind the string (IndexError in the reference). */
+int himut_sbs96_counts(himut_ctx* ctx, const int32_t* pos0, const uint8_t* ref, const uint8_t* alt, int64_t n, int64_t out[99]);
+
 /* ---- next row: phaselib.get_edges (phaselib.py:16-67) --------------------------------
  * hpos / href: the contig's heterozygous SNPs (1-based position ascending, ASCII reference base), as
  * vcflib.load_hetsnps lists them.  For every primary read with mapq >= min_mapq and every ordered pair (i, j) of

@@ -159,3 +159,54 @@ def test_ref_tricounts_match_reference_golden(worker):
     rs = np.random.RandomState(7)
     big = bytes(rs.choice(np.frombuffer(b"ACGTACGTACGTNacgt", np.uint8), 5_000_000))
     assert N.get_chrom_tricount_device(worker.ctx, big) == N.get_chrom_tricount(big)
+
+
+def test_sbs96_counts_on_device_match_reference(worker, tmp_path):
+    """mutlib.load_sbs96_counts / get_sbs96 with the classification and counting on the device
+    (himut_sbs96_counts) against the reference's own counts (tests/golden/norm_host.json), and against the host mirror
+    on a string with N and lower-case stretches where classes are dropped or raise."""
+    from himut_amd import normcounts as N
+    exp = util.load_json("norm_host")
+    fa = tmp_path / "ref.fa"
+    fa.write_text(exp["fasta_text"])
+    sbs = tmp_path / "calls.vcf"
+    sbs.write_text(exp["sbs_vcf_text"])
+    refseq = N.read_fasta(str(fa))
+    chrom = exp["contig"]
+
+    def ctx_for(c):
+        chars, cls = N.tri_classes(refseq[c])
+        worker.ctx.set_reference(refseq[c], cls, len(chars))
+        return worker.ctx
+    got = N.load_sbs96_counts_device(ctx_for, str(sbs), refseq, [chrom])
+    assert got == exp["sbs96_counts"] and list(got) == N.SBS96_LST and sum(got.values()) > 0
+    # direct: every (ref, alt) at every position of a string with N / soft-masked stretches, bins against the host mirror
+    rs = np.random.RandomState(5)
+    seq = "".join(rs.choice(list("ACGT"), 4000))
+    seq = seq[:500] + "N" * 7 + seq[507:900] + seq[900:960].lower() + seq[960:]
+    ref = {"c": seq}
+    pos, rr, aa = [], [], []
+    want = {k: 0 for k in N.SBS96_LST}
+    n_drop = n_key = 0
+    for p in range(0, len(seq) - 1):
+        r = seq[p]
+        if r not in "ACGT":
+            continue
+        for a in "ACGT":
+            if a == r:
+                continue
+            k = N.get_sbs96("c", p, r, a, ref)
+            pos.append(p); rr.append(ord(r)); aa.append(ord(a))
+            if "N" in k:
+                n_drop += 1
+            elif k in want:
+                want[k] += 1
+            else:
+                n_key += 1
+    chars, cls = N.tri_classes(seq)
+    worker.ctx.set_reference(seq, cls, len(chars))
+    h = worker.ctx.sbs96_counts(pos, rr, aa)
+    subs = N.SUB_LST
+    dev = {"{}[{}]{}".format("ACGT"[u], subs[s6], "ACGT"[d]): int(h[s6 * 16 + u * 4 + d]) for s6 in range(6) for u in range(4) for d in range(4)}
+    assert dev == want and int(h[96]) == n_drop and int(h[97]) == n_key and n_drop > 0 and n_key > 0 and int(h[98]) == 0
+    assert int(worker.ctx.sbs96_counts([len(seq) - 1], [ord("C")], [ord("T")])[98]) == 1          # IndexError in the reference
