@@ -43,11 +43,17 @@ class RunStats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class IngestResult(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int64) for k in ("n_reads", "bases_padded", "cs_bytes", "read_bases", "n_missing_cs",
+                                              "n_unsorted", "n_malformed")]
+
+
 EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_error", "himut_set_params",
            "himut_set_gt_lut", "himut_set_chunks", "himut_set_site_set", "himut_set_phase", "himut_push_reads",
            "himut_run", "himut_get_records", "himut_get_log", "himut_get_stats", "himut_records_device",
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
-           "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing", "himut_sbs96_counts"]
+           "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing", "himut_sbs96_counts", "himut_ingest_begin", "himut_ingest_buffer",
+           "himut_ingest_wait", "himut_ingest_window", "himut_ingest_end", "himut_ingest_read_meta", "himut_download_reads"]
 
 _lib = None
 
@@ -112,9 +118,18 @@ def lib():
                                      ctypes.c_void_p]
     L.himut_run_edges.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int64, ctypes.c_void_p]
+    L.himut_ingest_begin.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+    L.himut_ingest_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.himut_ingest_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.himut_ingest_window.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    L.himut_ingest_end.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(IngestResult)]
+    L.himut_ingest_read_meta.argtypes = [ctypes.c_void_p] * 6
+    L.himut_download_reads.argtypes = [ctypes.c_void_p, ctypes.POINTER(ReadBatchStruct), ctypes.c_void_p]
     for name in EXPORTS:
-        if name not in ("himut_destroy", "himut_last_error"):
+        if name not in ("himut_destroy", "himut_last_error", "himut_ingest_buffer"):
             getattr(L, name).restype = ctypes.c_int
+    L.himut_ingest_buffer.restype = ctypes.c_void_p
     if L.himut_abi_version() != 2:
         raise ImportError("libhimut_hip.so ABI version mismatch")
     _lib = L
@@ -261,6 +276,46 @@ class Context:
         out = np.zeros(64, np.int64)
         self._check(self._L.himut_ref_tricounts(self._h, _ptr(out)))
         return out
+
+    # ---- device-side BAM ingest (bamio.ingest_contig drives it)
+    def ingest_begin(self, inflated_bound, window_bytes):
+        self._check(self._L.himut_ingest_begin(self._h, int(inflated_bound), int(window_bytes)))
+        return [self._L.himut_ingest_buffer(self._h, k) for k in (0, 1)]
+
+    def ingest_wait(self, slot):
+        self._check(self._L.himut_ingest_wait(self._h, int(slot)))
+
+    def ingest_window(self, slot, nbytes, rec_off, qid, n_rec, padded_bases, tag_bytes):
+        self._check(self._L.himut_ingest_window(self._h, int(slot), int(nbytes), _ptr(rec_off), _ptr(qid), int(n_rec),
+                                                int(padded_bases), int(tag_bytes)))
+
+    def ingest_end(self, unique_qnames):
+        r = IngestResult()
+        rc = self._L.himut_ingest_end(self._h, 1 if unique_qnames else 0, ctypes.byref(r))
+        self._check(rc)
+        return {k: getattr(r, k) for k, _ in IngestResult._fields_}
+
+    def ingest_read_meta(self, n):
+        """(tstart, tend, qlen, mapq, tp) of the resident reads: what bamlib.get_thresholds looks at."""
+        a = [np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint8), np.zeros(n, np.uint8)]
+        self._check(self._L.himut_ingest_read_meta(self._h, *[_ptr(x) for x in a]))
+        return a
+
+    def download_reads(self, res, name="", length=0):
+        """The resident read batch as a host ReadBatch (tests)."""
+        from .readbatch import ReadBatch
+        n = int(res["n_reads"])
+        a = dict(tstart=np.zeros(n, np.int32), tend=np.zeros(n, np.int32), qstart=np.zeros(n, np.int32),
+                 qlen=np.zeros(n, np.int32), mapq=np.zeros(n, np.uint8), flag=np.zeros(n, np.uint16),
+                 qid=np.zeros(n, np.int32), qoff=np.zeros(n, np.int64), cs_off=np.zeros(n + 1, np.int64),
+                 seq=np.zeros(int(res["bases_padded"]) // 2, np.uint8), bq=np.zeros(int(res["bases_padded"]), np.uint8),
+                 cs=np.zeros(int(res["cs_bytes"]), np.uint8))
+        tp = np.zeros(n, np.uint8)
+        order = ("tstart", "tend", "qstart", "qlen", "mapq", "flag", "qid", "qoff", "cs_off", "seq", "bq", "cs")
+        st = ReadBatchStruct(n, *[_ptr(a[k]) for k in order], int(a["seq"].shape[0]), int(a["bq"].shape[0]),
+                             int(a["cs"].shape[0]))
+        self._check(self._L.himut_download_reads(self._h, ctypes.byref(st), _ptr(tp)))
+        return ReadBatch(name=name, length=length, tp=tp, **a)
 
     def sbs96_counts(self, pos0, ref, alt):
         """99 bins (see himut_sbs96_counts) for the substitutions (0-based pos, ASCII ref / alt) of the contig whose

@@ -51,6 +51,27 @@ def _load():
         L.bam_ref_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
         L.bam_free.restype = None
         L.bam_free.argtypes = [ctypes.c_void_p]
+        L.bam_stream_open.restype = ctypes.c_void_p
+        L.bam_stream_open.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        for f in ("bam_stream_error", "bam_stream_header_text"):
+            getattr(L, f).restype = ctypes.c_char_p
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        L.bam_stream_ref_name.restype = ctypes.c_char_p
+        L.bam_stream_ref_name.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        L.bam_stream_n_ref.restype = ctypes.c_int64
+        L.bam_stream_n_ref.argtypes = [ctypes.c_void_p]
+        L.bam_stream_ref_len.restype = ctypes.c_int64
+        L.bam_stream_ref_len.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        for f in ("bam_stream_indexed", "bam_stream_unique_names"):
+            getattr(L, f).restype = ctypes.c_int
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        L.bam_stream_close.restype = None
+        L.bam_stream_close.argtypes = [ctypes.c_void_p]
+        L.bam_stream_select.restype = ctypes.c_int
+        L.bam_stream_select.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
+        L.bam_stream_next.restype = ctypes.c_int64
+        L.bam_stream_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]
         L.bam_write.restype = ctypes.c_int
         L.bam_write.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_WriteContig), ctypes.c_int64]
         _lib = L
@@ -128,6 +149,74 @@ class BamFile:
                     if f.startswith("SM"):
                         return f.split(":")[1]
         raise ValueError("SM field is missing; provide a BAM file with an @RG group")
+
+
+class BamStream:
+    """One BAM opened for the device-side ingest: the header here, the records of one contig at a time to the GPU
+    (``ingest_contig``).  With an index beside the file (x.bam.bai) only the contig's own BGZF blocks are inflated."""
+
+    def __init__(self, path, threads=0):
+        L = _load()
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self._L = L
+        self._h = L.bam_stream_open(path.encode(), int(threads))
+        err = L.bam_stream_error(self._h).decode()
+        if err:
+            raise ValueError("{}: {}".format(path, err))
+        self.path = path
+        self.header_text = L.bam_stream_header_text(self._h).decode("utf-8", "replace")
+        self.names = [L.bam_stream_ref_name(self._h, i).decode() for i in range(L.bam_stream_n_ref(self._h))]
+        self.tname2tsize = {n: L.bam_stream_ref_len(self._h, i) for i, n in enumerate(self.names)}
+        self.indexed = bool(L.bam_stream_indexed(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bam_stream_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    sample = BamFile.sample
+
+    def ingest_contig(self, ctx, chrom, window_bytes=None):
+        """Streams the records of ``chrom`` into the context ``ctx`` (an _ffi.Context), parsed on the device.  Two
+        pinned windows: while the GPU copies and parses one, the host's pool inflates the next.  Leaves the context as
+        ``push_reads`` would and returns the ingest result (n_reads, bases_padded, cs_bytes, read_bases)."""
+        L, h = self._L, self._h
+        if window_bytes is None:
+            window_bytes = int(os.environ.get("HIMUT_INGEST_WINDOW_KB", str(64 << 10))) << 10
+        bound = ctypes.c_int64()
+        if L.bam_stream_select(h, self.names.index(chrom), ctypes.byref(bound)):
+            raise ValueError(L.bam_stream_error(h).decode())
+        bufs = ctx.ingest_begin(bound.value, window_bytes)
+        rec_cap = window_bytes // 64 + 16
+        rec_off = [np.zeros(rec_cap, np.uint32) for _ in (0, 1)]
+        qid = [np.zeros(rec_cap, np.int32) for _ in (0, 1)]
+        nbytes = ctypes.c_int64()
+        sums = np.zeros(2, np.int64)
+        slot = 0
+        while True:
+            ctx.ingest_wait(slot)                     # the bytes this buffer held two windows ago have left the host
+            n = L.bam_stream_next(h, bufs[slot], window_bytes, _p(rec_off[slot]), _p(qid[slot]), rec_cap,
+                                  ctypes.byref(nbytes), _p(sums))
+            if n == -1:
+                break
+            if n < 0:
+                raise ValueError("{}: {}".format(self.path, L.bam_stream_error(h).decode()))
+            ctx.ingest_window(slot, nbytes.value, rec_off[slot], qid[slot], n, int(sums[0]), int(sums[1]))
+            slot ^= 1
+        res = ctx.ingest_end(bool(L.bam_stream_unique_names(h)))
+        if res["n_missing_cs"]:
+            # the reference does line.get_tag("cs") on every record (bamlib.py:32)
+            raise KeyError("tag 'cs' not present in {} records of {}".format(res["n_missing_cs"], self.path))
+        if res["n_unsorted"]:
+            raise ValueError("{} is not coordinate sorted".format(self.path))
+        return res
 
 
 _cache = {}

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -61,6 +62,7 @@ struct Deflate {
 const Deflate& deflate_lib() { static Deflate d; return d; }
 
 struct BlockRef {
+    size_t file_off;      // first byte of the block in the file (virtual file offsets of the index point here)
     size_t cdata_off;     // first byte of the deflate stream
     uint32_t cdata_len;
     uint32_t isize;       // inflated size
@@ -138,6 +140,7 @@ struct Bgzf {
             const size_t total = (size_t)bsize + 1;
             if (total < 12 + xlen + 8 || p + total > fsize) { err = "truncated BGZF block"; return false; }
             BlockRef b;
+            b.file_off = p;
             b.cdata_off = p + 12 + xlen;
             b.cdata_len = (uint32_t)(total - 12 - xlen - 8);
             const uint8_t* t = base + p + total - 4;
@@ -158,6 +161,11 @@ struct Bgzf {
         size_t total = 0;
         for (size_t k = b0; k < b1; k++) total += blocks[k].isize;
         out.resize(total);
+        return inflate_blocks(b0, b1, out.data(), blocks[b0 < b1 ? b0 : 0].uoff);
+    }
+    // inflates blocks [b0, b1) with the pool: block k lands at dst + (uoff[k] - base_uoff) when the blocks belong to one
+    // window, or back to back from dst when ``packed`` (any range)
+    std::string inflate_blocks(size_t b0, size_t b1, uint8_t* dst, size_t base_uoff, const std::vector<size_t>* packed_off = nullptr) const {
         std::atomic<size_t> next(b0);
         std::atomic<int> bad(0);
         auto work = [&]() {
@@ -171,13 +179,14 @@ struct Bgzf {
                 if (k >= b1) break;
                 const BlockRef& b = blocks[k];
                 if (!b.isize) continue;
+                uint8_t* to = packed_off ? dst + (*packed_off)[k - b0] : dst + (b.uoff - base_uoff);
                 if (dec) {
                     size_t got = 0;
-                    if (L.run(dec, base + b.cdata_off, b.cdata_len, out.data() + b.uoff, b.isize, &got) != 0 || got != b.isize) { bad = 2; break; }
+                    if (L.run(dec, base + b.cdata_off, b.cdata_len, to, b.isize, &got) != 0 || got != b.isize) { bad = 2; break; }
                 } else {
                     inflateReset(&zs);
                     zs.next_in = (Bytef*)(base + b.cdata_off); zs.avail_in = b.cdata_len;
-                    zs.next_out = out.data() + b.uoff; zs.avail_out = b.isize;
+                    zs.next_out = to; zs.avail_out = b.isize;
                     if (inflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 2; break; }
                 }
             }
@@ -339,6 +348,8 @@ struct BgzfWriter {
     FILE* f;
     std::vector<uint8_t> buf;
     bool ok = true;
+    uint64_t foff = 0;      // bytes of finished blocks
+    uint64_t voffset() const { return (foff << 16) | (uint64_t)buf.size(); }   // virtual file offset of the next byte
     void flush_block(const uint8_t* data, size_t n) {
         std::vector<uint8_t> comp(n + 1024);
         z_stream zs;
@@ -355,6 +366,7 @@ struct BgzfWriter {
         uint8_t tail[8];
         for (int k = 0; k < 4; k++) { tail[k] = (uint8_t)(crc >> (8 * k)); tail[4 + k] = (uint8_t)((uint32_t)n >> (8 * k)); }
         ok = ok && fwrite(hdr, 1, 18, f) == 18 && fwrite(comp.data(), 1, clen, f) == clen && fwrite(tail, 1, 8, f) == 8;
+        foff += 18 + clen + 8;
     }
     void write(const void* p, size_t n) {
         const uint8_t* d = (const uint8_t*)p;
@@ -377,8 +389,19 @@ extern "C" {
 
 // Loads the whole file with `threads` inflate threads (0: one per hardware thread, at most 16).
 // Returns a handle (never null); check bam_error().
+static void* bam_load_threads_impl(Bam* B, const char* path, int threads);
+
 void* bam_load_threads(const char* path, int threads) {
     Bam* B = new Bam();
+    try {
+        return bam_load_threads_impl(B, path, threads);
+    } catch (const std::exception& e) {         // e.g. bad_alloc / length_error on a corrupt header: an error, not an abort
+        B->err = std::string("BAM load failed: ") + e.what();
+        return B;
+    }
+}
+
+static void* bam_load_threads_impl(Bam* B, const char* path, int threads) {
     Bgzf z;
     if (threads <= 0) {
         const char* e = getenv("HIMUT_INGEST_THREADS");
@@ -392,15 +415,20 @@ void* bam_load_threads(const char* path, int threads) {
     if (!z.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) return fail(z.err.empty() ? "not a BAM file" : z.err);
     if (!z.read(b4, 4)) return fail(z.err);
     const uint32_t l_text = le32(b4);
+    size_t inflated_all = 0;                // sizes read from the header are checked against what the file can hold
+    for (const BlockRef& b : z.blocks) inflated_all += b.isize;
+    if ((size_t)l_text > inflated_all) return fail("BAM header text longer than the file");
     B->header_text.resize(l_text);
     if (l_text && !z.read(&B->header_text[0], l_text)) return fail(z.err);
     while (!B->header_text.empty() && B->header_text.back() == '\0') B->header_text.pop_back();
     if (!z.read(b4, 4)) return fail(z.err);
     const uint32_t n_ref = le32(b4);
+    if ((size_t)n_ref * 8 > inflated_all) return fail("BAM header lists more contigs than the file can hold");
     B->contigs.resize(n_ref);
     for (uint32_t i = 0; i < n_ref; i++) {
         if (!z.read(b4, 4)) return fail(z.err);
         const uint32_t l_name = le32(b4);
+        if ((size_t)l_name > inflated_all) return fail("contig name longer than the file");
         std::string nm(l_name, '\0');
         if (!z.read(&nm[0], l_name)) return fail(z.err);
         while (!nm.empty() && nm.back() == '\0') nm.pop_back();
@@ -476,7 +504,7 @@ void* bam_load_threads(const char* path, int threads) {
         C.mapq.push_back(I.mapq);
         C.flag.push_back(I.flag);
         C.tp.push_back(I.tp);
-        auto it = C.first_by_name.emplace(std::string(I.qname), idx);
+        auto it = C.first_by_name.emplace(std::string(I.qname, strnlen(I.qname, I.l_qname)), idx);
         C.qid.push_back(it.first->second);
         C.qoff.push_back(C.bases_padded);
         I.C = &C; I.dst_bases = C.bases_padded; I.dst_cs = C.cs_n;
@@ -722,6 +750,18 @@ int bam_write(const char* path, const char* sample, const BamWriteContig* contig
     w.write(hdr.data(), hdr.size());
     std::vector<uint8_t> rec;
     std::vector<uint32_t> cigar;
+    // index (.bai, SAM spec section 5.2): per contig the bins with their chunks and the 16-kb linear index
+    struct RefIndex { std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lin; uint64_t beg = 0, end = 0, n = 0; };
+    std::vector<RefIndex> index((size_t)n_contigs);
+    auto reg2bin = [](int64_t beg, int64_t end) -> uint32_t {
+        --end;
+        if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+        if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+        if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+        if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+        if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+        return 0;
+    };
     for (int64_t ci = 0; ci < n_contigs; ci++) {
         const BamWriteContig& C = contigs[ci];
         for (int64_t r = 0; r < C.n; r++) {
@@ -772,13 +812,264 @@ int bam_write(const char* path, const char* sample, const BamWriteContig* contig
             if (C.tp[r]) { rec.insert(rec.end(), {'t', 'p', 'A'}); rec.push_back(C.tp[r]); }
             const uint32_t bs = (uint32_t)rec.size() - 4;
             for (int k = 0; k < 4; k++) rec[k] = (uint8_t)(bs >> (8 * k));
+            int64_t ref_len = 0;
+            for (uint32_t c : cigar) if ((c & 15) == 0 || (c & 15) == 2) ref_len += c >> 4;
+            const uint64_t v0 = w.voffset();
             w.write(rec.data(), rec.size());
+            const uint64_t v1 = w.voffset();
+            RefIndex& X = index[(size_t)ci];
+            const int64_t beg = C.tstart[r], end = beg + (ref_len > 0 ? ref_len : 1);
+            auto& ch = X.bins[reg2bin(beg, end)];
+            if (!ch.empty() && ch.back().second == v0) ch.back().second = v1; else ch.emplace_back(v0, v1);
+            for (int64_t wdw = beg >> 14; wdw <= (end - 1) >> 14; wdw++) {
+                if ((size_t)wdw >= X.lin.size()) X.lin.resize((size_t)wdw + 1, 0);
+                if (!X.lin[(size_t)wdw]) X.lin[(size_t)wdw] = v0;
+            }
+            if (!X.n) X.beg = v0;
+            X.end = v1; X.n++;
         }
     }
     w.finish();
-    const bool ok = w.ok;
+    bool ok = w.ok;
     fclose(f);
+    if (ok) {
+        std::vector<uint8_t> bai = {'B', 'A', 'I', 1};
+        auto w64 = [&](uint64_t x) { for (int k = 0; k < 8; k++) bai.push_back((uint8_t)(x >> (8 * k))); };
+        w32(bai, (uint32_t)n_contigs);
+        for (auto& X : index) {
+            w32(bai, (uint32_t)X.bins.size() + (X.n ? 1u : 0u));
+            for (auto& kv : X.bins) {
+                w32(bai, kv.first); w32(bai, (uint32_t)kv.second.size());
+                for (auto& c : kv.second) { w64(c.first); w64(c.second); }
+            }
+            if (X.n) { w32(bai, 37450u); w32(bai, 2u); w64(X.beg); w64(X.end); w64(X.n); w64(0); }   // samtools' metadata pseudo-bin
+            for (size_t k = 1; k < X.lin.size(); k++) if (!X.lin[k]) X.lin[k] = X.lin[k - 1];
+            w32(bai, (uint32_t)X.lin.size());
+            for (uint64_t v : X.lin) w64(v);
+        }
+        FILE* g = fopen((std::string(path) + ".bai").c_str(), "wb");
+        ok = g && fwrite(bai.data(), 1, bai.size(), g) == bai.size();
+        if (g) fclose(g);
+    }
     return ok ? 0 : 2;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming ingest of ONE contig for the device-side record parser (libhimut_hip.so: himut_ingest_*): the host's part
+// is what has to be sequential or is cheap -- block inflate (thread pool) straight into a caller's (pinned) buffer,
+// the hop from length field to length field, the read-name table -- and the device does the rest (CIGAR walk, tag
+// scan, placement, byte copies).  With an index beside the file (x.bam.bai) only the contig's own BGZF blocks are
+// inflated; without one the blocks in front of it are inflated and hopped over.
+struct BamStream {
+    Bgzf z;
+    Bam hdr;
+    size_t first_block = 0, first_skip = 0;            // where the first record of the file starts
+    bool have_bai = false;
+    std::vector<std::pair<uint64_t, uint64_t>> ref_range;   // per contig: virtual offsets of its first record / end of its last
+    int32_t target = -1;
+    size_t blk = 0, blk_end = 0, skip = 0;
+    std::vector<uint8_t> carry;
+    std::unordered_map<std::string, int32_t> names;
+    int64_t nkept = 0;
+    bool done = false, unique = true;
+    std::string err;
+};
+
+static bool read_bai(const std::string& path, size_t n_ref, std::vector<std::pair<uint64_t, uint64_t>>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> d;
+    uint8_t tmp[1 << 16];
+    size_t k;
+    while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) d.insert(d.end(), tmp, tmp + k);
+    fclose(f);
+    size_t p = 0;
+    auto need = [&](size_t n) { return p + n <= d.size(); };
+    auto r32 = [&]() { const uint32_t v = le32(&d[p]); p += 4; return v; };
+    auto r64 = [&]() { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)d[p + i] << (8 * i); p += 8; return v; };
+    if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) return false;
+    p = 4;
+    const uint32_t n = r32();
+    if (n != n_ref) return false;
+    out.assign(n, {~0ull, 0ull});
+    for (uint32_t i = 0; i < n; i++) {
+        if (!need(4)) return false;
+        const uint32_t nbin = r32();
+        for (uint32_t b = 0; b < nbin; b++) {
+            if (!need(8)) return false;
+            const uint32_t bin = r32(), nch = r32();
+            if (!need(16ull * nch)) return false;
+            for (uint32_t c = 0; c < nch; c++) {
+                const uint64_t beg = r64(), end = r64();
+                if (bin == 37450) continue;
+                out[i].first = std::min(out[i].first, beg);
+                out[i].second = std::max(out[i].second, end);
+            }
+        }
+        if (!need(4)) return false;
+        const uint32_t nint = r32();
+        if (!need(8ull * nint)) return false;
+        p += 8ull * nint;
+    }
+    return true;
+}
+
+void* bam_stream_open(const char* path, int threads) {
+    BamStream* S = new BamStream();
+    try {
+        if (threads <= 0) {
+            const char* e = getenv("HIMUT_INGEST_THREADS");
+            threads = e ? atoi(e) : 0;
+            if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        }
+        Bgzf& z = S->z;
+        if (!z.open(path, threads)) { S->err = z.err; return S; }
+        size_t consumed = 0;
+        auto rd = [&](void* dst, size_t n) { if (!z.read(dst, n)) return false; consumed += n; return true; };
+        uint8_t b4[4];
+        if (!rd(b4, 4) || memcmp(b4, "BAM\1", 4) != 0) { S->err = z.err.empty() ? "not a BAM file" : z.err; return S; }
+        size_t inflated_total = 0;
+        for (const BlockRef& b : z.blocks) inflated_total += b.isize;
+        if (!rd(b4, 4)) { S->err = "truncated BAM header"; return S; }
+        const uint32_t l_text = le32(b4);
+        if ((size_t)l_text > inflated_total) { S->err = "BAM header text longer than the file"; return S; }
+        S->hdr.header_text.resize(l_text);
+        if (l_text && !rd(&S->hdr.header_text[0], l_text)) { S->err = "truncated BAM header"; return S; }
+        while (!S->hdr.header_text.empty() && S->hdr.header_text.back() == '\0') S->hdr.header_text.pop_back();
+        if (!rd(b4, 4)) { S->err = "truncated BAM header"; return S; }
+        const uint32_t n_ref = le32(b4);
+        if ((size_t)n_ref * 8 > inflated_total) { S->err = "BAM header lists more contigs than the file can hold"; return S; }
+        S->hdr.contigs.resize(n_ref);
+        for (uint32_t i = 0; i < n_ref; i++) {
+            if (!rd(b4, 4)) { S->err = "truncated BAM header"; return S; }
+            const uint32_t l_name = le32(b4);
+            if ((size_t)l_name > inflated_total) { S->err = "contig name longer than the file"; return S; }
+            std::string nm(l_name, '\0');
+            if (l_name && !rd(&nm[0], l_name)) { S->err = "truncated BAM header"; return S; }
+            while (!nm.empty() && nm.back() == '\0') nm.pop_back();
+            if (!rd(b4, 4)) { S->err = "truncated BAM header"; return S; }
+            S->hdr.contigs[i].name = nm;
+            S->hdr.contigs[i].length = le32(b4);
+        }
+        if (z.pending.valid()) (void)z.pending.get();       // the loader's read-ahead is not used from here on
+        size_t acc = 0;
+        for (size_t k = 0; k < z.blocks.size(); k++) {
+            if (consumed < acc + z.blocks[k].isize) { S->first_block = k; S->first_skip = consumed - acc; break; }
+            acc += z.blocks[k].isize;
+            S->first_block = k + 1; S->first_skip = 0;
+        }
+        z.buf[0].clear(); z.buf[0].shrink_to_fit(); z.buf[1].clear(); z.buf[1].shrink_to_fit();
+        if (!getenv("HIMUT_INGEST_NO_INDEX"))
+            S->have_bai = read_bai(std::string(path) + ".bai", n_ref, S->ref_range);
+    } catch (const std::exception& e) { S->err = std::string("BAM header: ") + e.what(); }
+    return S;
+}
+
+const char* bam_stream_error(void* h) { return ((BamStream*)h)->err.c_str(); }
+const char* bam_stream_header_text(void* h) { return ((BamStream*)h)->hdr.header_text.c_str(); }
+int64_t bam_stream_n_ref(void* h) { return (int64_t)((BamStream*)h)->hdr.contigs.size(); }
+const char* bam_stream_ref_name(void* h, int64_t i) { return ((BamStream*)h)->hdr.contigs[(size_t)i].name.c_str(); }
+int64_t bam_stream_ref_len(void* h, int64_t i) { return ((BamStream*)h)->hdr.contigs[(size_t)i].length; }
+int bam_stream_indexed(void* h) { return ((BamStream*)h)->have_bai ? 1 : 0; }
+int bam_stream_unique_names(void* h) { return ((BamStream*)h)->unique ? 1 : 0; }
+void bam_stream_close(void* h) { BamStream* S = (BamStream*)h; S->z.close(); delete S; }
+
+// Restricts the stream to one contig.  *inflated_bound = inflated bytes of the blocks that will be read (an upper
+// bound of the contig's record bytes when the file is indexed, of everything from the first record on otherwise).
+int bam_stream_select(void* h, int32_t ref_id, int64_t* inflated_bound) {
+    BamStream* S = (BamStream*)h;
+    if (ref_id < 0 || (size_t)ref_id >= S->hdr.contigs.size()) { S->err = "no such contig"; return 1; }
+    S->target = ref_id; S->carry.clear(); S->names.clear(); S->nkept = 0; S->done = false; S->unique = true;
+    const auto& B = S->z.blocks;
+    S->blk = S->first_block; S->skip = S->first_skip; S->blk_end = B.size();
+    if (S->have_bai) {
+        const auto rg = S->ref_range[(size_t)ref_id];
+        if (rg.first == ~0ull) { S->blk = S->blk_end = 0; S->done = true; }       // no records on this contig
+        else {
+            auto find = [&](uint64_t foff) { size_t lo = 0, hi = B.size(); while (lo < hi) { const size_t m = (lo + hi) / 2; if (B[m].file_off < foff) lo = m + 1; else hi = m; } return lo; };
+            const size_t b0 = find(rg.first >> 16), b1 = find(rg.second >> 16);
+            if (b0 >= B.size() || B[b0].file_off != (rg.first >> 16)) { S->err = "index does not match the BAM file"; return 1; }
+            S->blk = b0; S->skip = (size_t)(rg.first & 0xffff);
+            S->blk_end = std::min(B.size(), b1 + 1);
+        }
+    }
+    int64_t tot = 0;
+    for (size_t k = S->blk; k < S->blk_end; k++) tot += B[k].isize;
+    if (inflated_bound) *inflated_bound = tot;
+    return 0;
+}
+
+// Next window: inflates as many of the contig's blocks as fit ``cap`` bytes of dst (behind the partial record kept from
+// the window before), hops over the records and lists the kept ones (this contig, mapped): rec_off[k] = offset of record
+// k's body (behind its length field) in dst, qid[k] = index of the first kept record with the same read name.  *nbytes =
+// bytes of dst the records occupy.  Returns the number of kept records, -1 at the end of the contig, -2 on error.
+int64_t bam_stream_next(void* h, uint8_t* dst, int64_t cap, uint32_t* rec_off, int32_t* qid, int64_t rec_cap, int64_t* nbytes,
+                        int64_t* sums) {
+    BamStream* S = (BamStream*)h;
+    *nbytes = 0;
+    sums[0] = sums[1] = 0;      // of the kept records: query lengths rounded up to 32, bytes of the auxiliary fields
+    try {
+        const auto& B = S->z.blocks;
+        for (;;) {
+            if (S->done || (S->blk >= S->blk_end && S->carry.empty())) return -1;
+            size_t c = S->carry.size();
+            if ((int64_t)c >= cap) { S->err = "a BAM record is larger than the ingest window"; return -2; }
+            if (c) memcpy(dst, S->carry.data(), c);
+            S->carry.clear();
+            std::vector<size_t> off;
+            size_t tot = 0, b0 = S->blk, b1 = S->blk;
+            while (b1 < S->blk_end && (int64_t)(c + tot + B[b1].isize) <= cap) { off.push_back(c + tot); tot += B[b1].isize; b1++; }
+            if (b1 == b0 && b0 < S->blk_end) { S->err = "ingest window smaller than a BGZF block"; return -2; }
+            if (b1 > b0) {
+                const std::string e = S->z.inflate_blocks(b0, b1, dst, 0, &off);
+                if (!e.empty()) { S->err = e; return -2; }
+            }
+            S->blk = b1;
+            const size_t nb = c + tot;
+            size_t pos = S->skip;
+            S->skip = 0;
+            int64_t n = 0;
+            while (pos + 4 <= nb && n < rec_cap) {
+                const uint32_t bs = le32(dst + pos);
+                if (bs < 32) { S->err = "BAM record too short"; return -2; }
+                if (pos + 4 + (size_t)bs > nb) break;
+                const uint8_t* rec = dst + pos + 4;
+                const int32_t ref_id = (int32_t)le32(rec);
+                const uint16_t flag = le16(rec + 14);
+                if (ref_id > S->target || ref_id < 0) { S->done = true; break; }       // coordinate sorted: the contig is over
+                if (ref_id == S->target && !(flag & 4)) {
+                    const size_t l_qname = rec[8];
+                    if (32 + l_qname > bs) { S->err = "malformed BAM record"; return -2; }
+                    const char* qn = (const char*)rec + 32;
+                    auto it = S->names.emplace(std::string(qn, strnlen(qn, l_qname)), (int32_t)S->nkept);
+                    if (!it.second) S->unique = false;
+                    const uint64_t n_cigar = le16(rec + 12), l_seq = le32(rec + 16);
+                    const uint64_t fixed = 32 + l_qname + 4 * n_cigar + (l_seq + 1) / 2 + l_seq;
+                    if (fixed > bs) { S->err = "malformed BAM record"; return -2; }
+                    sums[0] += (int64_t)((l_seq + 31) & ~(uint64_t)31);
+                    sums[1] += (int64_t)(bs - fixed);
+                    rec_off[n] = (uint32_t)(pos + 4);
+                    qid[n] = it.first->second;
+                    S->nkept++; n++;
+                }
+                pos += 4 + (size_t)bs;
+            }
+            *nbytes = (int64_t)pos;
+            if (!S->done) {
+                if (pos < nb) S->carry.assign(dst + pos, dst + nb);
+                if (S->blk >= S->blk_end && !S->carry.empty() && n < rec_cap && S->carry.size() >= 4) {
+                    // the last block ended inside a record (an indexed range ends at the contig's last record, so what
+                    // is left belongs to the next contig or the file is truncated)
+                    if (!S->have_bai) { S->err = "truncated BAM record"; return -2; }
+                    S->carry.clear();
+                }
+            }
+            if (n > 0) return n;
+            if (S->done || (S->blk >= S->blk_end && S->carry.empty())) return -1;
+            // a window without kept records (another contig's in front of ours, no index): next one
+        }
+    } catch (const std::exception& e) { S->err = std::string("BAM stream: ") + e.what(); return -2; }
+}
+
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 #include "himut_hip.h"
 #include "himut_kernels.h"
 #include "himut_norm.h"
+#include "himut_ingest.h"
 
 using namespace himut;
 
@@ -47,6 +48,17 @@ struct DevBuf {
         size_t want = std::max<size_t>(bytes, 256);
         HCHECK(hipMalloc(&p, want));
         cap = want;
+    }
+    // grows to at least `bytes` keeping the first `used` bytes (the ingest's arrays grow while they are being filled)
+    void grow_keep(size_t bytes, size_t used) {
+        if (bytes <= cap && p) return;
+        const size_t want = std::max<size_t>(std::max(bytes, cap + cap / 2), 256);
+        void* q = nullptr;
+        HCHECK(hipDeviceSynchronize());
+        HCHECK(hipMalloc(&q, want));
+        if (p && used) HCHECK(hipMemcpy(q, p, std::min(used, cap), hipMemcpyDeviceToDevice));
+        if (p) HCHECK(hipFree(p));
+        p = q; cap = want;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -114,6 +126,13 @@ struct himut_ctx {
     int64_t cap_cand = 0, cap_slots = 0;
     int timing = 1;                          // himut_set_stage_timing: 0 total only, 1 + the column capture, 2 every stage
     bool mask_clean = false;                 // d_mask and d_tilecnt hold zeros only (k_mask_emit leaves them so)
+    // device-side BAM ingest (himut_ingest_*)
+    void* ing_pinned[2] = {nullptr, nullptr};
+    size_t ing_window = 0;
+    DevBuf d_stage[2], d_recoff[2], d_qidin[2], d_desc, d_sizes, d_offs, d_istate, d_tp;
+    hipEvent_t ing_copied[2] = {}, ing_parsed[2] = {};
+    bool ing_open = false, ing_used[2] = {false, false};
+    int64_t ing_reads = 0, ing_bases = 0, ing_cs = 0;   // capacity the windows so far may need (upper bounds)
     int64_t win_nblk = 0;                    // d_winlo / d_winhi hold the read windows of the pushed reads for this many
                                              // 256-position blocks (0: not computed yet)
     void* h_scalars = nullptr;               // pinned landing zone of the scalars block
@@ -700,6 +719,11 @@ void himut_destroy(himut_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    for (int k = 0; k < 2; k++) {
+        if (c->ing_pinned[k]) (void)hipHostFree(c->ing_pinned[k]);
+        if (c->ing_copied[k]) (void)hipEventDestroy(c->ing_copied[k]);
+        if (c->ing_parsed[k]) (void)hipEventDestroy(c->ing_parsed[k]);
+    }
     delete c;
 }
 
@@ -837,6 +861,184 @@ int himut_push_reads(himut_ctx* c, const himut_read_batch* b) {
         c->tables_valid = false;   // the chunk tables hold read windows
         c->win_nblk = 0;
         c->h_recs_valid = false;
+        return HIMUT_OK;
+    });
+}
+
+// ---- device-side BAM ingest: see include/himut_hip.h and csrc/himut_ingest.h
+int himut_ingest_begin(himut_ctx* c, int64_t inflated_bound, int64_t window_bytes) {
+    if (!c || inflated_bound < 0 || window_bytes < (1 << 16)) return fail(c, HIMUT_ERR_ARG, "bad ingest arguments");
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        HCHECK(hipStreamSynchronize(c->stream));
+        HCHECK(hipStreamSynchronize(c->side));
+        const size_t W = (size_t)window_bytes;
+        if (c->ing_window != W) {
+            for (int k = 0; k < 2; k++) {
+                if (c->ing_pinned[k]) { HCHECK(hipHostFree(c->ing_pinned[k])); c->ing_pinned[k] = nullptr; }
+                HCHECK(hipHostMalloc(&c->ing_pinned[k], W + 4096, hipHostMallocDefault));
+                if (!c->ing_copied[k]) HCHECK(hipEventCreateWithFlags(&c->ing_copied[k], hipEventDisableTiming));
+                if (!c->ing_parsed[k]) HCHECK(hipEventCreateWithFlags(&c->ing_parsed[k], hipEventDisableTiming));
+            }
+            c->ing_window = W;
+        }
+        for (int k = 0; k < 2; k++) { c->d_stage[k].reserve(W + 4096); c->ing_used[k] = false; }
+        // first sizes from what CCS records look like (two thirds of a record are qualities); the arrays grow if a
+        // window needs more
+        const size_t B = (size_t)inflated_bound;
+        c->d_bq.reserve(B * 7 / 10 + (1 << 20));
+        c->d_seq.reserve(B * 7 / 20 + (1 << 20));
+        c->d_cs.reserve(B / 16 + (1 << 20));
+        const size_t nr = B / 4000 + 4096;
+        c->d_tstart.reserve(nr * 4 + 256); c->d_tend.reserve(nr * 4 + 256); c->d_qstart.reserve(nr * 4 + 256); c->d_qlen.reserve(nr * 4 + 256);
+        c->d_qid.reserve(nr * 4 + 256); c->d_mapq.reserve(nr + 256); c->d_tp.reserve(nr + 256); c->d_flag.reserve(nr * 2 + 256);
+        c->d_qoff.reserve(nr * 8 + 256); c->d_csoff.reserve((nr + 1) * 8 + 256);
+        c->d_istate.reserve(sizeof(IngestState));
+        IngestState z;
+        memset(&z, 0, sizeof(z));
+        z.last_pos = -0x7fffffff - 1;
+        HCHECK(hipMemcpy(c->d_istate.p, &z, sizeof(z), hipMemcpyHostToDevice));
+        HCHECK(hipMemset(c->d_csoff.p, 0, 8));
+        c->ing_reads = c->ing_bases = c->ing_cs = 0;
+        c->ing_open = true;
+        c->have_reads = false; c->tables_valid = false; c->win_nblk = 0; c->h_recs_valid = false;
+        return HIMUT_OK;
+    });
+}
+
+void* himut_ingest_buffer(himut_ctx* c, int slot) { return (c && (slot == 0 || slot == 1)) ? c->ing_pinned[slot] : nullptr; }
+
+int himut_ingest_wait(himut_ctx* c, int slot) {
+    if (!c || (slot != 0 && slot != 1)) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int {
+        if (c->ing_used[slot]) HCHECK(hipEventSynchronize(c->ing_copied[slot]));
+        return HIMUT_OK;
+    });
+}
+
+int himut_ingest_window(himut_ctx* c, int slot, int64_t nbytes, const uint32_t* rec_off, const int32_t* qid, int64_t n_rec,
+                        int64_t padded_bases, int64_t tag_bytes) {
+    if (!c || (slot != 0 && slot != 1) || n_rec < 0 || nbytes < 0 || (n_rec && (!rec_off || !qid))) return fail(c, HIMUT_ERR_ARG, "bad ingest window");
+    if (!c->ing_open) return fail(c, HIMUT_ERR_ARG, "himut_ingest_begin has not been called");
+    if ((size_t)nbytes > c->ing_window) return fail(c, HIMUT_ERR_ARG, "ingest window larger than the buffer");
+    if (n_rec == 0) return HIMUT_OK;
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        hipStream_t st = c->stream, cp = c->side;
+        // room for this window's reads: exact for the per-read arrays and the bases, an upper bound for the cs text
+        const int64_t nr = c->ing_reads + n_rec, nb = c->ing_bases + padded_bases, nc = c->ing_cs + tag_bytes;
+        const size_t ur = (size_t)c->ing_reads;
+        c->d_tstart.grow_keep((size_t)nr * 4 + 256, ur * 4); c->d_tend.grow_keep((size_t)nr * 4 + 256, ur * 4);
+        c->d_qstart.grow_keep((size_t)nr * 4 + 256, ur * 4); c->d_qlen.grow_keep((size_t)nr * 4 + 256, ur * 4);
+        c->d_qid.grow_keep((size_t)nr * 4 + 256, ur * 4); c->d_mapq.grow_keep((size_t)nr + 256, ur); c->d_tp.grow_keep((size_t)nr + 256, ur);
+        c->d_flag.grow_keep((size_t)nr * 2 + 256, ur * 2); c->d_qoff.grow_keep((size_t)nr * 8 + 256, ur * 8);
+        c->d_csoff.grow_keep((size_t)(nr + 1) * 8 + 256, (ur + 1) * 8);
+        c->d_bq.grow_keep((size_t)nb + 256, (size_t)c->ing_bases); c->d_seq.grow_keep((size_t)nb / 2 + 256, (size_t)c->ing_bases / 2);
+        c->d_cs.grow_keep((size_t)nc + 2048 + 256, (size_t)c->ing_cs);
+        c->d_recoff[slot].reserve((size_t)n_rec * 4 + 256); c->d_qidin[slot].reserve((size_t)n_rec * 4 + 256);
+        c->d_desc.reserve((size_t)n_rec * sizeof(RecDesc) + 256);
+        c->d_sizes.reserve((size_t)n_rec * 8 + 256); c->d_offs.reserve((size_t)n_rec * 8 + 256);
+        size_t scan_b = 0;
+        HCHECK(rocprim::exclusive_scan(nullptr, scan_b, c->d_sizes.as<uint2>(), c->d_offs.as<uint2>(), make_uint2(0u, 0u), (size_t)n_rec, PlusU2(), st));
+        c->d_tmp.reserve(scan_b + 256);
+        // copy stream: the window's bytes (pinned -> HBM) once the parse of the window that used this staging buffer is over
+        if (c->ing_used[slot]) HCHECK(hipStreamWaitEvent(cp, c->ing_parsed[slot], 0));
+        HCHECK(hipMemcpyAsync(c->d_stage[slot].p, c->ing_pinned[slot], (size_t)nbytes, hipMemcpyHostToDevice, cp));
+        HCHECK(hipEventRecord(c->ing_copied[slot], cp));
+        c->ing_used[slot] = true;
+        // compute stream: record list, decode, offsets, scatter
+        HCHECK(hipMemcpyAsync(c->d_recoff[slot].p, rec_off, (size_t)n_rec * 4, hipMemcpyHostToDevice, st));
+        HCHECK(hipMemcpyAsync(c->d_qidin[slot].p, qid, (size_t)n_rec * 4, hipMemcpyHostToDevice, st));
+        HCHECK(hipStreamWaitEvent(st, c->ing_copied[slot], 0));
+        const uint8_t* win = c->d_stage[slot].as<uint8_t>();
+        hipLaunchKernelGGL(k_bam_decode, dim3(blocks_for(n_rec, 256)), dim3(256), 0, st, win, nbytes, c->d_recoff[slot].as<uint32_t>(), n_rec,
+                           c->d_desc.as<RecDesc>(), c->d_sizes.as<uint2>());
+        HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_b, c->d_sizes.as<uint2>(), c->d_offs.as<uint2>(), make_uint2(0u, 0u), (size_t)n_rec, PlusU2(), st));
+        IngestOut O;
+        O.tstart = c->d_tstart.as<int32_t>(); O.tend = c->d_tend.as<int32_t>(); O.qstart = c->d_qstart.as<int32_t>(); O.qlen = c->d_qlen.as<int32_t>();
+        O.qid = c->d_qid.as<int32_t>(); O.mapq = c->d_mapq.as<uint8_t>(); O.tp = c->d_tp.as<uint8_t>(); O.flag = c->d_flag.as<uint16_t>();
+        O.qoff = c->d_qoff.as<int64_t>(); O.cs_off = c->d_csoff.as<int64_t>();
+        O.seq = c->d_seq.as<uint8_t>(); O.bq = c->d_bq.as<uint8_t>(); O.cs = c->d_cs.as<uint8_t>();
+        O.cap_reads = nr; O.cap_bases = nb; O.cap_cs = nc;
+        hipLaunchKernelGGL(k_bam_scatter, dim3(blocks_for(n_rec, 4)), dim3(256), 0, st, win, c->d_desc.as<RecDesc>(), c->d_offs.as<uint2>(),
+                           c->d_qidin[slot].as<int32_t>(), n_rec, O, c->d_istate.as<IngestState>());
+        hipLaunchKernelGGL(k_bam_advance, dim3(1), dim3(64), 0, st, c->d_desc.as<RecDesc>(), c->d_sizes.as<uint2>(), c->d_offs.as<uint2>(), n_rec,
+                           c->d_istate.as<IngestState>(), c->d_csoff.as<int64_t>(), nr);
+        HCHECK(hipEventRecord(c->ing_parsed[slot], st));
+        c->ing_reads = nr; c->ing_bases = nb; c->ing_cs = nc;
+        return HIMUT_OK;
+    });
+}
+
+int himut_ingest_end(himut_ctx* c, int unique_qnames, himut_ingest_result* out) {
+    if (!c || !out) return HIMUT_ERR_ARG;
+    if (!c->ing_open) return fail(c, HIMUT_ERR_ARG, "himut_ingest_begin has not been called");
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        HCHECK(hipStreamSynchronize(c->side));
+        HCHECK(hipStreamSynchronize(st));
+        c->ing_open = false;
+        IngestState S;
+        HCHECK(hipMemcpy(&S, c->d_istate.p, sizeof(S), hipMemcpyDeviceToHost));
+        memset(out, 0, sizeof(*out));
+        out->n_reads = (int64_t)S.n_reads; out->bases_padded = (int64_t)S.bases_padded; out->cs_bytes = (int64_t)S.cs_n;
+        out->read_bases = (int64_t)S.read_bases; out->n_missing_cs = (int64_t)S.n_missing_cs; out->n_unsorted = (int64_t)S.n_unsorted;
+        out->n_malformed = (int64_t)S.n_bad;
+        if (S.overflow) return fail(c, HIMUT_ERR_NOMEM, "ingest: a window needed more room than the host announced");
+        if (S.n_bad) return fail(c, HIMUT_ERR_ARG, "malformed BAM record");
+        const int64_t n = (int64_t)S.n_reads;
+        c->n = n; c->cs_bytes = (int64_t)S.cs_n; c->bq_bytes = (int64_t)S.bases_padded; c->seq_bytes = (int64_t)S.bases_padded / 2;
+        c->read_bases = (int64_t)S.read_bases;
+        c->unique_qnames = unique_qnames != 0;
+        c->any_longcs = S.any_longcs != 0;
+        c->h_tstart.resize((size_t)n); c->h_tend.resize((size_t)n); c->h_prefmax.resize((size_t)n);
+        if (n) {
+            HCHECK(hipMemcpy(c->h_tstart.data(), c->d_tstart.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+            HCHECK(hipMemcpy(c->h_tend.data(), c->d_tend.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        }
+        int32_t run = INT32_MIN;
+        for (int64_t i = 0; i < n; i++) { run = std::max(run, c->h_tend[(size_t)i]); c->h_prefmax[(size_t)i] = run; }
+        upload(c->d_prefmax, c->h_prefmax, st);
+        // the kernels read whole 16 / 32-byte windows and 1 KB of cs text past the end: the arrays carry that slack
+        c->d_cs.grow_keep((size_t)S.cs_n + 2048 + 256, (size_t)S.cs_n);
+        HCHECK(hipStreamSynchronize(st));
+        c->have_reads = S.n_unsorted == 0 && S.n_missing_cs == 0;
+        c->tables_valid = false; c->win_nblk = 0; c->h_recs_valid = false;
+        return HIMUT_OK;
+    });
+}
+
+int himut_ingest_read_meta(himut_ctx* c, int32_t* tstart, int32_t* tend, int32_t* qlen, uint8_t* mapq, uint8_t* tp) {
+    if (!c) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        const size_t n = (size_t)c->n;
+        if (!n) return HIMUT_OK;
+        if (tstart) HCHECK(hipMemcpy(tstart, c->d_tstart.p, n * 4, hipMemcpyDeviceToHost));
+        if (tend) HCHECK(hipMemcpy(tend, c->d_tend.p, n * 4, hipMemcpyDeviceToHost));
+        if (qlen) HCHECK(hipMemcpy(qlen, c->d_qlen.p, n * 4, hipMemcpyDeviceToHost));
+        if (mapq) HCHECK(hipMemcpy(mapq, c->d_mapq.p, n, hipMemcpyDeviceToHost));
+        if (tp) HCHECK(hipMemcpy(tp, c->d_tp.p, n, hipMemcpyDeviceToHost));
+        return HIMUT_OK;
+    });
+}
+
+// The read batch as it sits in HBM, back on the host (tests: the device-parsed batch against the host-parsed one).
+int himut_download_reads(himut_ctx* c, himut_read_batch* b, uint8_t* tp) {
+    if (!c || !b) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        const size_t n = (size_t)c->n;
+        if (b->n_reads < c->n || b->seq_bytes < c->seq_bytes || b->bq_bytes < c->bq_bytes || b->cs_bytes < c->cs_bytes)
+            return fail(c, HIMUT_ERR_ARG, "destination batch too small");
+        auto down = [&](const void* dst, const DevBuf& src, size_t bytes) { if (bytes) HCHECK(hipMemcpy(const_cast<void*>(dst), src.p, bytes, hipMemcpyDeviceToHost)); };
+        down(b->tstart, c->d_tstart, n * 4); down(b->tend, c->d_tend, n * 4); down(b->qstart, c->d_qstart, n * 4); down(b->qlen, c->d_qlen, n * 4);
+        down(b->mapq, c->d_mapq, n); down(b->flag, c->d_flag, n * 2); down(b->qid, c->d_qid, n * 4); down(b->qoff, c->d_qoff, n * 8);
+        down(b->cs_off, c->d_csoff, (n + 1) * 8);
+        down(b->seq, c->d_seq, (size_t)c->seq_bytes); down(b->bq, c->d_bq, (size_t)c->bq_bytes); down(b->cs, c->d_cs, (size_t)c->cs_bytes);
+        if (tp) down(tp, c->d_tp, n);
+        b->n_reads = c->n; b->seq_bytes = c->seq_bytes; b->bq_bytes = c->bq_bytes; b->cs_bytes = c->cs_bytes;
         return HIMUT_OK;
     });
 }

@@ -194,6 +194,34 @@ int himut_set_stage_timing(himut_ctx* ctx, int level);
 int himut_records_device(himut_ctx* ctx, const void** dev_ptr, int64_t* n);
 int himut_copy_records_to_device(himut_ctx* ctx, void* dst_device, int64_t capacity_records);
 
+/* ---- next row: the BAM ingest in front of the path (reference call sites caller.py:267,299:
+ * pysam.AlignmentFile + alignments.fetch, and the record wrapper bamlib.BAM.__init__, bamlib.py:14-32).
+ * An alternative to himut_push_reads: the contig's inflated BAM records go to HBM a window at a time and are parsed
+ * there (CIGAR walk, tag scan, placement, byte copies: csrc/himut_ingest.h).  The caller inflates BGZF blocks straight
+ * into one of the library's two pinned buffers (himut_ingest_buffer), lists where the records of the contig start
+ * (rec_off: offset of each record's body, i.e. behind its block_size field) and which earlier record carries the same
+ * read name (qid, as in himut_read_batch), and hands the window over; the copy of window k overlaps the inflate of
+ * window k + 1 (two buffers: himut_ingest_wait(slot) returns once slot's bytes have left the host).  padded_bases =
+ * sum of the records' l_seq rounded up to 32, tag_bytes = an upper bound of the cs text in the window (the bytes of
+ * the records' auxiliary fields): what the library must have room for.  himut_ingest_end leaves the context as
+ * himut_push_reads would.  libhimut_host.so's bam_stream_* (csrc/bam_ingest.cpp) is the host side that goes with it. */
+typedef struct himut_ingest_result {
+    int64_t n_reads, bases_padded, cs_bytes, read_bases;
+    int64_t n_missing_cs;       /* records without a cs tag (the reference's get_tag("cs") raises KeyError, bamlib.py:32) */
+    int64_t n_unsorted;         /* records in front of their predecessor: not coordinate sorted */
+    int64_t n_malformed;
+} himut_ingest_result;
+int himut_ingest_begin(himut_ctx* ctx, int64_t inflated_bytes_bound, int64_t window_bytes);
+void* himut_ingest_buffer(himut_ctx* ctx, int slot);
+int himut_ingest_wait(himut_ctx* ctx, int slot);
+int himut_ingest_window(himut_ctx* ctx, int slot, int64_t nbytes, const uint32_t* rec_off, const int32_t* qid, int64_t n_rec,
+                        int64_t padded_bases, int64_t tag_bytes);
+int himut_ingest_end(himut_ctx* ctx, int unique_qnames, himut_ingest_result* out);
+/* per-read fields the host needs for bamlib.get_thresholds (bamlib.py:137-178); any pointer may be null */
+int himut_ingest_read_meta(himut_ctx* ctx, int32_t* tstart, int32_t* tend, int32_t* qlen, uint8_t* mapq, uint8_t* tp);
+/* the resident read batch back on the host (arrays of the caller, sized by the fields of `batch` on entry) */
+int himut_download_reads(himut_ctx* ctx, himut_read_batch* batch, uint8_t* tp);
+
 /* ---- next row: normcounts.get_callable_tricounts ---------------------------------
  * The worker's arguments (normcounts.py:206-241) map onto the same calls as the call path
  * (params, LUT, chunks, site sets, phase sets, reads) plus the contig's reference string:

@@ -32,8 +32,8 @@ def test_roundtrip_two_contigs(tmp_path):
     f.batches["chr2"].validate()
 
 
-def test_reader_on_hand_packed_record(tmp_path):
-    """One record packed by hand from the SAM/BAM specification (not by our writer)."""
+def hand_packed_bam(path):
+    """One record packed by hand from the SAM/BAM specification (not by our writer); returns (seq, qual)."""
     text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:ctg\tLN:1000\n@RG\tID:x\tSM:hand\n"
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 4) + b"ctg\0" + \
         struct.pack("<i", 1000)
@@ -60,15 +60,24 @@ def test_reader_on_hand_packed_record(tmp_path):
         bsize = len(comp) + 25
         return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + comp +
                 struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
-    path = tmp_path / "hand.bam"
-    path.write_bytes(bgzf(raw) + bgzf(b""))
-    f = bamio.read_bam(str(path))
-    b = f.batches["ctg"]
-    assert b.n == 1 and f.sample() == "hand"
+    with open(path, "wb") as o:
+        o.write(bgzf(raw) + bgzf(b""))
+    return seq, qual
+
+
+def check_hand_packed(b, sample, seq, qual):
+    assert b.n == 1 and sample == "hand"
     assert (int(b.tstart[0]), int(b.tend[0]), int(b.qstart[0]), int(b.qlen[0])) == (99, 99 + 12, 2, 13)
     assert int(b.mapq[0]) == 60 and int(b.flag[0]) == 16 and chr(int(b.tp[0])) == "P"
     assert b.query_sequence(0) == seq and list(b.query_qualities(0)) == list(qual)
     assert b.cs_tag(0) == ":5+t:3-ag:2"
+
+
+def test_reader_on_hand_packed_record(tmp_path):
+    path = tmp_path / "hand.bam"
+    seq, qual = hand_packed_bam(str(path))
+    f = bamio.read_bam(str(path))
+    check_hand_packed(f.batches["ctg"], f.sample(), seq, qual)
 
 
 def test_missing_cs_tag_is_an_error(tmp_path):
