@@ -121,8 +121,8 @@ def lib():
     L.himut_ingest_begin.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
     L.himut_ingest_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.himut_ingest_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    L.himut_ingest_window.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                      ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    L.himut_ingest_window.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
     L.himut_ingest_end.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(IngestResult)]
     L.himut_ingest_read_meta.argtypes = [ctypes.c_void_p] * 6
     L.himut_download_reads.argtypes = [ctypes.c_void_p, ctypes.POINTER(ReadBatchStruct), ctypes.c_void_p]
@@ -285,9 +285,9 @@ class Context:
     def ingest_wait(self, slot):
         self._check(self._L.himut_ingest_wait(self._h, int(slot)))
 
-    def ingest_window(self, slot, nbytes, rec_off, qid, n_rec, padded_bases, tag_bytes):
-        self._check(self._L.himut_ingest_window(self._h, int(slot), int(nbytes), _ptr(rec_off), _ptr(qid), int(n_rec),
-                                                int(padded_bases), int(tag_bytes)))
+    def ingest_window(self, slot, start, nbytes, rec_off, qid, n_rec, padded_bases, tag_bytes):
+        self._check(self._L.himut_ingest_window(self._h, int(slot), int(start), int(nbytes), _ptr(rec_off), _ptr(qid),
+                                                int(n_rec), int(padded_bases), int(tag_bytes)))
 
     def ingest_end(self, unique_qnames):
         r = IngestResult()

@@ -71,7 +71,12 @@ def _load():
         L.bam_stream_select.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
         L.bam_stream_next.restype = ctypes.c_int64
         L.bam_stream_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                      ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]
+                                      ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                      ctypes.c_void_p]
+        L.bam_stream_prefetch.restype = ctypes.c_int
+        L.bam_stream_prefetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        L.bam_stream_head.restype = ctypes.c_int64
+        L.bam_stream_head.argtypes = []
         L.bam_write.restype = ctypes.c_int
         L.bam_write.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_WriteContig), ctypes.c_int64]
         _lib = L
@@ -193,22 +198,33 @@ class BamStream:
         bound = ctypes.c_int64()
         if L.bam_stream_select(h, self.names.index(chrom), ctypes.byref(bound)):
             raise ValueError(L.bam_stream_error(h).decode())
-        bufs = ctx.ingest_begin(bound.value, window_bytes)
+        cap = window_bytes + L.bam_stream_head()       # head room for the record a window boundary cuts
+        bufs = ctx.ingest_begin(bound.value, cap)
         rec_cap = window_bytes // 64 + 16
         rec_off = [np.zeros(rec_cap, np.uint32) for _ in (0, 1)]
         qid = [np.zeros(rec_cap, np.int32) for _ in (0, 1)]
-        nbytes = ctypes.c_int64()
+        start, nbytes = ctypes.c_int64(), ctypes.c_int64()
         sums = np.zeros(2, np.int64)
+
+        def fail():
+            raise ValueError("{}: {}".format(self.path, L.bam_stream_error(h).decode()))
         slot = 0
+        if L.bam_stream_prefetch(h, bufs[0], cap) < 0:
+            fail()
         while True:
-            ctx.ingest_wait(slot)                     # the bytes this buffer held two windows ago have left the host
-            n = L.bam_stream_next(h, bufs[slot], window_bytes, _p(rec_off[slot]), _p(qid[slot]), rec_cap,
+            n = L.bam_stream_next(h, bufs[slot], cap, _p(rec_off[slot]), _p(qid[slot]), rec_cap, ctypes.byref(start),
                                   ctypes.byref(nbytes), _p(sums))
             if n == -1:
                 break
             if n < 0:
-                raise ValueError("{}: {}".format(self.path, L.bam_stream_error(h).decode()))
-            ctx.ingest_window(slot, nbytes.value, rec_off[slot], qid[slot], n, int(sums[0]), int(sums[1]))
+                fail()
+            # the pool goes on with the next window (into the other buffer, once its bytes of two windows ago have left
+            # the host) while this one is handed to the GPU
+            ctx.ingest_wait(slot ^ 1)
+            if L.bam_stream_prefetch(h, bufs[slot ^ 1], cap) < 0:
+                fail()
+            if n > 0:
+                ctx.ingest_window(slot, start.value, nbytes.value, rec_off[slot], qid[slot], n, int(sums[0]), int(sums[1]))
             slot ^= 1
         res = ctx.ingest_end(bool(L.bam_stream_unique_names(h)))
         if res["n_missing_cs"]:

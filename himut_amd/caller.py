@@ -112,6 +112,17 @@ class Worker:
         ctx.run()
         return ctx.records(), ctx.log()
 
+    def call_resident(self, chunks, pon_keys=None, common_keys=None, phase_sets=None):
+        """The same on the reads the context already holds (bamio.BamStream.ingest_contig put them in HBM)."""
+        ctx = self.ctx
+        ctx.set_chunks(chunks)
+        ctx.set_site_set(0, pon_keys if pon_keys is not None else np.zeros(0, np.uint64))
+        ctx.set_site_set(1, common_keys if common_keys is not None else np.zeros(0, np.uint64))
+        if phase_sets is not None:
+            ctx.set_phase(*pack_phase_sets(chunks, *phase_sets))
+        ctx.run()
+        return ctx.records(), ctx.log()
+
 
 _default_worker = {}
 
@@ -129,7 +140,7 @@ def get_somatic_substitutions(
     phase_set2hetsnp_lst, min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq,
     min_trim, max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
     somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample, create_panel_of_normals,
-    chrom2tsbs_lst, chrom2tsbs_log, device=0, read_batch=None, chrom2records=None,
+    chrom2tsbs_lst, chrom2tsbs_log, device=0, read_batch=None, chrom2records=None, resident_worker=None,
 ):
     """Drop-in for himut.caller.get_somatic_substitutions (caller.py:208).
 
@@ -149,16 +160,19 @@ def get_somatic_substitutions(
         pon_keys = site_keys(vcflib.load_pon(chrom, panel_of_normals))
     elif panel_of_normals is not None and human and panel_of_normals.endswith(".bgz"):  # caller.py:280-289
         pon_keys = site_keys(vcflib.load_bgz_pon(chrom, panel_of_normals))
-    if read_batch is None:
+    if resident_worker is None and read_batch is None:
         from . import bamio
         read_batch = bamio.read_contig(bam_file, chrom)
-    w = _worker_for(device)
+    w = resident_worker if resident_worker is not None else _worker_for(device)
     w.configure(min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
                 max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
                 germline_snv_prior, phase)
     chunks = [(int(s), int(e)) for (_c, s, e) in chunkloci_lst]
     phase_sets = (phase_set2hbit_lst, phase_set2hpos_lst, phase_set2hetsnp_lst) if phase else None
-    recs, log = w.call_contig(read_batch, chunks, pon_keys, com_keys, phase_sets)
+    if resident_worker is not None:     # the contig's reads are in HBM already (device-side ingest)
+        recs, log = w.call_resident(chunks, pon_keys, com_keys, phase_sets)
+    else:
+        recs, log = w.call_contig(read_batch, chunks, pon_keys, com_keys, phase_sets)
     if chrom2records is not None:       # the driver prints from the integer records (vcflib.dump_records)
         chrom2records[chrom] = recs
     else:
@@ -187,20 +201,42 @@ def call_somatic_substitutions(
     if not out_file.endswith(".vcf"):
         raise ValueError("VCF file must have .vcf suffix")
     group = dist.join_group(devices)       # (rank, world, device) under torch.distributed.run, else None
-    bam = bamio.read_bam(bam_file)
+    bam = bamio.BamStream(bam_file, threads if threads and threads > 1 else 0)
     tname2tsize = bam.tname2tsize
     chrom_lst, chrom2chunkloci_lst = util.load_loci(region, region_list, tname2tsize)       # caller.py:681-682
     ps2hbit, ps2hpos, ps2hetsnp = {}, {}, {}
     if phase:                                                                               # caller.py:683-689
         ps2hbit, ps2hpos, ps2hetsnp, chrom2chunkloci_lst = vcflib.load_phased_hetsnps(phased_vcf_file, chrom_lst,
                                                                                       tname2tsize)
-    if group is None or group[0] == 0:
-        qlen_lower_limit, qlen_upper_limit, md_threshold = bamlib.get_thresholds(bam.batches, chrom_lst, tname2tsize)
+    # The contigs are the unit of work (the reference's starmap axis, caller.py:766-810): this process takes its share
+    # -- its rank's under torch.distributed.run, else everything, spread over ``devices`` -- and brings ONLY those
+    # contigs' BGZF blocks in (the index beside the BAM says where they are): inflated by the host pool into pinned
+    # windows, parsed and placed by the GPU, one resident context per contig.
+    sizes = {c: tname2tsize[c] for c in chrom_lst}
+    devices = list(devices) or [0]
+    if group is not None:
+        rank, world, dev = group
+        share = [(c, dev) for c in dist.lpt_assign(sizes, world)[rank]]
     else:
-        qlen_lower_limit = qlen_upper_limit = md_threshold = 0
-    if group is not None:                  # the sampled thresholds are global: rank 0's three scalars go to everyone
-        qlen_lower_limit, qlen_upper_limit, md_threshold = dist.broadcast_ints(
-            [qlen_lower_limit, qlen_upper_limit, md_threshold])
+        share = [(c, d) for d, contigs in zip(devices, dist.lpt_assign(sizes, len(devices))) for c in contigs]
+    starts = bamlib.sample_starts(chrom_lst, tname2tsize)
+    resident, samples = {}, {}
+    for chrom, dev in share:
+        w = Worker(dev)
+        res = bam.ingest_contig(w.ctx, chrom)
+        ts, te, ql_, mq_, tp_ = w.ctx.ingest_read_meta(res["n_reads"])
+        # the thresholds are global (bamlib.py:137-178): what each contig contributes are the query lengths over its
+        # sampled windows, a few thousand integers
+        samples[chrom] = bamlib.sample_qlens(ts, te, ql_, mq_, tp_, starts[chrom])
+        resident[chrom] = w
+    if group is not None:
+        import torch.distributed as tdist
+        parts = [None] * group[1]
+        tdist.all_gather_object(parts, samples)
+        samples = {}
+        for p_ in parts:
+            samples.update(p_)
+    qlen_lower_limit, qlen_upper_limit, md_threshold = bamlib.thresholds_from_samples(samples, chrom_lst)
     if create_panel_of_normals:                                                             # caller.py:707-718
         (min_bq, min_gq, min_qv, min_mapq, min_trim, min_hap_count, min_sequence_identity, phase) = util.load_pon_params()
     if non_human_sample:                                                                    # caller.py:720-723
@@ -214,7 +250,6 @@ def call_somatic_substitutions(
         somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample, reference_sample,
         create_panel_of_normals, version, out_file, bam.sample())
     chrom2tsbs_lst, chrom2tsbs_log, chrom2records = {}, {}, {}
-    devices = list(devices) or [0]
 
     def scan(chrom, dev):
         get_somatic_substitutions(
@@ -223,17 +258,16 @@ def call_somatic_substitutions(
             qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
             max_mismatch_count, mismatch_window_size, md_threshold, min_ref_count, min_alt_count, min_hap_count,
             somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample,
-            create_panel_of_normals, chrom2tsbs_lst, chrom2tsbs_log, device=dev, read_batch=bam.batches[chrom],
+            create_panel_of_normals, chrom2tsbs_lst, chrom2tsbs_log, device=dev, resident_worker=resident[chrom],
             chrom2records=chrom2records)
 
-    sizes = {c: tname2tsize[c] for c in chrom_lst}
+    for chrom, dev in share:
+        scan(chrom, dev)
+        resident.pop(chrom).close()            # the contig's reads leave HBM
     if group is not None:
-        # one process per GPU (torch.distributed.run): this rank scans its share of the contigs -- the reference's
-        # starmap axis, caller.py:766-810 -- and one exchange at the end brings every contig's record buffer and
+        # one process per GPU (torch.distributed.run): one exchange at the end brings every contig's record buffer and
         # counters to rank 0, which writes the files
         rank, world, dev = group
-        for chrom in dist.lpt_assign(sizes, world)[rank]:
-            scan(chrom, dev)
         res = dist.gather_contig_results({c: (chrom2records[c], chrom2tsbs_log[c]) for c in chrom2records},
                                          chrom_lst, rank, world)
         if rank != 0:
@@ -241,10 +275,6 @@ def call_somatic_substitutions(
             return None, None
         chrom2records = {c: r for c, (r, _) in res.items()}
         chrom2tsbs_log = {c: l for c, (_, l) in res.items()}
-    else:
-        for dev, contigs in zip(devices, dist.lpt_assign(sizes, len(devices))):
-            for chrom in contigs:
-                scan(chrom, dev)
     vcflib.dump_call_log(chrom_lst, chrom2tsbs_log, path=log_path)                         # caller.py:812-817
     vcflib.dump_records(out_file, vcf_header, chrom_lst, chrom2records, bool(phase))       # = dump_sbs / dump_phased_sbs
     print("himut single molecule somatic mutation detection took {} minutes".format((time.time() - t0) / 60))

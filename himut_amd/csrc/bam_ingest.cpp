@@ -123,11 +123,19 @@ struct Bgzf {
     bool scan() {
         size_t p = 0, wbytes = 0;
         win_first.push_back(0);
+        // the block headers are read with pread (a few bytes each) rather than through the mapping: a page fault per
+        // block costs several times more, and the pages are faulted in by the inflate threads in parallel anyway
+        uint8_t hb[64], tb[4];
         while (p < fsize) {
             if (p + 18 > fsize) { err = "truncated BGZF header"; return false; }
             const uint8_t* h = base + p;
+            if (fd >= 0 && owned.empty()) {
+                const size_t want = std::min<size_t>(sizeof(hb), fsize - p);
+                if (::pread(fd, hb, want, (off_t)p) == (ssize_t)want) h = hb;
+            }
             if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
             const unsigned xlen = h[10] | (h[11] << 8);
+            if (h == hb && 12 + xlen > sizeof(hb)) h = base + p;          // unusually long extra field: through the mapping
             if (p + 12 + xlen > fsize) { err = "truncated BGZF header"; return false; }
             int bsize = -1;
             for (size_t k = 0; k + 4 <= xlen;) {      // BC is normally the first subfield; tolerate others
@@ -144,6 +152,7 @@ struct Bgzf {
             b.cdata_off = p + 12 + xlen;
             b.cdata_len = (uint32_t)(total - 12 - xlen - 8);
             const uint8_t* t = base + p + total - 4;
+            if (fd >= 0 && owned.empty() && ::pread(fd, tb, 4, (off_t)(p + total - 4)) == 4) t = tb;
             b.isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
             if (wbytes && wbytes + b.isize > WINDOW) { win_first.push_back(blocks.size()); wbytes = 0; }
             b.uoff = wbytes;
@@ -174,18 +183,26 @@ struct Bgzf {
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
             if (!dec && inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+            // The compressed bytes are taken with pread into a buffer of the thread's own: through the shared mapping every
+            // first touch of a page is a fault that takes the address space's lock, and the pool's threads queue up on it.
+            std::vector<uint8_t> cbuf;
+            const bool use_pread = fd >= 0 && owned.empty() && !getenv("HIMUT_INGEST_MMAP");
+            if (use_pread) cbuf.resize(1 << 16);
             for (;;) {
                 const size_t k = next.fetch_add(1);
                 if (k >= b1) break;
                 const BlockRef& b = blocks[k];
                 if (!b.isize) continue;
                 uint8_t* to = packed_off ? dst + (*packed_off)[k - b0] : dst + (b.uoff - base_uoff);
+                const uint8_t* cin = base + b.cdata_off;
+                if (use_pread && b.cdata_len <= cbuf.size() && ::pread(fd, cbuf.data(), b.cdata_len, (off_t)b.cdata_off) == (ssize_t)b.cdata_len)
+                    cin = cbuf.data();
                 if (dec) {
                     size_t got = 0;
-                    if (L.run(dec, base + b.cdata_off, b.cdata_len, to, b.isize, &got) != 0 || got != b.isize) { bad = 2; break; }
+                    if (L.run(dec, cin, b.cdata_len, to, b.isize, &got) != 0 || got != b.isize) { bad = 2; break; }
                 } else {
                     inflateReset(&zs);
-                    zs.next_in = (Bytef*)(base + b.cdata_off); zs.avail_in = b.cdata_len;
+                    zs.next_in = (Bytef*)cin; zs.avail_in = b.cdata_len;
                     zs.next_out = to; zs.avail_out = b.isize;
                     if (inflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 2; break; }
                 }
@@ -694,7 +711,7 @@ static bool vcf_format_slice(const void* records, int64_t k0, int64_t k1, const 
 // VCF body lines of n records into out (cap bytes); returns the length, or -1 when cap is too small.  Large inputs
 // are formatted by a few threads, a slice of the records each, and the slices are laid end to end.
 int64_t vcf_format_records(const void* records, int64_t n, const char* chrom, int phased, int sm_file, char* out, int64_t cap) {
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, n / 20000, (int64_t)std::thread::hardware_concurrency()}));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)32, n / 8000, (int64_t)std::thread::hardware_concurrency()}));
     std::vector<std::string> part((size_t)nt);
     std::vector<char> ok((size_t)nt, 1);
     auto work = [&](int t) {
@@ -873,7 +890,14 @@ struct BamStream {
     int64_t nkept = 0;
     bool done = false, unique = true;
     std::string err;
+    double t_inflate = 0, t_hop = 0;      // HIMUT_INGEST_PROFILE
+    int64_t n_windows = 0;
+    std::future<std::string> inflating;   // the window being inflated in the background (bam_stream_prefetch)
+    std::vector<size_t> inf_off;
+    size_t inf_tot = 0;
+    uint8_t* inf_buf = nullptr;
 };
+constexpr size_t BAM_STREAM_HEAD = (size_t)4 << 20;
 
 static bool read_bai(const std::string& path, size_t n_ref, std::vector<std::pair<uint64_t, uint64_t>>& out) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -924,8 +948,22 @@ void* bam_stream_open(const char* path, int threads) {
         }
         Bgzf& z = S->z;
         if (!z.open(path, threads)) { S->err = z.err; return S; }
-        size_t consumed = 0;
-        auto rd = [&](void* dst, size_t n) { if (!z.read(dst, n)) return false; consumed += n; return true; };
+        // the header sits in the first block or two: they are inflated one at a time, not a window at a time
+        size_t consumed = 0, hb_next = 0;
+        std::vector<uint8_t> hbuf;
+        auto rd = [&](void* dst, size_t n) {
+            while (hbuf.size() < consumed + n) {
+                if (hb_next >= z.blocks.size()) return false;
+                const size_t at = hbuf.size();
+                hbuf.resize(at + z.blocks[hb_next].isize);
+                std::vector<size_t> off(1, 0);
+                if (!z.inflate_blocks(hb_next, hb_next + 1, hbuf.data() + at, 0, &off).empty()) return false;
+                hb_next++;
+            }
+            memcpy(dst, hbuf.data() + consumed, n);
+            consumed += n;
+            return true;
+        };
         uint8_t b4[4];
         if (!rd(b4, 4) || memcmp(b4, "BAM\1", 4) != 0) { S->err = z.err.empty() ? "not a BAM file" : z.err; return S; }
         size_t inflated_total = 0;
@@ -951,14 +989,12 @@ void* bam_stream_open(const char* path, int threads) {
             S->hdr.contigs[i].name = nm;
             S->hdr.contigs[i].length = le32(b4);
         }
-        if (z.pending.valid()) (void)z.pending.get();       // the loader's read-ahead is not used from here on
         size_t acc = 0;
         for (size_t k = 0; k < z.blocks.size(); k++) {
             if (consumed < acc + z.blocks[k].isize) { S->first_block = k; S->first_skip = consumed - acc; break; }
             acc += z.blocks[k].isize;
             S->first_block = k + 1; S->first_skip = 0;
         }
-        z.buf[0].clear(); z.buf[0].shrink_to_fit(); z.buf[1].clear(); z.buf[1].shrink_to_fit();
         if (!getenv("HIMUT_INGEST_NO_INDEX"))
             S->have_bai = read_bai(std::string(path) + ".bai", n_ref, S->ref_range);
     } catch (const std::exception& e) { S->err = std::string("BAM header: ") + e.what(); }
@@ -972,13 +1008,22 @@ const char* bam_stream_ref_name(void* h, int64_t i) { return ((BamStream*)h)->hd
 int64_t bam_stream_ref_len(void* h, int64_t i) { return ((BamStream*)h)->hdr.contigs[(size_t)i].length; }
 int bam_stream_indexed(void* h) { return ((BamStream*)h)->have_bai ? 1 : 0; }
 int bam_stream_unique_names(void* h) { return ((BamStream*)h)->unique ? 1 : 0; }
-void bam_stream_close(void* h) { BamStream* S = (BamStream*)h; S->z.close(); delete S; }
+void bam_stream_close(void* h) {
+    BamStream* S = (BamStream*)h;
+    if (S->inflating.valid()) (void)S->inflating.get();
+    if (getenv("HIMUT_INGEST_PROFILE"))
+        fprintf(stderr, "stream profile (s): inflate %.3f in %lld windows, hop + names %.3f (threads %d)\n", S->t_inflate,
+                (long long)S->n_windows, S->t_hop, S->z.threads);
+    S->z.close();
+    delete S;
+}
 
 // Restricts the stream to one contig.  *inflated_bound = inflated bytes of the blocks that will be read (an upper
 // bound of the contig's record bytes when the file is indexed, of everything from the first record on otherwise).
 int bam_stream_select(void* h, int32_t ref_id, int64_t* inflated_bound) {
     BamStream* S = (BamStream*)h;
     if (ref_id < 0 || (size_t)ref_id >= S->hdr.contigs.size()) { S->err = "no such contig"; return 1; }
+    if (S->inflating.valid()) (void)S->inflating.get();
     S->target = ref_id; S->carry.clear(); S->names.clear(); S->nkept = 0; S->done = false; S->unique = true;
     const auto& B = S->z.blocks;
     S->blk = S->first_block; S->skip = S->first_skip; S->blk_end = B.size();
@@ -999,77 +1044,114 @@ int bam_stream_select(void* h, int32_t ref_id, int64_t* inflated_bound) {
     return 0;
 }
 
-// Next window: inflates as many of the contig's blocks as fit ``cap`` bytes of dst (behind the partial record kept from
-// the window before), hops over the records and lists the kept ones (this contig, mapped): rec_off[k] = offset of record
-// k's body (behind its length field) in dst, qid[k] = index of the first kept record with the same read name.  *nbytes =
-// bytes of dst the records occupy.  Returns the number of kept records, -1 at the end of the contig, -2 on error.
-int64_t bam_stream_next(void* h, uint8_t* dst, int64_t cap, uint32_t* rec_off, int32_t* qid, int64_t rec_cap, int64_t* nbytes,
-                        int64_t* sums) {
+// A window buffer = BAM_STREAM_HEAD bytes of head room + the inflated blocks.  The inflate of window k + 1 (thread pool,
+// started by bam_stream_prefetch, running in the background) overlaps the hop over window k and its hand-over to the
+// GPU; the partial record that window k ends with is then put in FRONT of window k + 1's bytes, in the head room, so
+// the inflate never has to wait for it.
+int64_t bam_stream_head(void) { return (int64_t)BAM_STREAM_HEAD; }
+
+// Starts inflating the next blocks of the contig into buf + HEAD (as many as fit cap - HEAD).  Returns 1 when an
+// inflate is in flight, 0 when the contig has no more blocks, -2 on error.  One prefetch may be in flight.
+int bam_stream_prefetch(void* h, uint8_t* buf, int64_t cap) {
     BamStream* S = (BamStream*)h;
-    *nbytes = 0;
-    sums[0] = sums[1] = 0;      // of the kept records: query lengths rounded up to 32, bytes of the auxiliary fields
     try {
+        if (S->inflating.valid()) { S->err = "a prefetch is in flight already"; return -2; }
+        if (S->done || S->blk >= S->blk_end) return 0;
         const auto& B = S->z.blocks;
-        for (;;) {
-            if (S->done || (S->blk >= S->blk_end && S->carry.empty())) return -1;
-            size_t c = S->carry.size();
-            if ((int64_t)c >= cap) { S->err = "a BAM record is larger than the ingest window"; return -2; }
-            if (c) memcpy(dst, S->carry.data(), c);
-            S->carry.clear();
-            std::vector<size_t> off;
-            size_t tot = 0, b0 = S->blk, b1 = S->blk;
-            while (b1 < S->blk_end && (int64_t)(c + tot + B[b1].isize) <= cap) { off.push_back(c + tot); tot += B[b1].isize; b1++; }
-            if (b1 == b0 && b0 < S->blk_end) { S->err = "ingest window smaller than a BGZF block"; return -2; }
-            if (b1 > b0) {
-                const std::string e = S->z.inflate_blocks(b0, b1, dst, 0, &off);
-                if (!e.empty()) { S->err = e; return -2; }
-            }
-            S->blk = b1;
-            const size_t nb = c + tot;
-            size_t pos = S->skip;
-            S->skip = 0;
-            int64_t n = 0;
-            while (pos + 4 <= nb && n < rec_cap) {
-                const uint32_t bs = le32(dst + pos);
-                if (bs < 32) { S->err = "BAM record too short"; return -2; }
-                if (pos + 4 + (size_t)bs > nb) break;
-                const uint8_t* rec = dst + pos + 4;
-                const int32_t ref_id = (int32_t)le32(rec);
-                const uint16_t flag = le16(rec + 14);
-                if (ref_id > S->target || ref_id < 0) { S->done = true; break; }       // coordinate sorted: the contig is over
-                if (ref_id == S->target && !(flag & 4)) {
-                    const size_t l_qname = rec[8];
-                    if (32 + l_qname > bs) { S->err = "malformed BAM record"; return -2; }
-                    const char* qn = (const char*)rec + 32;
-                    auto it = S->names.emplace(std::string(qn, strnlen(qn, l_qname)), (int32_t)S->nkept);
-                    if (!it.second) S->unique = false;
-                    const uint64_t n_cigar = le16(rec + 12), l_seq = le32(rec + 16);
-                    const uint64_t fixed = 32 + l_qname + 4 * n_cigar + (l_seq + 1) / 2 + l_seq;
-                    if (fixed > bs) { S->err = "malformed BAM record"; return -2; }
-                    sums[0] += (int64_t)((l_seq + 31) & ~(uint64_t)31);
-                    sums[1] += (int64_t)(bs - fixed);
-                    rec_off[n] = (uint32_t)(pos + 4);
-                    qid[n] = it.first->second;
-                    S->nkept++; n++;
-                }
-                pos += 4 + (size_t)bs;
-            }
-            *nbytes = (int64_t)pos;
-            if (!S->done) {
-                if (pos < nb) S->carry.assign(dst + pos, dst + nb);
-                if (S->blk >= S->blk_end && !S->carry.empty() && n < rec_cap && S->carry.size() >= 4) {
-                    // the last block ended inside a record (an indexed range ends at the contig's last record, so what
-                    // is left belongs to the next contig or the file is truncated)
-                    if (!S->have_bai) { S->err = "truncated BAM record"; return -2; }
-                    S->carry.clear();
-                }
-            }
-            if (n > 0) return n;
-            if (S->done || (S->blk >= S->blk_end && S->carry.empty())) return -1;
-            // a window without kept records (another contig's in front of ours, no index): next one
-        }
+        S->inf_off.clear();
+        size_t tot = 0, b0 = S->blk, b1 = S->blk;
+        while (b1 < S->blk_end && (int64_t)(BAM_STREAM_HEAD + tot + B[b1].isize) <= cap) { S->inf_off.push_back(tot); tot += B[b1].isize; b1++; }
+        if (b1 == b0) { S->err = "ingest window smaller than a BGZF block"; return -2; }
+        S->blk = b1;
+        S->inf_tot = tot; S->inf_buf = buf;
+        uint8_t* dst = buf + BAM_STREAM_HEAD;
+        S->inflating = std::async(std::launch::async, [S, b0, b1, dst]() {
+            const double t0 = now_s();
+            std::string e = S->z.inflate_blocks(b0, b1, dst, 0, &S->inf_off);
+            S->t_inflate += now_s() - t0; S->n_windows++;
+            return e;
+        });
+        return 1;
     } catch (const std::exception& e) { S->err = std::string("BAM stream: ") + e.what(); return -2; }
 }
 
+// Finishes the window whose inflate bam_stream_prefetch(buf) started (or, with none in flight, inflates one now): hops
+// over the records and lists the kept ones (this contig, mapped): rec_off[k] = offset of record k's body (behind its
+// length field) from buf + *start, qid[k] = index of the first kept record with the same read name.  The records occupy
+// *nbytes bytes from buf + *start.  sums: of the kept records, query lengths rounded up to 32 and bytes of the auxiliary
+// fields.  Returns the number of kept records (0: a window of other contigs' records, go on), -1 at the end of the
+// contig, -2 on error.
+int64_t bam_stream_next(void* h, uint8_t* buf, int64_t cap, uint32_t* rec_off, int32_t* qid, int64_t rec_cap, int64_t* start,
+                        int64_t* nbytes, int64_t* sums) {
+    BamStream* S = (BamStream*)h;
+    *nbytes = 0; *start = 0;
+    sums[0] = sums[1] = 0;
+    try {
+        if (!S->inflating.valid()) {
+            if (S->done) return -1;
+            const int r = bam_stream_prefetch(h, buf, cap);
+            if (r < 0) return -2;
+            if (r == 0 && S->carry.empty()) return -1;
+        }
+        size_t tot = 0;
+        if (S->inflating.valid()) {
+            if (S->inf_buf != buf) { (void)S->inflating.get(); S->err = "bam_stream_next on a buffer other than the prefetched one"; return -2; }
+            const std::string e = S->inflating.get();
+            if (!e.empty()) { S->err = e; return -2; }
+            tot = S->inf_tot;
+        }
+        const double t_h0 = now_s();
+        const size_t c = S->carry.size();
+        if (c > BAM_STREAM_HEAD) { S->err = "a BAM record is larger than the head room of the ingest window"; return -2; }
+        uint8_t* dst = buf + BAM_STREAM_HEAD - c;
+        if (c) memcpy(dst, S->carry.data(), c);
+        S->carry.clear();
+        const size_t nb = c + tot;
+        size_t pos = S->skip;
+        S->skip = 0;
+        const size_t first = pos;
+        int64_t n = 0;
+        while (pos + 4 <= nb && n < rec_cap) {
+            const uint32_t bs = le32(dst + pos);
+            if (bs < 32) { S->err = "BAM record too short"; return -2; }
+            if (pos + 4 + (size_t)bs > nb) break;
+            const uint8_t* rec = dst + pos + 4;
+            const int32_t ref_id = (int32_t)le32(rec);
+            const uint16_t flag = le16(rec + 14);
+            if (ref_id > S->target || ref_id < 0) { S->done = true; break; }       // coordinate sorted: the contig is over
+            if (ref_id == S->target && !(flag & 4)) {
+                const size_t l_qname = rec[8];
+                if (32 + l_qname > bs) { S->err = "malformed BAM record"; return -2; }
+                const char* qn = (const char*)rec + 32;
+                auto it = S->names.emplace(std::string(qn, strnlen(qn, l_qname)), (int32_t)S->nkept);
+                if (!it.second) S->unique = false;
+                const uint64_t n_cigar = le16(rec + 12), l_seq = le32(rec + 16);
+                const uint64_t fixed = 32 + l_qname + 4 * n_cigar + (l_seq + 1) / 2 + l_seq;
+                if (fixed > bs) { S->err = "malformed BAM record"; return -2; }
+                sums[0] += (int64_t)((l_seq + 31) & ~(uint64_t)31);
+                sums[1] += (int64_t)(bs - fixed);
+                rec_off[n] = (uint32_t)(pos + 4 - first);
+                qid[n] = it.first->second;
+                S->nkept++; n++;
+            }
+            pos += 4 + (size_t)bs;
+        }
+        *start = (int64_t)(BAM_STREAM_HEAD - c + first);
+        *nbytes = (int64_t)(pos - first);
+        S->t_hop += now_s() - t_h0;
+        if (!S->done) {
+            if (pos < nb) S->carry.assign(dst + pos, dst + nb);
+            if (S->blk >= S->blk_end && !S->carry.empty() && n < rec_cap) {
+                // the last block ended inside a record: an indexed range ends with the contig's last record, so what is
+                // left belongs to the next contig; without an index the file is truncated
+                if (!S->have_bai && S->carry.size() >= 4) { S->err = "truncated BAM record"; return -2; }
+                S->carry.clear();
+            }
+        }
+        if (n > 0) return n;
+        if (S->done || (S->blk >= S->blk_end && S->carry.empty())) return -1;
+        return 0;
+    } catch (const std::exception& e) { S->err = std::string("BAM stream: ") + e.what(); return -2; }
+}
 
 }  // extern "C"

@@ -720,7 +720,6 @@ void himut_destroy(himut_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     for (int k = 0; k < 2; k++) {
-        if (c->ing_pinned[k]) (void)hipHostFree(c->ing_pinned[k]);
         if (c->ing_copied[k]) (void)hipEventDestroy(c->ing_copied[k]);
         if (c->ing_parsed[k]) (void)hipEventDestroy(c->ing_parsed[k]);
     }
@@ -873,15 +872,25 @@ int himut_ingest_begin(himut_ctx* c, int64_t inflated_bound, int64_t window_byte
         HCHECK(hipStreamSynchronize(c->stream));
         HCHECK(hipStreamSynchronize(c->side));
         const size_t W = (size_t)window_bytes;
-        if (c->ing_window != W) {
+        // The two pinned windows belong to the process, not to the context (pinning 128 MB takes tens of
+        // milliseconds; a call makes one context per contig and ingests them one after the other).
+        static void* g_pinned[2] = {nullptr, nullptr};
+        static size_t g_pinned_bytes = 0;
+        if (g_pinned_bytes < W + 4096) {
             for (int k = 0; k < 2; k++) {
-                if (c->ing_pinned[k]) { HCHECK(hipHostFree(c->ing_pinned[k])); c->ing_pinned[k] = nullptr; }
-                HCHECK(hipHostMalloc(&c->ing_pinned[k], W + 4096, hipHostMallocDefault));
-                if (!c->ing_copied[k]) HCHECK(hipEventCreateWithFlags(&c->ing_copied[k], hipEventDisableTiming));
-                if (!c->ing_parsed[k]) HCHECK(hipEventCreateWithFlags(&c->ing_parsed[k], hipEventDisableTiming));
+                if (g_pinned[k]) { HCHECK(hipHostFree(g_pinned[k])); g_pinned[k] = nullptr; }
+                // cacheable pages: the inflate reads its own output back (LZ77 matches)
+                const unsigned fl = getenv("HIMUT_PINNED_COHERENT") ? hipHostMallocDefault : (hipHostMallocNonCoherent | hipHostMallocPortable);
+                HCHECK(hipHostMalloc(&g_pinned[k], W + 4096, fl));
             }
-            c->ing_window = W;
+            g_pinned_bytes = W + 4096;
         }
+        for (int k = 0; k < 2; k++) {
+            c->ing_pinned[k] = g_pinned[k];
+            if (!c->ing_copied[k]) HCHECK(hipEventCreateWithFlags(&c->ing_copied[k], hipEventDisableTiming));
+            if (!c->ing_parsed[k]) HCHECK(hipEventCreateWithFlags(&c->ing_parsed[k], hipEventDisableTiming));
+        }
+        c->ing_window = W;
         for (int k = 0; k < 2; k++) { c->d_stage[k].reserve(W + 4096); c->ing_used[k] = false; }
         // first sizes from what CCS records look like (two thirds of a record are qualities); the arrays grow if a
         // window needs more
@@ -916,11 +925,12 @@ int himut_ingest_wait(himut_ctx* c, int slot) {
     });
 }
 
-int himut_ingest_window(himut_ctx* c, int slot, int64_t nbytes, const uint32_t* rec_off, const int32_t* qid, int64_t n_rec,
+int himut_ingest_window(himut_ctx* c, int slot, int64_t start, int64_t nbytes, const uint32_t* rec_off, const int32_t* qid, int64_t n_rec,
                         int64_t padded_bases, int64_t tag_bytes) {
-    if (!c || (slot != 0 && slot != 1) || n_rec < 0 || nbytes < 0 || (n_rec && (!rec_off || !qid))) return fail(c, HIMUT_ERR_ARG, "bad ingest window");
+    if (!c || (slot != 0 && slot != 1) || n_rec < 0 || nbytes < 0 || start < 0 || (n_rec && (!rec_off || !qid)))
+        return fail(c, HIMUT_ERR_ARG, "bad ingest window");
     if (!c->ing_open) return fail(c, HIMUT_ERR_ARG, "himut_ingest_begin has not been called");
-    if ((size_t)nbytes > c->ing_window) return fail(c, HIMUT_ERR_ARG, "ingest window larger than the buffer");
+    if ((size_t)(start + nbytes) > c->ing_window) return fail(c, HIMUT_ERR_ARG, "ingest window larger than the buffer");
     if (n_rec == 0) return HIMUT_OK;
     return guarded(c, [&]() -> int {
         HCHECK(hipSetDevice(c->device));
@@ -943,7 +953,7 @@ int himut_ingest_window(himut_ctx* c, int slot, int64_t nbytes, const uint32_t* 
         c->d_tmp.reserve(scan_b + 256);
         // copy stream: the window's bytes (pinned -> HBM) once the parse of the window that used this staging buffer is over
         if (c->ing_used[slot]) HCHECK(hipStreamWaitEvent(cp, c->ing_parsed[slot], 0));
-        HCHECK(hipMemcpyAsync(c->d_stage[slot].p, c->ing_pinned[slot], (size_t)nbytes, hipMemcpyHostToDevice, cp));
+        HCHECK(hipMemcpyAsync(c->d_stage[slot].p, (const uint8_t*)c->ing_pinned[slot] + start, (size_t)nbytes, hipMemcpyHostToDevice, cp));
         HCHECK(hipEventRecord(c->ing_copied[slot], cp));
         c->ing_used[slot] = true;
         // compute stream: record list, decode, offsets, scatter

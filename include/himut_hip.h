@@ -199,7 +199,8 @@ int himut_copy_records_to_device(himut_ctx* ctx, void* dst_device, int64_t capac
  * An alternative to himut_push_reads: the contig's inflated BAM records go to HBM a window at a time and are parsed
  * there (CIGAR walk, tag scan, placement, byte copies: csrc/himut_ingest.h).  The caller inflates BGZF blocks straight
  * into one of the library's two pinned buffers (himut_ingest_buffer), lists where the records of the contig start
- * (rec_off: offset of each record's body, i.e. behind its block_size field) and which earlier record carries the same
+ * (rec_off: offset of each record's body, i.e. behind its block_size field, from byte `start` of the buffer, where the
+ * window's nbytes begin) and which earlier record carries the same
  * read name (qid, as in himut_read_batch), and hands the window over; the copy of window k overlaps the inflate of
  * window k + 1 (two buffers: himut_ingest_wait(slot) returns once slot's bytes have left the host).  padded_bases =
  * sum of the records' l_seq rounded up to 32, tag_bytes = an upper bound of the cs text in the window (the bytes of
@@ -214,8 +215,8 @@ typedef struct himut_ingest_result {
 int himut_ingest_begin(himut_ctx* ctx, int64_t inflated_bytes_bound, int64_t window_bytes);
 void* himut_ingest_buffer(himut_ctx* ctx, int slot);
 int himut_ingest_wait(himut_ctx* ctx, int slot);
-int himut_ingest_window(himut_ctx* ctx, int slot, int64_t nbytes, const uint32_t* rec_off, const int32_t* qid, int64_t n_rec,
-                        int64_t padded_bases, int64_t tag_bytes);
+int himut_ingest_window(himut_ctx* ctx, int slot, int64_t start, int64_t nbytes, const uint32_t* rec_off, const int32_t* qid,
+                        int64_t n_rec, int64_t padded_bases, int64_t tag_bytes);
 int himut_ingest_end(himut_ctx* ctx, int unique_qnames, himut_ingest_result* out);
 /* per-read fields the host needs for bamlib.get_thresholds (bamlib.py:137-178); any pointer may be null */
 int himut_ingest_read_meta(himut_ctx* ctx, int32_t* tstart, int32_t* tend, int32_t* qlen, uint8_t* mapq, uint8_t* tp);

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "himut_hip.h")).read()
-    return sorted(set(re.findall(r"^(?:int|void|const char\*)\s+(himut_\w+)\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|void\*?|const char\*)\s+(himut_\w+)\(", text, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():
