@@ -1207,8 +1207,9 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     const bool tiled = !(sweep && strcmp(sweep, "store") == 0);
     if (c->n > 0 && T.n > 0 && tiled) {
         A.X = PosIndex{}; A.colstore = nullptr; A.p_lo = 0; A.p_hi = 0;
-        hipLaunchKernelGGL(k_norm_tile, dim3(ex, (unsigned)T.n), dim3(256), 0, st, A, D, c->d_callable.as<uint32_t>(),
-                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk);
+        const int64_t per = ((int64_t)blocks_for(maxspan, 256) + 7) / 8;          // tiles of a chunk per XCD class: see the tile mapping
+        hipLaunchKernelGGL(k_norm_tile, dim3(8u * (unsigned)std::min<int64_t>(NT_Q, per), (unsigned)T.n), dim3(256), 0, st, A, D,
+                           c->d_callable.as<uint32_t>(), c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per);
     } else if (c->n > 0 && T.n > 0) {
         for (int64_t p_lo = 0; p_lo < (int64_t)maxend; p_lo += NORM_PASS) {
             const int64_t p_hi = std::min<int64_t>(p_lo + NORM_PASS, maxend);

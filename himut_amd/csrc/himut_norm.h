@@ -123,13 +123,25 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
     const int32_t trim_lo = (int32_t)trim_start, trim_hi = (int32_t)trim_end;
     const int maxmm = P.p.max_mismatch_count;
     const int32_t q_first = uni(lseg[0].y);
+    // the qualities of the next window are asked for before this one is worked on (addresses clamped into the read)
+    const int32_t q_last = (max(qlen, 1) - 1) & ~31;
+    uint4 p0, p1;
+    {
+        const int32_t qn = min((q_first & ~2047) + lane * 32, q_last);
+        p0 = *reinterpret_cast<const uint4*>(R.bq + qo + qn);
+        p1 = *reinterpret_cast<const uint4*>(R.bq + qo + qn + 16);
+    }
     for (int32_t c0 = q_first & ~2047; c0 < qlen; c0 += 2048) {
         const int32_t qa = c0 + lane * 32;
         uint32_t word = 0;
+        const uint4 b0 = p0, b1 = p1;
+        {
+            const int32_t qn = min(c0 + 2048 + lane * 32, q_last);
+            p0 = *reinterpret_cast<const uint4*>(R.bq + qo + qn);
+            p1 = *reinterpret_cast<const uint4*>(R.bq + qo + qn + 16);
+        }
         if (qa < qlen) {
             // qualities of the lane's 32 bases
-            const uint4 b0 = *reinterpret_cast<const uint4*>(R.bq + qo + qa);
-            const uint4 b1 = *reinterpret_cast<const uint4*>(R.bq + qo + qa + 16);
             const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             uint32_t okq = 0;    // quality and trim tests per base, four bytes at a time (qualities are < 128)
 #pragma unroll
@@ -603,11 +615,18 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
 // of a row, finds them in the read's segment list, and loads the four qualities, the four packed bases and the
 // four callable bits with one unaligned load each -- then every thread runs down its own column in read order.
 // Nothing is written to HBM except the counters.
+#ifndef HIMUT_NT_Q
+#define HIMUT_NT_Q 16
+#endif
+#ifndef HIMUT_NT_WAVES
+#define HIMUT_NT_WAVES 5
+#endif
+constexpr int NT_Q = HIMUT_NT_Q;         // workgroups per XCD class and chunk (each strides over its class's tiles)
 constexpr int NT_ROWS = 48;
 constexpr int NT_RPW = NT_ROWS / 4;    // rows per wave and batch
 
-__global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, const uint32_t* callable, const int32_t* winlo,
-                                                   const int32_t* winhi, int64_t nblk) {
+__global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, Derived D, const uint32_t* callable, const int32_t* winlo,
+                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class) {
     __shared__ double s_lut[3 * 257];         // three tables of 256 qualities + a zero entry each (index 256)
     __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
@@ -628,8 +647,17 @@ __global__ void __launch_bounds__(256, 5) k_norm_tile(NormArgs A, Derived D, con
     const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
     const Reads& R = A.R;
     int bad = 0;
-    for (int t = 0; t < NE_TILES; t++) {
-        const int64_t base = (int64_t)cs_ + ((int64_t)blockIdx.x * NE_TILES + t) * 256;
+    // Which tile: workgroups are dealt round-robin over the eight XCDs (each with an L2 of its own), so the workgroups
+    // b, b + 8, b + 16 ... that run side by side on one XCD take NEIGHBOURING tiles of the chunk: a read's bytes at a
+    // tile boundary (its rows are 256 + 128 bytes at arbitrary offsets, i.e. partial 128-byte lines at both ends) are
+    // then asked for twice within microseconds and the second time come out of that L2.  gridDim.x is a multiple of 8.
+    // (Speed only: any mapping gives the same counts.)
+    // A workgroup goes through several such tiles (its counters go to memory once): XCD class r = blockIdx.x & 7 owns the
+    // tiles [r * per, (r + 1) * per) of the chunk and its NT_Q workgroups take NT_Q neighbouring ones per step.
+    const int64_t per = tiles_per_class;
+    for (int64_t t = blockIdx.x >> 3; t < per; t += (int64_t)(gridDim.x >> 3)) {
+        const int64_t tile = (int64_t)(blockIdx.x & 7) * per + t;
+        const int64_t base = (int64_t)cs_ + tile * 256;
         if (base >= ce_) break;                                   // the same for every thread
         const int64_t rpos = base + tid;
         bool valid = rpos < ce_;
