@@ -349,6 +349,12 @@ inline void stage_event(himut_ctx* c, int ev, int level, hipStream_t st) {
     if (c->timing >= level) HCHECK(hipEventRecord(c->ev[ev], st));
 }
 
+template <bool WITH_BQ>
+void launch_parse(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, uint32_t* posbits, int64_t nposwords) {
+    hipLaunchKernelGGL(k_parse_cs<WITH_BQ>, dim3(blocks_for(c->n, 4)), dim3(256), 0, c->stream, R, D, c->params, &sc->err,
+                       c->d_ccs.as<uint8_t>(), posbits, nposwords);
+}
+
 // side_work: work for the second stream, done while the quality stream + cs decode run
 template <bool WITH_BQ, class F>
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, F side_work, uint32_t* posbits = nullptr,
@@ -356,8 +362,7 @@ void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc
     hipStream_t st = c->stream;
     // the side stream takes the work that needs nothing from the decode (it starts behind EV_START: the
     // previous run on this context is over by then)
-    hipLaunchKernelGGL(k_parse_cs<WITH_BQ>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err,
-                       c->d_ccs.as<uint8_t>(), posbits, nposwords);
+    launch_parse<WITH_BQ>(c, R, D, sc, posbits, nposwords);
     HCHECK(hipStreamWaitEvent(c->side, c->ev[EV_START], 0));
     side_work(c->side);
     HCHECK(hipEventRecord(c->ev[EV_SIDE], c->side));
@@ -487,8 +492,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         if (clear_all || need_win)
             run_parse_stage<false>(c, R, D, sc, side_work, c->d_posbits_c.as<uint32_t>(), nwords);
         else {
-            hipLaunchKernelGGL(k_parse_cs<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, &sc->err,
-                               c->d_ccs.as<uint8_t>(), c->d_posbits_c.as<uint32_t>(), nwords);
+            launch_parse<false>(c, R, D, sc, c->d_posbits_c.as<uint32_t>(), nwords);
             if (c->any_longcs)
                 hipLaunchKernelGGL(k_check_longcs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, &sc->err);
             stage_event(c, EV_PARSE, 2, st);
@@ -529,12 +533,12 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
         CaptureArgs G;
         G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)slot_cap;
         G.r_begin = 0; G.r_end = c->n; G.callable = nullptr; G.bqsum = c->d_bqsum.as<uint32_t>(); G.err = &sc->err;
+        // the proposals of a read (read filters, trim / window filters -> mask) are the tail of its capture wave
+        G.C = C; G.H = H; G.P = c->params; G.mask = c->d_mask.as<uint32_t>(); G.tilecnt = c->d_tilecnt.as<uint32_t>();
+        G.ccs_flag = c->d_ccs.as<uint8_t>();
         stage_event(c, EV_INDEX, 1, st);
         hipLaunchKernelGGL(k_stream_capture<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
         stage_event(c, EV_GATHER, 1, st);
-        // ---- proposals (the read filters know the quality mean now) -> mask
-        hipLaunchKernelGGL(k_propose, dim3(blocks_for(c->n, PROP_READS)), dim3(PROP_READS * 16), 0, st, R, D, C, H, c->params,
-                           c->d_mask.as<uint32_t>(), c->d_tilecnt.as<uint32_t>(), c->d_ccs.as<uint8_t>());
     } else {
         stage_event(c, EV_INDEX, 1, st);
         stage_event(c, EV_GATHER, 1, st);
@@ -1252,7 +1256,8 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
             X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
             CaptureArgs G;
             G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)nslots;
-            G.r_begin = rb; G.r_end = std::max(rb, re); G.callable = c->d_callable.as<uint32_t>(); G.bqsum = nullptr; G.err = &sc->err;
+            G.r_begin = rb; G.r_end = std::max(rb, re); G.callable = c->d_callable.as<uint32_t>(); G.bqsum = nullptr; G.err = &sc->err; G.mask = nullptr; G.tilecnt = nullptr; G.ccs_flag = nullptr;
+            G.C = C; G.H = H; G.P = c->params;
             if (re > rb)
                 hipLaunchKernelGGL(k_stream_capture<true>, dim3(blocks_for(re - rb, 4)), dim3(256), 0, st, G);
             A.X = X; A.colstore = c->d_colstore.as<uint16_t>(); A.p_lo = p_lo; A.p_hi = p_hi;

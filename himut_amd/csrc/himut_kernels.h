@@ -728,42 +728,38 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
 }
 
 // ---------------------------------------------------------------------------------------
-// k_propose: sixteen lanes per read, four reads per wave (a read has about ten mismatch entries and the chunk
-// look-up needs sixteen lanes: a whole wave per read would leave the kernel bound by the number of
-// resident waves times the latency of its dependent loads).  Applies the read filters (caller.py:310-317), checks
-// every substitution of the cs tag against SEQ, and for every substitution that survives
-// the trim and mismatch-window filters (bamlib.py:69-86,222-282), and for every chunk that
-// both contains tpos (caller.py:104-108,325) and fetched the read (caller.py:299), sets the
-// (ref, alt) bit of the position in that chunk's mask -- the set() of caller.py:324.
-// The candidates are enumerated from the mask afterwards.
+// propose_read: the proposals of one read.  Applies the read filters (caller.py:310-317) and, for every substitution that
+// survives the trim and mismatch-window filters (bamlib.py:69-86,222-282) and every chunk that both contains tpos
+// (caller.py:104-108,325) and fetched the read (caller.py:299), sets the (ref, alt) bit of the position in that
+// chunk's mask -- the set() of caller.py:324.  The candidates are enumerated from the mask afterwards.  The proposal
+// that sets a mask bit for the first time also counts it in its tile of 8192 mask cells: the scan of those counts is
+// where k_mask_emit puts each tile's candidates.
 //
-// Scattered atomics are what this kernel is made of (the chip does 20-30 of them per ns, each lane its own cache
-// line), and three in four of them repeat one that a neighbouring read has just made: the 15-30 reads over a
-// germline site propose the same (position, ref, alt).  A workgroup therefore takes 64 consecutive reads and keeps
-// the proposals it has made in a small LDS table (the key is swapped in; finding itself there, a proposal is
-// dropped), which leaves about one atomic per germline site and workgroup.  The table only ever drops exact
-// repeats, so the mask is the same set() as before.
-// The proposal that sets a mask bit for the first time also counts it in its tile of 8192 mask cells: the scan of
-// those counts is where k_mask_emit puts each tile's candidates.
+// It is the tail of k_stream_capture's wave: the wave that has streamed a read knows the read's quality sum, the last
+// thing the read filters were waiting for, and what follows is a chain of dependent look-ups (chunk hint -> chunk
+// records -> mismatch entries -> atomics) that costs a wave microseconds of latency and next to no bandwidth -- as a
+// kernel of its own that chain, times the number of waves a chip holds, was 0.1 ms; behind a bandwidth-bound stream
+// the other waves of the CU fill the time.
 constexpr int EMIT_MAXC = 4;   // chunks of one read kept in registers
-constexpr int PROP_READS = 64; // reads per workgroup (16 lanes each)
-constexpr int PROP_TAB = 2048; // entries of the recent-proposal table
+constexpr int PROP_TAB_BITS = 11;   // entries of a recent-proposal table (a workgroup's, where one is kept)
 constexpr int MASK_TILE_SHIFT = 13;
 constexpr int MASK_TILE_CELLS = 1 << MASK_TILE_SHIFT;
 
-__global__ void __launch_bounds__(PROP_READS * 16) k_propose(Reads R, Derived D, Chunks C, Phase H, Params P, uint32_t* mask,
-                                                             uint32_t* tilecnt, uint8_t* ccs_flag) {
-    __shared__ unsigned long long s_seen[PROP_TAB];
-    for (int i = threadIdx.x; i < PROP_TAB; i += PROP_READS * 16) s_seen[i] = ~0ull;
-    __syncthreads();
-    const int gl = threadIdx.x & 15, gsh = (threadIdx.x & 48);      // lane in its group of 16, the group's first lane
-    const int64_t r = (int64_t)blockIdx.x * PROP_READS + (threadIdx.x >> 4);
-    if (r >= R.n) return;
+// The proposals of ONE read, by the sixteen lanes of a DPP row (gl = lane in the row, gsh = the row's first lane in
+// the wave); the row takes the mismatch entries e0, e0 + estride, ...  (k_stream_capture calls it with the four rows of
+// the read's wave: each row works out the read's chunks for itself, the rows share the entries.)  bqs: the sum of the
+// read's qualities.  s_seen: the workgroup's recent-proposal table, or null.
+__device__ __forceinline__ void propose_read(const Reads& R, const Derived& D, const Chunks& C, const Phase& H, const Params& P,
+                                             const int64_t r, const uint32_t bqs, const int e0, const int estride, const int gl,
+                                             const int gsh, uint32_t* mask, uint32_t* tilecnt, uint8_t* ccs_flag,
+                                             unsigned long long* s_seen) {
     // the (ref, alt) bit of a mask cell: 16 mask bits per position, two positions per 32-bit word
     auto propose = [&](const int64_t cell, const int bit) {
-        const unsigned long long key = ((unsigned long long)cell << 4) | (unsigned long long)bit;
-        const uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53);        // 11 bits
-        if (atomicExch(&s_seen[h], key) == key) return;
+        if (s_seen) {
+            const unsigned long long key = ((unsigned long long)cell << 4) | (unsigned long long)bit;
+            const uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - PROP_TAB_BITS));
+            if (atomicExch(&s_seen[h], key) == key) return;
+        }
         const uint32_t m = (1u << bit) << ((cell & 1) ? 16 : 0);
         if (!(atomicOr(mask + (cell >> 1), m) & m)) atomicAdd(tilecnt + (cell >> MASK_TILE_SHIFT), 1u);
     };
@@ -773,7 +769,6 @@ __global__ void __launch_bounds__(PROP_READS * 16) k_propose(Reads R, Derived D,
     const ReadMeta M = D.meta[r];
     const int32_t qlen = R.qlen[r];
     const int mapq = R.mapq[r];
-    const uint32_t bqs = D.bqsum[r];
     const int nm = D.nmis[r];
     const int32_t qid = R.qid[r];
     if (M.flags & RF_SECONDARY) return;
@@ -842,7 +837,7 @@ __global__ void __launch_bounds__(PROP_READS * 16) k_propose(Reads R, Derived D,
     const double trim_start = floor(P.p.min_trim * (double)qlen);        // bamlib.py:226
     const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);   // bamlib.py:227
     const int64_t w = P.p.mismatch_window_size;
-    for (int e = gl; e < nm; e += 16) {
+    for (int e = e0; e < nm; e += estride) {
         const uint32_t v = mq[e];
         const int32_t tp1 = mis[e];
         const int32_t mprev = e > 0 ? mis[e - 1] : -0x7fffffff - 1;
@@ -1141,6 +1136,12 @@ struct CaptureArgs {
     const uint32_t* callable;    // normcounts: one bit per query base (bit q of read r at word (qoff[r] + q) >> 5)
     uint32_t* bqsum;             // call path: per read, the sum of the qualities of the whole query (bamlib.py:34-36)
     const int* err;              // a device error raised by an earlier kernel of the run: nothing is captured then
+    // call path: the read's proposals follow its stream (propose_read); mask null = none
+    Chunks C;
+    Phase H;
+    Params P;
+    uint32_t *mask, *tilecnt;
+    uint8_t* ccs_flag;
 };
 
 constexpr int CLQ = 128;    // candidate list entries per wave (circular, power of two)
@@ -1165,8 +1166,11 @@ constexpr int CPD = 2;      // windows in flight (register sets, at most 4); the
 //     handles the list one candidate per lane: segment by binary search in LDS, query
 //     offset, base and quality out of the window in LDS, slot from the block table.
 // Every byte of the read is fetched exactly once; stores return nothing.
+#ifndef HIMUT_CAP_WAVES
+#define HIMUT_CAP_WAVES 7
+#endif
 template <bool NORM>
-__global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
+__global__ void __launch_bounds__(256, NORM ? 1 : HIMUT_CAP_WAVES) k_stream_capture(CaptureArgs A) {
     __shared__ __align__(16) uint8_t s_bq[4][CWQ];
     __shared__ __align__(16) uint8_t s_sq[4][CWQ / 2];
     __shared__ __align__(16) int4 s_seg[4][CSG + 1];
@@ -1193,6 +1197,7 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
                 if (lane == 0) A.bqsum[r] = sum;
+                if (A.mask) propose_read(R, A.D, A.C, A.H, A.P, r, uni(sum), lane, 64, lane & 15, lane & 48, A.mask, A.tilecnt, A.ccs_flag, nullptr);
             }
         }
         return;
@@ -1555,6 +1560,8 @@ __global__ void __launch_bounds__(256) k_stream_capture(CaptureArgs A) {
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) qsum += __shfl_down(qsum, d, 64);
             if (lane == 0) A.bqsum[r] = qsum;
+            // the read filters have their last input: this read's proposals
+            if (A.mask) propose_read(R, A.D, A.C, A.H, A.P, r, uni(qsum), lane, 64, lane & 15, lane & 48, A.mask, A.tilecnt, A.ccs_flag, nullptr);
         }
     }
 #undef CAP_ISSUE
