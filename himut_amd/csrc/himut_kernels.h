@@ -369,11 +369,20 @@ __device__ __forceinline__ uint32_t cs_pack4(uint32_t f) {                      
 // it is bound by instruction issue.
 constexpr int MARK_CAP = 128;
 
+// The decode is bound by latency (a chain of three memory round trips per wave times the waves a CU holds), and what
+// limits the waves is the scalar registers: the values the wave keeps uniform.  256-thread workgroups are admitted
+// per CU up to 800 / (ceil(sgpr / 16) * 16 + 16) (MI355X_MICROARCH.md): 80 scalars give 8, the 106 the compiler takes
+// unasked give 6 -- the cap costs a few spills to vector lanes and is worth a tenth of the kernel.
+#ifndef HIMUT_PARSE_SGPR
+#define HIMUT_PARSE_SGPR 80
+#endif
 template <bool WITH_BQ>
-__global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbits,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(HIMUT_PARSE_SGPR)))
+k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbits,
                                                   int64_t nposwords) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
-    __shared__ int32_t s_start[4][PB + 8];                       // absolute offsets of the operation starts
+    __shared__ uint16_t s_start[4][PB + 8];                      // operation starts, relative to the step (an operation carried
+                                                                 // over from an earlier step keeps its start in a register)
     __shared__ int32_t s_mark[4][MARK_CAP];                      // substitution positions of the read (0-based)
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
@@ -393,7 +402,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
     const int n = (int)(uni(R.cs_off[r + 1]) - cs0);
     const uint8_t* cs = R.cs + cs0;
     uint8_t* txt = s_txt[wv];
-    int32_t* starts = s_start[wv];
+    uint16_t* starts = s_start[wv];
     Seg* segs = D.segs + sb;
     int32_t* mis = D.mis + sb;
     uint32_t* mq = D.mq + sb;
@@ -460,15 +469,14 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
         const int incl = wave_incl_add(cnt, lane);
         const int total = lane_val(incl, 63);
         const int off0 = have_carry ? 1 : 0;
-        if (have_carry && lane == 0) starts[0] = carry_start;
         {
             int w = off0 + incl - cnt;
             uint32_t mk = mask16;
-            while (mk) { const int i = __ffs((int)mk) - 1; mk &= mk - 1; starts[w++] = base + 16 * lane + i; }
+            while (mk) { const int i = __ffs((int)mk) - 1; mk &= mk - 1; starts[w++] = (uint16_t)(16 * lane + i); }
         }
         const int m = off0 + total;
         const bool last_block = base + PB >= n;
-        if (last_block && lane == 0) starts[m] = n;
+        if (last_block && lane == 0) starts[m] = (uint16_t)(n - base);
         const int nops = last_block ? m : m - 1;
         __builtin_amdgcn_wave_barrier();
         if (base == 0 && (m == 0 || starts[0] != 0)) bad = HIMUT_ERR_CS;   // the tag does not begin with an operation
@@ -479,7 +487,8 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
             const bool valid = k < nops;
             int s = 0, e = 0, kind = 0, len = 0, dt = 0, dq = 0, ref = 0, alt = 0;
             if (valid) {
-                s = starts[k]; e = starts[k + 1];
+                s = (k == 0 && have_carry) ? carry_start : base + (int)starts[k];
+                e = base + (int)starts[k + 1];
                 kind = (k == 0 && have_carry) ? carry_kind : (int)txt[32 + (s - base)];
                 len = e - s - 1;
                 if (kind == ':') {
@@ -543,7 +552,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
                 if (kind == '-') segs[w] = sg_del;
             }
             // mismatch list (cslib.py:54-62): substitutions with a non-N reference base, all indels
-            int aa = 0, ra = 0;
+            int aa = 0, ra = 0, seq_nib = -1;
             if (sub) {
                 aa = char2allele(alt);
                 if (aa < 0) bad = HIMUT_ERR_BASE;                    // caller.py:62
@@ -553,11 +562,7 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
                 // instruction issue, not by memory
                 if (ref != 'N' && !bad) {
                     if (qk < 0 || qk >= qlen) bad = HIMUT_ERR_CS;
-                    else {
-                        const int qa = nib2allele(nib_at(R.seq, M.qoff + qk));
-                        if (qa > 3) bad = HIMUT_ERR_BASE;
-                        else if (qa != aa) bad = HIMUT_ERR_CS;
-                    }
+                    else seq_nib = nib_at(R.seq, M.qoff + qk);       // looked at when the round is over: the load has the round to arrive
                 }
             }
             const bool ismis = indel || (sub && ref != 'N');
@@ -606,13 +611,18 @@ __global__ void __launch_bounds__(256) k_parse_cs(Reads R, Derived D, Params P, 
                 aligned_open = true;
             }
             last_kind = lane_val(kind, nvalid - 1);
+            if (seq_nib >= 0) {                                    // the substitutions' bases against SEQ
+                const int qa = nib2allele(seq_nib);
+                if (qa > 3) bad = HIMUT_ERR_BASE;
+                else if (qa != aa) bad = HIMUT_ERR_CS;
+            }
             if (__ballot(bad != 0)) break;
         }
         if (__ballot(bad != 0)) break;
         if (!last_block) {
             if (m > 0) {
                 have_carry = true;
-                carry_start = starts[m - 1];
+                carry_start = (m == 1 && off0 == 1) ? carry_start : base + (int)starts[m - 1];
                 carry_kind = (m == 1 && off0 == 1) ? carry_kind : (int)txt[32 + (carry_start - base)];
             }
         }
