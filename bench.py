@@ -22,19 +22,20 @@ if ROOT not in sys.path:
 CHR20_LEN = 64_444_167
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # algorithmic HBM bytes per unit of work, per kernel (DESIGN.md "Kernels and their rooflines")
-STAGE_KERNEL = {"ms_parse": "k_parse_cs", "ms_emit": "k_propose",
+STAGE_KERNEL = {"ms_parse": "k_parse_cs", "ms_emit": "k_mask_emit",
                 "ms_capture": "k_stream_capture", "ms_eval": "k_eval_columns"}   # a stage's dominant kernel
 
 
 def algorithmic_bytes(stage, st, cs_bytes):
     """Bytes the design has to move per launch, from the run's own counts."""
     rb, pos, cand, slots = st["read_bases"], st["positions"], st["n_candidates"], st["column_slots"]
-    if stage == "ms_capture":    # every quality byte + every packed base once, one 2-byte slot per pile cell kept
-        return rb * 1.5 + slots * 2.0
+    if stage == "ms_capture":    # every quality byte + every packed base once, one 2-byte slot per pile cell kept; the read's
+        # proposals ride on the same wave: its mismatch list in, a mask word per candidate
+        return rb * 1.5 + slots * 2.0 + cs_bytes / 4.0 * 8.0 + cand * 8.0
     if stage == "ms_parse":      # cs text in, ~16 B per cs operation out (segments + mismatch list), one bitmap word per mark
         return cs_bytes * 1.0 + cs_bytes / 4.0 * 16.0
-    if stage == "ms_emit":       # mismatch list in, mask word per candidate; the two sweeps read the position bitmap
-        return cs_bytes / 4.0 * 8.0 + cand * 16.0 + pos / 8.0
+    if stage == "ms_emit":       # the sweep reads the position bitmap and the marked mask cells, writes candidate + key
+        return pos / 8.0 + cand * (2.0 + 16.0)
     if stage == "ms_eval":       # column slots in, one 64-byte record out
         return slots * 2.0 + cand * 64.0
     if stage == "ms_index":      # position bitmap in, block table + empty column store out

@@ -789,16 +789,17 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
             __syncthreads();
             // ---- every thread down its column, in read order
             if (valid) {
-                // four rows at a time: the cells, then the three table values of each (the zero row unless the cell is the
-                // reference allele), are loaded before any of them is used: the LDS latency is paid once per four cells
-                for (int i0 = 0; i0 < nb; i0 += 4) {
-                    uint32_t v4[4];
-                    double th[4], tt[4], te[4];
-                    bool use4[4], ref4[4];
+                // NB rows at a time: the cells, then the three table values of each (the zero row unless the cell is the
+                // reference allele), are loaded before any of them is used: the LDS latency is paid once per NB cells
+                constexpr int NB = 2;      // (four at a time costs more in spills than the extra LDS round trips save)
+                for (int i0 = 0; i0 < nb; i0 += NB) {
+                    uint32_t v4[NB];
+                    double th[NB], tt[NB], te[NB];
+                    bool use4[NB], ref4[NB];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) v4[k] = i0 + k < nb ? (uint32_t)s_cells[i0 + k][tid] : (uint32_t)CELL_EMPTY;
+                    for (int k = 0; k < NB; k++) v4[k] = i0 + k < nb ? (uint32_t)s_cells[i0 + k][tid] : (uint32_t)CELL_EMPTY;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < NB; k++) {
                         const uint32_t v = v4[k];
                         const int ri = min(i0 + k, nb - 1);
                         // an EMPTY cell, or a read this chunk did not fetch (normcounts.py:289), adds nothing
@@ -808,7 +809,7 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
                         th[k] = s_lut[qe]; tt[k] = s_lut[257 + qe]; te[k] = s_lut[514 + qe];
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
+                    for (int k = 0; k < NB; k++)
                         NORM_CELL_Z(v4[k], use4[k], ref4[k], s_hap[min(i0 + k, nb - 1)], th[k], tt[k], te[k], acc1, acc2)
                 }
             }
