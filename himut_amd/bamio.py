@@ -77,6 +77,8 @@ def _load():
         L.bam_stream_prefetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
         L.bam_stream_head.restype = ctypes.c_int64
         L.bam_stream_head.argtypes = []
+        L.bam_stream_inflated_bytes.restype = ctypes.c_int64
+        L.bam_stream_inflated_bytes.argtypes = [ctypes.c_void_p]
         L.bam_write.restype = ctypes.c_int
         L.bam_write.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_WriteContig), ctypes.c_int64]
         _lib = L
@@ -187,6 +189,10 @@ class BamStream:
             pass
 
     sample = BamFile.sample
+
+    def inflated_bytes(self):
+        """Inflated bytes this stream has produced since it was opened (the header's blocks not counted)."""
+        return int(self._L.bam_stream_inflated_bytes(self._h))
 
     def ingest_contig(self, ctx, chrom, window_bytes=None):
         """Streams the records of ``chrom`` into the context ``ctx`` (an _ffi.Context), parsed on the device.  Two

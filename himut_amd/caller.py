@@ -221,21 +221,34 @@ def call_somatic_substitutions(
         share = [(c, d) for d, contigs in zip(devices, dist.lpt_assign(sizes, len(devices))) for c in contigs]
     starts = bamlib.sample_starts(chrom_lst, tname2tsize)
     resident, samples = {}, {}
-    for chrom, dev in share:
-        w = Worker(dev)
-        res = bam.ingest_contig(w.ctx, chrom)
-        ts, te, ql_, mq_, tp_ = w.ctx.ingest_read_meta(res["n_reads"])
-        # the thresholds are global (bamlib.py:137-178): what each contig contributes are the query lengths over its
-        # sampled windows, a few thousand integers
-        samples[chrom] = bamlib.sample_qlens(ts, te, ql_, mq_, tp_, starts[chrom])
-        resident[chrom] = w
-    if group is not None:
-        import torch.distributed as tdist
-        parts = [None] * group[1]
-        tdist.all_gather_object(parts, samples)
-        samples = {}
-        for p_ in parts:
-            samples.update(p_)
+
+    def ingest_share():
+        for chrom, dev in share:
+            w = Worker(dev)
+            resident[chrom] = w
+            res = bam.ingest_contig(w.ctx, chrom)
+            ts, te, ql_, mq_, tp_ = w.ctx.ingest_read_meta(res["n_reads"])
+            # the thresholds are global (bamlib.py:137-178): what each contig contributes are the query lengths over
+            # its sampled windows, a few thousand integers
+            samples[chrom] = bamlib.sample_qlens(ts, te, ql_, mq_, tp_, starts[chrom])
+
+    def close_share():
+        for w in resident.values():
+            w.close()
+        resident.clear()
+
+    if group is None:
+        ingest_share()
+    else:
+        # a rank that fails on one of its contigs (a record without cs, an unsorted file) still joins the collective
+        # and every rank leaves with the same error
+        err = None
+        try:
+            ingest_share()
+        except Exception as e:                  # noqa: BLE001 -- handed to every rank, re-raised there
+            err = e
+            close_share()
+        samples = {c: s for p_ in dist.share_or_raise(samples, err) for c, s in p_.items()}
     qlen_lower_limit, qlen_upper_limit, md_threshold = bamlib.thresholds_from_samples(samples, chrom_lst)
     if create_panel_of_normals:                                                             # caller.py:707-718
         (min_bq, min_gq, min_qv, min_mapq, min_trim, min_hap_count, min_sequence_identity, phase) = util.load_pon_params()
@@ -261,13 +274,24 @@ def call_somatic_substitutions(
             create_panel_of_normals, chrom2tsbs_lst, chrom2tsbs_log, device=dev, resident_worker=resident[chrom],
             chrom2records=chrom2records)
 
-    for chrom, dev in share:
-        scan(chrom, dev)
-        resident.pop(chrom).close()            # the contig's reads leave HBM
-    if group is not None:
+    def scan_share():
+        for chrom, dev in share:
+            scan(chrom, dev)
+            resident.pop(chrom).close()        # the contig's reads leave HBM
+
+    if group is None:
+        scan_share()
+    else:
         # one process per GPU (torch.distributed.run): one exchange at the end brings every contig's record buffer and
-        # counters to rank 0, which writes the files
+        # counters to rank 0, which writes the files; before it the ranks agree that every scan went through
         rank, world, dev = group
+        err = None
+        try:
+            scan_share()
+        except Exception as e:                  # noqa: BLE001
+            err = e
+            close_share()
+        dist.share_or_raise(None, err)
         res = dist.gather_contig_results({c: (chrom2records[c], chrom2tsbs_log[c]) for c in chrom2records},
                                          chrom_lst, rank, world)
         if rank != 0:

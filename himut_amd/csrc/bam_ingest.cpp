@@ -891,7 +891,7 @@ struct BamStream {
     bool done = false, unique = true;
     std::string err;
     double t_inflate = 0, t_hop = 0;      // HIMUT_INGEST_PROFILE
-    int64_t n_windows = 0;
+    int64_t n_windows = 0, inflated_bytes = 0;   // inflated_bytes: what this stream has inflated since it was opened (header blocks excluded)
     std::future<std::string> inflating;   // the window being inflated in the background (bam_stream_prefetch)
     std::vector<size_t> inf_off;
     size_t inf_tot = 0;
@@ -1007,6 +1007,7 @@ int64_t bam_stream_n_ref(void* h) { return (int64_t)((BamStream*)h)->hdr.contigs
 const char* bam_stream_ref_name(void* h, int64_t i) { return ((BamStream*)h)->hdr.contigs[(size_t)i].name.c_str(); }
 int64_t bam_stream_ref_len(void* h, int64_t i) { return ((BamStream*)h)->hdr.contigs[(size_t)i].length; }
 int bam_stream_indexed(void* h) { return ((BamStream*)h)->have_bai ? 1 : 0; }
+int64_t bam_stream_inflated_bytes(void* h) { return ((BamStream*)h)->inflated_bytes; }
 int bam_stream_unique_names(void* h) { return ((BamStream*)h)->unique ? 1 : 0; }
 void bam_stream_close(void* h) {
     BamStream* S = (BamStream*)h;
@@ -1063,7 +1064,7 @@ int bam_stream_prefetch(void* h, uint8_t* buf, int64_t cap) {
         while (b1 < S->blk_end && (int64_t)(BAM_STREAM_HEAD + tot + B[b1].isize) <= cap) { S->inf_off.push_back(tot); tot += B[b1].isize; b1++; }
         if (b1 == b0) { S->err = "ingest window smaller than a BGZF block"; return -2; }
         S->blk = b1;
-        S->inf_tot = tot; S->inf_buf = buf;
+        S->inf_tot = tot; S->inf_buf = buf; S->inflated_bytes += (int64_t)tot;
         uint8_t* dst = buf + BAM_STREAM_HEAD;
         S->inflating = std::async(std::launch::async, [S, b0, b1, dst]() {
             const double t0 = now_s();

@@ -57,6 +57,29 @@ def leave_group():
         dist.destroy_process_group()
 
 
+class RankError(RuntimeError):
+    """Some rank of the group failed; raised on EVERY rank so that none is left waiting in a collective."""
+
+
+def share_or_raise(payload, error=None):
+    """The ranks' payloads (a list, rank order) -- or RankError on every rank when any rank passes an ``error``
+    (the exception it caught while doing its share).  The first collective after a stretch of per-rank work: a rank
+    that failed still joins it, so its peers do not hang until the backend's timeout; the group is torn down before
+    raising."""
+    import torch.distributed as dist
+    parts = [None] * dist.get_world_size()
+    msg = None if error is None else "{}: {}".format(type(error).__name__, error)
+    dist.all_gather_object(parts, (msg, None if error is not None else payload))
+    failed = [(r, m) for r, (m, _) in enumerate(parts) if m is not None]
+    if failed:
+        leave_group()
+        text = "; ".join("rank {}: {}".format(r, m) for r, m in failed)
+        if error is not None:
+            raise RankError(text) from error
+        raise RankError(text)
+    return [p for _, p in parts]
+
+
 def broadcast_ints(values, src=0):
     """The integers of rank ``src`` on every rank."""
     import torch

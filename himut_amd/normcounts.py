@@ -63,7 +63,8 @@ def norm_contig(worker, batch, chunks, refseq, pon_keys=None, common_keys=None, 
     ctx.set_reference(refseq, cls, len(chars))
     if phase_sets is not None:
         ctx.set_phase(*pack_phase_sets(chunks, *phase_sets))
-    ctx.push_reads(batch)
+    if batch is not None:               # None: the contig's reads are in HBM already (bamio.BamStream.ingest_contig)
+        ctx.push_reads(batch)
     ctx.run_normcounts(alt_order_table(alt_order), non_human_sample)
     ccs, ref, log = ctx.normcounts()
     d_ccs, d_ref = tri_dicts(chars, ccs, ref)
@@ -76,6 +77,7 @@ def get_callable_tricounts(
     min_bq, mismatch_window, max_mismatch_count, min_ref_count, min_alt_count, min_hap_count, md_threshold,
     somatic_snv_prior, germline_snv_prior, germline_indel_prior, phase, non_human_sample,
     chrom2ccs_callable_tri2count, chrom2ref_callable_tri2count, chrom2norm_log, device=0, read_batch=None,
+    resident_worker=None,
 ):
     """Drop-in for himut.normcounts.get_callable_tricounts (normcounts.py:206): same arguments, same three
     assignments."""
@@ -89,10 +91,10 @@ def get_callable_tricounts(
         pon_keys = site_keys(vcflib.load_pon(chrom, panel_of_normals))
     elif panel_of_normals is not None and panel_of_normals.endswith(".bgz"):  # normcounts.py:273-282
         pon_keys = site_keys(vcflib.load_bgz_pon(chrom, panel_of_normals))
-    if read_batch is None:
+    if resident_worker is None and read_batch is None:
         from . import bamio
         read_batch = bamio.read_contig(bam_file, chrom)
-    w = _worker_for(device)
+    w = resident_worker if resident_worker is not None else _worker_for(device)
     w.configure(min_qv, min_mapq, qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, min_trim,
                 max_mismatch_count, mismatch_window, md_threshold, min_ref_count, min_alt_count, min_hap_count,
                 germline_snv_prior, phase)
@@ -348,10 +350,13 @@ def get_normcounts(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, comm
                    germline_snv_prior, germline_indel_prior, threads, phase, non_human_sample, reference_sample,
                    out_file, devices=(0,), log_path="norm.log"):
     """Driver of `himut normcounts` (normcounts.py:424-592): same arguments, the same table and norm.log; the PDF
-    plot is left out.  Contigs go to the GPUs of ``devices`` round-robin."""
+    plot is left out.  Contigs go to the GPUs of ``devices`` round-robin.  A contig's reads come in through the
+    device-side ingest (bamio.BamStream), one contig at a time: a process inflates only the BGZF blocks of the contigs it
+    sweeps itself."""
     from . import bamio, dist, util, vcflib
+    from .caller import Worker
     group = dist.join_group(devices)       # (rank, world, device) under torch.distributed.run, else None
-    bam = bamio.read_bam(bam_file)
+    bam = bamio.BamStream(bam_file, threads if threads and threads > 1 else 0)
     tname2tsize = bam.tname2tsize
     chrom_lst, chrom2chunkloci_lst = util.load_loci(region, region_list, tname2tsize)
     ps2hbit, ps2hpos, ps2hetsnp = {}, {}, {}
@@ -365,23 +370,33 @@ def get_normcounts(bam_file, ref_file, sbs_file, vcf_file, phased_vcf_file, comm
     ccs, ref, log = {}, {}, {}
 
     def sweep(chrom, dev):
+        w = Worker(dev)
+        try:
+            bam.ingest_contig(w.ctx, chrom)
+            sweep_resident(chrom, dev, w)
+        finally:
+            w.close()                      # the contig's reads leave HBM
+
+    def sweep_resident(chrom, dev, w):
         get_callable_tricounts(
             chrom, refseq[chrom], bam_file, common_snps, panel_of_normals, chrom2chunkloci_lst[chrom],
             ps2hbit.get(chrom, {}), ps2hpos.get(chrom, {}), ps2hetsnp.get(chrom, {}), min_qv, min_mapq, min_trim,
             qlen_lower_limit, qlen_upper_limit, min_sequence_identity, min_gq, min_bq, mismatch_window,
             max_mismatch_count, min_ref_count, min_alt_count, min_hap_count, md_threshold, somatic_snv_prior,
             germline_snv_prior, germline_indel_prior, phase, non_human_sample, ccs, ref, log,
-            device=dev, read_batch=bam.batches[chrom])
+            device=dev, resident_worker=w)
 
     if group is not None:
         # one process per GPU: each rank sweeps its LPT share of the contigs; the per-contig dictionaries (a few
         # hundred integers each) are collected on every rank and rank 0 writes the table
-        import torch.distributed as tdist
         rank, world, dev = group
-        for chrom in dist.lpt_assign({c: tname2tsize[c] for c in chrom_lst}, world)[rank]:
-            sweep(chrom, dev)
-        parts = [None] * world
-        tdist.all_gather_object(parts, (ccs, ref, log))
+        err = None
+        try:
+            for chrom in dist.lpt_assign({c: tname2tsize[c] for c in chrom_lst}, world)[rank]:
+                sweep(chrom, dev)
+        except Exception as e:              # noqa: BLE001 -- every rank leaves with the same error (dist.share_or_raise)
+            err = e
+        parts = dist.share_or_raise((ccs, ref, log), err)
         dist.leave_group()
         if rank != 0:
             return None, None, None

@@ -115,3 +115,43 @@ def test_gather_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "GATHER_OK" in outs[0] and "EXCHANGE_OK" in outs[0] and "EXCHANGE1_OK" in outs[0], outs[0]
+
+
+ERR_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from himut_amd import dist as hdist
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+# a stretch of per-rank work in which every rank succeeds ...
+parts = hdist.share_or_raise({"rank": rank})
+assert [p["rank"] for p in parts] == list(range(world))
+# ... and one in which rank 1 fails: both ranks must leave with RankError naming rank 1, none may hang
+err = None
+try:
+    if rank == 1:
+        raise KeyError("tag 'cs' not present")
+except Exception as e:
+    err = e
+try:
+    hdist.share_or_raise("payload", err)
+except hdist.RankError as e:
+    assert "rank 1: KeyError" in str(e), str(e)
+    assert not dist.is_initialized()
+    print("RANKERROR_OK")
+    sys.exit(3)
+print("NOT RAISED")
+'''
+
+
+def test_failed_rank_takes_every_rank_down_gloo(tmp_path):
+    """ADVICE r1: a rank that raises in its share must not leave the peers blocked in the next collective."""
+    script = tmp_path / "e.py"
+    script.write_text(ERR_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29619", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert [p.returncode for p in procs] == [3, 3], "\n".join(outs)
+    assert all("RANKERROR_OK" in o for o in outs), "\n".join(outs)

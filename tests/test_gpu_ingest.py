@@ -59,7 +59,13 @@ def test_two_contig_bam_device_parse_equals_host_parse(worker, tmp_path, monkeyp
     st = bamio.BamStream(path, threads=3)
     assert st.indexed == index and st.sample() == "sampleA" and st.tname2tsize == host.tname2tsize
     for chrom in ("chr10", "chr2", "chr10"):           # any order, a contig twice
+        before = st.inflated_bytes()
         res = st.ingest_contig(worker.ctx, chrom, window_bytes=window_kb << 10)
+        if index:
+            # a process that takes only this contig (its rank's share under torch.distributed.run) inflates this
+            # contig's blocks and no others: its record bytes + at most a block either side
+            own = sum(36 + 64 + int(q) + (int(q) + 1) // 2 for q in host.batches[chrom].qlen) + len(host.batches[chrom].cs)
+            assert res["n_reads"] * 40 < st.inflated_bytes() - before <= own + 2 * 65536 + 512 * res["n_reads"]
         got = worker.ctx.download_reads(res, chrom, st.tname2tsize[chrom])
         _same(got, host.batches[chrom])
         assert res["read_bases"] == host.batches[chrom].total_read_bases()
