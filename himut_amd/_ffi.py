@@ -282,6 +282,18 @@ class Context:
         self._check(self._L.himut_ingest_begin(self._h, int(inflated_bound), int(window_bytes)))
         return [self._L.himut_ingest_buffer(self._h, k) for k in (0, 1)]
 
+    @property
+    def handle(self):
+        """The himut_ctx* (for a host library that calls the C ABI itself: bamio's ingest pump)."""
+        return self._h
+
+    def fn_address(self, name):
+        """Address of an exported function of the library, as a void*."""
+        return ctypes.cast(getattr(self._L, name), ctypes.c_void_p)
+
+    def raise_for(self, rc):
+        self._check(rc)
+
     def ingest_wait(self, slot):
         self._check(self._L.himut_ingest_wait(self._h, int(slot)))
 

@@ -75,10 +75,15 @@ def _load():
                                       ctypes.c_void_p]
         L.bam_stream_prefetch.restype = ctypes.c_int
         L.bam_stream_prefetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        L.bam_stream_pump.restype = ctypes.c_int
+        L.bam_stream_pump.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64]
+        L.bam_stream_wait.restype = ctypes.c_int
+        L.bam_stream_wait.argtypes = [ctypes.c_void_p]
         L.bam_stream_head.restype = ctypes.c_int64
         L.bam_stream_head.argtypes = []
-        L.bam_stream_inflated_bytes.restype = ctypes.c_int64
-        L.bam_stream_inflated_bytes.argtypes = [ctypes.c_void_p]
+        for f in ("bam_stream_inflated_bytes", "bam_stream_scan_parts"):
+            getattr(L, f).restype = ctypes.c_int64
+            getattr(L, f).argtypes = [ctypes.c_void_p]
         L.bam_write.restype = ctypes.c_int
         L.bam_write.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_WriteContig), ctypes.c_int64]
         _lib = L
@@ -207,31 +212,14 @@ class BamStream:
         cap = window_bytes + L.bam_stream_head()       # head room for the record a window boundary cuts
         bufs = ctx.ingest_begin(bound.value, cap)
         rec_cap = window_bytes // 64 + 16
-        rec_off = [np.zeros(rec_cap, np.uint32) for _ in (0, 1)]
-        qid = [np.zeros(rec_cap, np.int32) for _ in (0, 1)]
-        start, nbytes = ctypes.c_int64(), ctypes.c_int64()
-        sums = np.zeros(2, np.int64)
-
-        def fail():
+        # the loop -- wait for window k's inflate, start window k + 1's, hop over k's records, hand k to the GPU -- is one
+        # call into the host library, which calls the device library's himut_ingest_wait / himut_ingest_window itself
+        rc = L.bam_stream_pump(h, ctx.handle, ctx.fn_address("himut_ingest_wait"), ctx.fn_address("himut_ingest_window"),
+                               bufs[0], bufs[1], cap, rec_cap)
+        if rc == -2:
             raise ValueError("{}: {}".format(self.path, L.bam_stream_error(h).decode()))
-        slot = 0
-        if L.bam_stream_prefetch(h, bufs[0], cap) < 0:
-            fail()
-        while True:
-            n = L.bam_stream_next(h, bufs[slot], cap, _p(rec_off[slot]), _p(qid[slot]), rec_cap, ctypes.byref(start),
-                                  ctypes.byref(nbytes), _p(sums))
-            if n == -1:
-                break
-            if n < 0:
-                fail()
-            # the pool goes on with the next window (into the other buffer, once its bytes of two windows ago have left
-            # the host) while this one is handed to the GPU
-            ctx.ingest_wait(slot ^ 1)
-            if L.bam_stream_prefetch(h, bufs[slot ^ 1], cap) < 0:
-                fail()
-            if n > 0:
-                ctx.ingest_window(slot, start.value, nbytes.value, rec_off[slot], qid[slot], n, int(sums[0]), int(sums[1]))
-            slot ^= 1
+        if rc:
+            ctx.raise_for(rc)
         res = ctx.ingest_end(bool(L.bam_stream_unique_names(h)))
         if res["n_missing_cs"]:
             # the reference does line.get_tag("cs") on every record (bamlib.py:32)

@@ -86,9 +86,10 @@ struct Bgzf {
     std::future<std::string> pending;
     bool started = false;
 
+    size_t scan_parts = 1;           // stretches the block table was made from (threads used)
     size_t WINDOW = (size_t)64 << 20;   // HIMUT_INGEST_WINDOW_KB overrides (tests use small windows)
 
-    bool open(const char* path, int nthreads) {
+    bool open(const char* path, int nthreads, const std::vector<size_t>* hints = nullptr) {
         threads = nthreads < 1 ? 1 : nthreads;
         if (const char* e = getenv("HIMUT_INGEST_WINDOW_KB")) { const long kb = atol(e); if (kb > 0) WINDOW = (size_t)kb << 10; }
         fd = ::open(path, O_RDONLY);
@@ -111,7 +112,7 @@ struct Bgzf {
             }
             base = owned.data();
         }
-        return scan();
+        return scan(hints);
     }
     void close() {
         if (pending.valid()) (void)pending.get();
@@ -119,24 +120,27 @@ struct Bgzf {
         if (fd >= 0) ::close(fd);
         base = nullptr; fd = -1;
     }
-    // block headers -> (offset, compressed length, inflated length); windows of ~WINDOW output bytes
-    bool scan() {
-        size_t p = 0, wbytes = 0;
-        win_first.push_back(0);
-        // the block headers are read with pread (a few bytes each) rather than through the mapping: a page fault per
-        // block costs several times more, and the pages are faulted in by the inflate threads in parallel anyway
-        uint8_t hb[64], tb[4];
-        while (p < fsize) {
-            if (p + 18 > fsize) { err = "truncated BGZF header"; return false; }
-            const uint8_t* h = base + p;
-            if (fd >= 0 && owned.empty()) {
-                const size_t want = std::min<size_t>(sizeof(hb), fsize - p);
-                if (::pread(fd, hb, want, (off_t)p) == (ssize_t)want) h = hb;
-            }
-            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
+    // Block headers of the file range [p0, p1) -> (offset, compressed length, inflated length).  One pread per block:
+    // the last four bytes of a block (its inflated length) and the header of the next block are neighbours.  (Through
+    // the mapping a page fault per block costs several times more, and the pages are faulted in by the inflate threads
+    // in parallel anyway.)  Returns "" or an error; "split" when the range does not end on a block boundary.
+    std::string scan_range(size_t p0, size_t p1, std::vector<BlockRef>& out) const {
+        uint8_t cur[64], nx[68];
+        const bool pr = fd >= 0 && owned.empty();
+        auto fetch = [&](size_t at, uint8_t* dst, size_t want) {
+            const size_t w = std::min(want, fsize - at);
+            if (!(pr && ::pread(fd, dst, w, (off_t)at) == (ssize_t)w)) memcpy(dst, base + at, w);
+            return w;
+        };
+        size_t p = p0;
+        if (p < p1) (void)fetch(p, cur, sizeof(cur));
+        while (p < p1) {
+            if (p + 18 > fsize) return "truncated BGZF header";
+            const uint8_t* h = cur;
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return "not a BGZF block";
             const unsigned xlen = h[10] | (h[11] << 8);
-            if (h == hb && 12 + xlen > sizeof(hb)) h = base + p;          // unusually long extra field: through the mapping
-            if (p + 12 + xlen > fsize) { err = "truncated BGZF header"; return false; }
+            if (p + 12 + xlen > fsize) return "truncated BGZF header";
+            if (12 + xlen > sizeof(cur)) h = base + p;          // unusually long extra field: through the mapping
             int bsize = -1;
             for (size_t k = 0; k + 4 <= xlen;) {      // BC is normally the first subfield; tolerate others
                 const uint8_t* e = h + 12 + k;
@@ -144,21 +148,63 @@ struct Bgzf {
                 if (e[0] == 'B' && e[1] == 'C' && slen == 2 && k + 6 <= xlen) bsize = e[4] | (e[5] << 8);
                 k += 4 + slen;
             }
-            if (bsize < 0) { err = "BGZF block without BC field"; return false; }
+            if (bsize < 0) return "BGZF block without BC field";
             const size_t total = (size_t)bsize + 1;
-            if (total < 12 + xlen + 8 || p + total > fsize) { err = "truncated BGZF block"; return false; }
+            if (total < 12 + xlen + 8 || p + total > fsize) return "truncated BGZF block";
             BlockRef b;
             b.file_off = p;
             b.cdata_off = p + 12 + xlen;
             b.cdata_len = (uint32_t)(total - 12 - xlen - 8);
-            const uint8_t* t = base + p + total - 4;
-            if (fd >= 0 && owned.empty() && ::pread(fd, tb, 4, (off_t)(p + total - 4)) == 4) t = tb;
-            b.isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
-            if (wbytes && wbytes + b.isize > WINDOW) { win_first.push_back(blocks.size()); wbytes = 0; }
+            const size_t got = fetch(p + total - 4, nx, sizeof(nx));
+            b.isize = nx[0] | (nx[1] << 8) | (nx[2] << 16) | ((uint32_t)nx[3] << 24);
+            b.uoff = 0;
+            out.push_back(b);
+            p += total;
+            memset(cur, 0, sizeof(cur));
+            if (got > 4) memcpy(cur, nx + 4, got - 4);
+        }
+        return p == p1 ? "" : "split";
+    }
+    // The whole file's block table; windows of ~WINDOW output bytes.  ``hints``: file offsets at which blocks are known
+    // to start (an index beside the file lists some): the table is then made by several threads, a stretch of the file
+    // each; a hint that turns out wrong only costs the serial scan.
+    bool scan(const std::vector<size_t>* hints = nullptr) {
+        std::vector<size_t> cut(1, 0);
+        const size_t T = (size_t)std::min(threads, 16);
+        size_t min_size = (size_t)8 << 20;            // below it the serial scan is as fast (tests lower it)
+        if (const char* e = getenv("HIMUT_INGEST_SCAN_MIN_KB")) min_size = (size_t)atol(e) << 10;
+        if (hints && !hints->empty() && T > 1 && fsize > min_size)
+            for (size_t i = 1; i < T; i++) {
+                auto it = std::lower_bound(hints->begin(), hints->end(), fsize / T * i);
+                if (it != hints->end() && *it > cut.back() && *it < fsize) cut.push_back(*it);
+            }
+        cut.push_back(fsize);
+        const size_t np = cut.size() - 1;
+        scan_parts = np;
+        std::vector<std::vector<BlockRef>> part(np);
+        std::vector<std::string> perr(np);
+        if (np > 1) {
+            std::vector<std::thread> pool;
+            for (size_t i = 1; i < np; i++) pool.emplace_back([&, i]() { perr[i] = scan_range(cut[i], cut[i + 1], part[i]); });
+            perr[0] = scan_range(cut[0], cut[1], part[0]);
+            for (auto& th : pool) th.join();
+            bool ok = true;
+            for (const auto& e : perr) ok = ok && e.empty();
+            if (!ok) { part.assign(1, {}); perr.assign(1, ""); cut = {0, fsize}; scan_parts = 1; }
+        }
+        if (part.size() == 1 && part[0].empty()) perr[0] = scan_range(0, fsize, part[0]);
+        if (!perr[0].empty()) { err = perr[0] == "split" ? "truncated BGZF block" : perr[0]; return false; }
+        size_t nb = 0;
+        for (const auto& v : part) nb += v.size();
+        blocks.reserve(nb);
+        for (const auto& v : part) blocks.insert(blocks.end(), v.begin(), v.end());
+        size_t wbytes = 0;
+        win_first.push_back(0);
+        for (size_t k = 0; k < blocks.size(); k++) {
+            BlockRef& b = blocks[k];
+            if (wbytes && wbytes + b.isize > WINDOW) { win_first.push_back(k); wbytes = 0; }
             b.uoff = wbytes;
             wbytes += b.isize;
-            blocks.push_back(b);
-            p += total;
         }
         win_first.push_back(blocks.size());
         return true;
@@ -896,8 +942,54 @@ struct BamStream {
     std::vector<size_t> inf_off;
     size_t inf_tot = 0;
     uint8_t* inf_buf = nullptr;
+    std::vector<uint32_t> pump_off[2];    // bam_stream_pump's record lists: handed to the device asynchronously, so they
+    std::vector<int32_t> pump_qid[2];     // live as long as the stream, not as long as the call
+    bool ready = false;                   // a window is inflated and waits for its hop (bam_stream_wait)
+    size_t ready_tot = 0;
+    uint8_t* ready_buf = nullptr;
 };
 constexpr size_t BAM_STREAM_HEAD = (size_t)4 << 20;
+
+// File offsets at which the index says BGZF blocks start (chunk begins and linear-index entries), sorted.  Only hints
+// for the parallel block scan: a wrong or stale index costs nothing but the serial scan.
+static std::vector<size_t> bai_block_hints(const std::string& path) {
+    std::vector<size_t> out;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return out;
+    std::vector<uint8_t> d;
+    uint8_t tmp[1 << 16];
+    size_t k;
+    while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) d.insert(d.end(), tmp, tmp + k);
+    fclose(f);
+    size_t p = 0;
+    auto need = [&](uint64_t n) { return p + n <= d.size(); };
+    auto r32 = [&]() { const uint32_t v = le32(&d[p]); p += 4; return v; };
+    auto r64 = [&]() { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)d[p + i] << (8 * i); p += 8; return v; };
+    if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) return out;
+    p = 4;
+    const uint32_t n = r32();
+    for (uint32_t i = 0; i < n; i++) {
+        if (!need(4)) return out;
+        const uint32_t nbin = r32();
+        for (uint32_t b = 0; b < nbin; b++) {
+            if (!need(8)) return out;
+            const uint32_t bin = r32(), nch = r32();
+            if (!need(16ull * nch)) return out;
+            for (uint32_t c = 0; c < nch; c++) {
+                const uint64_t beg = r64();
+                (void)r64();
+                if (bin != 37450) out.push_back((size_t)(beg >> 16));
+            }
+        }
+        if (!need(4)) return out;
+        const uint32_t nint = r32();
+        if (!need(8ull * nint)) return out;
+        for (uint32_t c = 0; c < nint; c++) { const uint64_t v = r64(); if (v) out.push_back((size_t)(v >> 16)); }
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    return out;
+}
 
 static bool read_bai(const std::string& path, size_t n_ref, std::vector<std::pair<uint64_t, uint64_t>>& out) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -947,7 +1039,9 @@ void* bam_stream_open(const char* path, int threads) {
             if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
         }
         Bgzf& z = S->z;
-        if (!z.open(path, threads)) { S->err = z.err; return S; }
+        std::vector<size_t> hints;
+        if (!getenv("HIMUT_INGEST_NO_INDEX")) hints = bai_block_hints(std::string(path) + ".bai");
+        if (!z.open(path, threads, &hints)) { S->err = z.err; return S; }
         // the header sits in the first block or two: they are inflated one at a time, not a window at a time
         size_t consumed = 0, hb_next = 0;
         std::vector<uint8_t> hbuf;
@@ -1007,6 +1101,7 @@ int64_t bam_stream_n_ref(void* h) { return (int64_t)((BamStream*)h)->hdr.contigs
 const char* bam_stream_ref_name(void* h, int64_t i) { return ((BamStream*)h)->hdr.contigs[(size_t)i].name.c_str(); }
 int64_t bam_stream_ref_len(void* h, int64_t i) { return ((BamStream*)h)->hdr.contigs[(size_t)i].length; }
 int bam_stream_indexed(void* h) { return ((BamStream*)h)->have_bai ? 1 : 0; }
+int64_t bam_stream_scan_parts(void* h) { return (int64_t)((BamStream*)h)->z.scan_parts; }
 int64_t bam_stream_inflated_bytes(void* h) { return ((BamStream*)h)->inflated_bytes; }
 int bam_stream_unique_names(void* h) { return ((BamStream*)h)->unique ? 1 : 0; }
 void bam_stream_close(void* h) {
@@ -1025,6 +1120,7 @@ int bam_stream_select(void* h, int32_t ref_id, int64_t* inflated_bound) {
     BamStream* S = (BamStream*)h;
     if (ref_id < 0 || (size_t)ref_id >= S->hdr.contigs.size()) { S->err = "no such contig"; return 1; }
     if (S->inflating.valid()) (void)S->inflating.get();
+    S->ready = false;
     S->target = ref_id; S->carry.clear(); S->names.clear(); S->nkept = 0; S->done = false; S->unique = true;
     const auto& B = S->z.blocks;
     S->blk = S->first_block; S->skip = S->first_skip; S->blk_end = B.size();
@@ -1076,6 +1172,21 @@ int bam_stream_prefetch(void* h, uint8_t* buf, int64_t cap) {
     } catch (const std::exception& e) { S->err = std::string("BAM stream: ") + e.what(); return -2; }
 }
 
+// Waits for the inflate in flight.  Returns 1 when a window is now ready for bam_stream_next, 0 when none was in flight,
+// -2 on error.  After it the next prefetch may be started BEFORE the hop over this window (bam_stream_next), so the
+// pool never idles while one thread walks the records.
+int bam_stream_wait(void* h) {
+    BamStream* S = (BamStream*)h;
+    try {
+        if (S->ready) return 1;
+        if (!S->inflating.valid()) return 0;
+        const std::string e = S->inflating.get();
+        if (!e.empty()) { S->err = e; return -2; }
+        S->ready = true; S->ready_tot = S->inf_tot; S->ready_buf = S->inf_buf;
+        return 1;
+    } catch (const std::exception& e) { S->err = std::string("BAM stream: ") + e.what(); return -2; }
+}
+
 // Finishes the window whose inflate bam_stream_prefetch(buf) started (or, with none in flight, inflates one now): hops
 // over the records and lists the kept ones (this contig, mapped): rec_off[k] = offset of record k's body (behind its
 // length field) from buf + *start, qid[k] = index of the first kept record with the same read name.  The records occupy
@@ -1088,18 +1199,18 @@ int64_t bam_stream_next(void* h, uint8_t* buf, int64_t cap, uint32_t* rec_off, i
     *nbytes = 0; *start = 0;
     sums[0] = sums[1] = 0;
     try {
-        if (!S->inflating.valid()) {
+        if (!S->ready && !S->inflating.valid()) {
             if (S->done) return -1;
             const int r = bam_stream_prefetch(h, buf, cap);
             if (r < 0) return -2;
             if (r == 0 && S->carry.empty()) return -1;
         }
+        if (!S->ready && bam_stream_wait(h) < 0) return -2;
         size_t tot = 0;
-        if (S->inflating.valid()) {
-            if (S->inf_buf != buf) { (void)S->inflating.get(); S->err = "bam_stream_next on a buffer other than the prefetched one"; return -2; }
-            const std::string e = S->inflating.get();
-            if (!e.empty()) { S->err = e; return -2; }
-            tot = S->inf_tot;
+        if (S->ready) {
+            S->ready = false;
+            if (S->ready_buf != buf) { S->err = "bam_stream_next on a buffer other than the prefetched one"; return -2; }
+            tot = S->ready_tot;
         }
         const double t_h0 = now_s();
         const size_t c = S->carry.size();
@@ -1140,9 +1251,12 @@ int64_t bam_stream_next(void* h, uint8_t* buf, int64_t cap, uint32_t* rec_off, i
         *start = (int64_t)(BAM_STREAM_HEAD - c + first);
         *nbytes = (int64_t)(pos - first);
         S->t_hop += now_s() - t_h0;
+        // nothing more comes once every block is taken AND no window is being inflated or waits for its hop (the next
+        // prefetch may have been started before this hop)
+        const bool last = S->blk >= S->blk_end && !S->inflating.valid() && !S->ready;
         if (!S->done) {
             if (pos < nb) S->carry.assign(dst + pos, dst + nb);
-            if (S->blk >= S->blk_end && !S->carry.empty() && n < rec_cap) {
+            if (last && !S->carry.empty() && n < rec_cap) {
                 // the last block ended inside a record: an indexed range ends with the contig's last record, so what is
                 // left belongs to the next contig; without an index the file is truncated
                 if (!S->have_bai && S->carry.size() >= 4) { S->err = "truncated BAM record"; return -2; }
@@ -1150,7 +1264,53 @@ int64_t bam_stream_next(void* h, uint8_t* buf, int64_t cap, uint32_t* rec_off, i
             }
         }
         if (n > 0) return n;
-        if (S->done || (S->blk >= S->blk_end && S->carry.empty())) return -1;
+        if (S->done || (last && S->carry.empty())) return -1;
+        return 0;
+    } catch (const std::exception& e) { S->err = std::string("BAM stream: ") + e.what(); return -2; }
+}
+
+// The whole loop of one contig's ingest in one call (no interpreter between the steps: a Python thread that parses the
+// side VCFs meanwhile would otherwise hold the GIL against every one of them).  ``wait_fn`` / ``window_fn`` are
+// libhimut_hip.so's himut_ingest_wait / himut_ingest_window, ``bufs`` its two pinned windows of ``cap`` bytes.
+// Returns 0, -2 on a stream error (bam_stream_error), or the positive error code of the device library.
+typedef int (*ingest_wait_fn)(void*, int);
+typedef int (*ingest_window_fn)(void*, int, int64_t, int64_t, const uint32_t*, const int32_t*, int64_t, int64_t, int64_t);
+int bam_stream_pump(void* h, void* ctx, void* wait_fn, void* window_fn, uint8_t* buf0, uint8_t* buf1, int64_t cap, int64_t rec_cap) {
+    BamStream* S = (BamStream*)h;
+    try {
+        ingest_wait_fn wait = (ingest_wait_fn)wait_fn;
+        ingest_window_fn window = (ingest_window_fn)window_fn;
+        uint8_t* bufs[2] = {buf0, buf1};
+        std::vector<uint32_t>* rec_off = S->pump_off;
+        std::vector<int32_t>* qid = S->pump_qid;
+        for (int k = 0; k < 2; k++) { rec_off[k].resize((size_t)rec_cap); qid[k].resize((size_t)rec_cap); }
+        int slot = 0;
+        const bool prof = getenv("HIMUT_INGEST_PROFILE") != nullptr;
+        double t_wait_inf = 0, t_wait_dev = 0, t_window = 0, t_first_window = 0, t_hop0 = S->t_hop;
+        int64_t nwin = 0;
+        if (bam_stream_prefetch(h, bufs[0], cap) < 0) return -2;
+        for (;;) {
+            // window `slot` is inflated: the pool goes on with the next one (into the other buffer, once its bytes of two
+            // windows ago have left the host) while this thread hops over the records and hands the window to the GPU
+            double t0 = prof ? now_s() : 0;
+            if (bam_stream_wait(h) < 0) return -2;
+            double t1 = prof ? now_s() : 0;
+            int rc = wait(ctx, slot ^ 1);
+            if (rc) return rc;
+            if (prof) { t_wait_inf += t1 - t0; t_wait_dev += now_s() - t1; }
+            if (bam_stream_prefetch(h, bufs[slot ^ 1], cap) < 0) return -2;
+            int64_t start = 0, nbytes = 0, sums[2] = {0, 0};
+            const int64_t n = bam_stream_next(h, bufs[slot], cap, rec_off[slot].data(), qid[slot].data(), rec_cap, &start, &nbytes, sums);
+            if (n == -1) break;
+            if (n < 0) return -2;
+            t0 = prof ? now_s() : 0;
+            if (n > 0 && (rc = window(ctx, slot, start, nbytes, rec_off[slot].data(), qid[slot].data(), n, sums[0], sums[1])) != 0) return rc;
+            if (prof) { const double dt = now_s() - t0; t_window += dt; if (!nwin) t_first_window = dt; nwin++; }
+            slot ^= 1;
+        }
+        if (prof)
+            fprintf(stderr, "pump (s): waiting for inflate %.3f, for the device %.3f, hop %.3f, handing over %.3f (first window %.3f) in %lld windows\n",
+                    t_wait_inf, t_wait_dev, S->t_hop - t_hop0, t_window, t_first_window, (long long)nwin);
         return 0;
     } catch (const std::exception& e) { S->err = std::string("BAM stream: ") + e.what(); return -2; }
 }

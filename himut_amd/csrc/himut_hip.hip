@@ -3,6 +3,7 @@
 // launches the kernels of himut_kernels.h on the context's stream and reads the
 // result back.  No torch types, no C++ exceptions across the boundary.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <string.h>  // rocprim's texture iterator needs the host memset declared first
 #include <rocprim/rocprim.hpp>
@@ -128,7 +129,8 @@ struct himut_ctx {
     bool mask_clean = false;                 // d_mask and d_tilecnt hold zeros only (k_mask_emit leaves them so)
     // device-side BAM ingest (himut_ingest_*)
     void* ing_pinned[2] = {nullptr, nullptr};
-    size_t ing_window = 0;
+    size_t ing_window = 0, ing_bound = 0;
+    bool ing_sized = false;
     DevBuf d_stage[2], d_recoff[2], d_qidin[2], d_desc, d_sizes, d_offs, d_istate, d_tp;
     hipEvent_t ing_copied[2] = {}, ing_parsed[2] = {};
     bool ing_open = false, ing_used[2] = {false, false};
@@ -685,6 +687,8 @@ extern "C" {
 
 int himut_abi_version(void) { return HIMUT_ABI_VERSION; }
 
+__global__ void k_warm(int* p) { if (p) *p = 0; }
+
 int himut_create(int device, himut_ctx** out) {
     if (!out) return HIMUT_ERR_ARG;
     *out = nullptr;
@@ -703,6 +707,10 @@ int himut_create(int device, himut_ctx** out) {
         HCHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         for (auto& e : c->ev) HCHECK(hipEventCreate(&e));
         HCHECK(hipHostMalloc(&c->h_scalars, sizeof(Scalars), hipHostMallocDefault));
+        // the library's code object is loaded with the first launch (tens of milliseconds): here, not in the first
+        // contig's ingest or scan
+        hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, c->stream, (int*)nullptr);
+        HCHECK(hipStreamSynchronize(c->stream));
         return HIMUT_OK;
     });
     if (rc) {
@@ -869,6 +877,21 @@ int himut_push_reads(himut_ctx* c, const himut_read_batch* b) {
 }
 
 // ---- device-side BAM ingest: see include/himut_hip.h and csrc/himut_ingest.h
+// First sizes of the contig's arrays from what CCS records look like (two thirds of a record are qualities); the arrays
+// grow if a window needs more.
+static void ingest_size_arrays(himut_ctx* c, hipStream_t st) {
+    const size_t B = c->ing_bound;
+    c->d_bq.reserve(B * 7 / 10 + (1 << 20));
+    c->d_seq.reserve(B * 7 / 20 + (1 << 20));
+    c->d_cs.reserve(B / 16 + (1 << 20));
+    const size_t nr0 = B / 4000 + 4096;
+    c->d_tstart.reserve(nr0 * 4 + 256); c->d_tend.reserve(nr0 * 4 + 256); c->d_qstart.reserve(nr0 * 4 + 256); c->d_qlen.reserve(nr0 * 4 + 256);
+    c->d_qid.reserve(nr0 * 4 + 256); c->d_mapq.reserve(nr0 + 256); c->d_tp.reserve(nr0 + 256); c->d_flag.reserve(nr0 * 2 + 256);
+    c->d_qoff.reserve(nr0 * 8 + 256); c->d_csoff.reserve((nr0 + 1) * 8 + 256);
+    HCHECK(hipMemsetAsync(c->d_csoff.p, 0, 8, st));
+    c->ing_sized = true;
+}
+
 int himut_ingest_begin(himut_ctx* c, int64_t inflated_bound, int64_t window_bytes) {
     if (!c || inflated_bound < 0 || window_bytes < (1 << 16)) return fail(c, HIMUT_ERR_ARG, "bad ingest arguments");
     return guarded(c, [&]() -> int {
@@ -881,6 +904,7 @@ int himut_ingest_begin(himut_ctx* c, int64_t inflated_bound, int64_t window_byte
         static void* g_pinned[2] = {nullptr, nullptr};
         static size_t g_pinned_bytes = 0;
         if (g_pinned_bytes < W + 4096) {
+            const auto t_pin = std::chrono::steady_clock::now();
             for (int k = 0; k < 2; k++) {
                 if (g_pinned[k]) { HCHECK(hipHostFree(g_pinned[k])); g_pinned[k] = nullptr; }
                 // cacheable pages: the inflate reads its own output back (LZ77 matches)
@@ -888,6 +912,9 @@ int himut_ingest_begin(himut_ctx* c, int64_t inflated_bound, int64_t window_byte
                 HCHECK(hipHostMalloc(&g_pinned[k], W + 4096, fl));
             }
             g_pinned_bytes = W + 4096;
+            if (getenv("HIMUT_INGEST_PROFILE"))
+                fprintf(stderr, "ingest: pinned windows 2 x %zu MB in %.1f ms\n", (W + 4096) >> 20,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pin).count());
         }
         for (int k = 0; k < 2; k++) {
             c->ing_pinned[k] = g_pinned[k];
@@ -896,22 +923,15 @@ int himut_ingest_begin(himut_ctx* c, int64_t inflated_bound, int64_t window_byte
         }
         c->ing_window = W;
         for (int k = 0; k < 2; k++) { c->d_stage[k].reserve(W + 4096); c->ing_used[k] = false; }
-        // first sizes from what CCS records look like (two thirds of a record are qualities); the arrays grow if a
-        // window needs more
-        const size_t B = (size_t)inflated_bound;
-        c->d_bq.reserve(B * 7 / 10 + (1 << 20));
-        c->d_seq.reserve(B * 7 / 20 + (1 << 20));
-        c->d_cs.reserve(B / 16 + (1 << 20));
-        const size_t nr = B / 4000 + 4096;
-        c->d_tstart.reserve(nr * 4 + 256); c->d_tend.reserve(nr * 4 + 256); c->d_qstart.reserve(nr * 4 + 256); c->d_qlen.reserve(nr * 4 + 256);
-        c->d_qid.reserve(nr * 4 + 256); c->d_mapq.reserve(nr + 256); c->d_tp.reserve(nr + 256); c->d_flag.reserve(nr * 2 + 256);
-        c->d_qoff.reserve(nr * 8 + 256); c->d_csoff.reserve((nr + 1) * 8 + 256);
+        // the contig's arrays are sized when the first window arrives (himut_ingest_window): by then the host's pool
+        // is inflating the second window, and gigabytes of hipMalloc are off the path
+        c->ing_bound = (size_t)inflated_bound;
+        c->ing_sized = false;
         c->d_istate.reserve(sizeof(IngestState));
         IngestState z;
         memset(&z, 0, sizeof(z));
         z.last_pos = -0x7fffffff - 1;
         HCHECK(hipMemcpy(c->d_istate.p, &z, sizeof(z), hipMemcpyHostToDevice));
-        HCHECK(hipMemset(c->d_csoff.p, 0, 8));
         c->ing_reads = c->ing_bases = c->ing_cs = 0;
         c->ing_open = true;
         c->have_reads = false; c->tables_valid = false; c->win_nblk = 0; c->h_recs_valid = false;
@@ -939,6 +959,13 @@ int himut_ingest_window(himut_ctx* c, int slot, int64_t start, int64_t nbytes, c
     return guarded(c, [&]() -> int {
         HCHECK(hipSetDevice(c->device));
         hipStream_t st = c->stream, cp = c->side;
+        if (!c->ing_sized) {
+            const auto t_sz = std::chrono::steady_clock::now();
+            ingest_size_arrays(c, st);
+            if (getenv("HIMUT_INGEST_PROFILE"))
+                fprintf(stderr, "ingest: contig arrays sized in %.1f ms\n",
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sz).count());
+        }
         // room for this window's reads: exact for the per-read arrays and the bases, an upper bound for the cs text
         const int64_t nr = c->ing_reads + n_rec, nb = c->ing_bases + padded_bases, nc = c->ing_cs + tag_bytes;
         const size_t ur = (size_t)c->ing_reads;
@@ -990,6 +1017,7 @@ int himut_ingest_end(himut_ctx* c, int unique_qnames, himut_ingest_result* out) 
     return guarded(c, [&]() -> int {
         HCHECK(hipSetDevice(c->device));
         hipStream_t st = c->stream;
+        if (!c->ing_sized) { c->ing_bound = 0; ingest_size_arrays(c, st); }       // a contig without records
         HCHECK(hipStreamSynchronize(c->side));
         HCHECK(hipStreamSynchronize(st));
         c->ing_open = false;

@@ -106,3 +106,80 @@ def test_threads_and_small_windows_agree(tmp_path, monkeypatch):
         _same(bamio.BamFile(path, threads=th).batches["chr3"], s.batch)
     monkeypatch.setenv("HIMUT_INGEST_ZLIB", "1")
     _same(bamio.BamFile(path, threads=2).batches["chr3"], s.batch)
+
+
+def _stream_records(path, chrom, window_bytes, threads=3):
+    """Drives bam_stream_pump the way BamStream.ingest_contig does, with plain host buffers in place of the library's
+    pinned ones and Python callbacks in place of himut_ingest_wait / himut_ingest_window; returns (pos, l_seq, flag) of the records it lists and the stream's unique-names verdict."""
+    import ctypes
+    st = bamio.BamStream(path, threads)
+    L, h = st._L, st._h
+    bound = ctypes.c_int64()
+    assert L.bam_stream_select(h, st.names.index(chrom), ctypes.byref(bound)) == 0
+    cap = window_bytes + L.bam_stream_head()
+    bufs = [np.zeros(cap, np.uint8) for _ in (0, 1)]
+    ptr = [b.ctypes.data_as(ctypes.c_void_p) for b in bufs]
+    rec_cap = window_bytes // 64 + 16
+    out, qids, state = [], [], {"total": 0, "waits": 0}
+
+    @ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
+    def wait(_ctx, slot):
+        state["waits"] += 1
+        return 0
+
+    @ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint32),
+                      ctypes.POINTER(ctypes.c_int32), ctypes.c_int64, ctypes.c_int64, ctypes.c_int64)
+    def window(_ctx, slot, start, nbytes, rec_off, qid, n, padded, tag_bytes):
+        w = bufs[slot][start:start + nbytes].tobytes()
+        pad = 0
+        for k in range(n):
+            o = int(rec_off[k])
+            ref_id, pos = struct.unpack_from("<ii", w, o)
+            flag, l_seq = struct.unpack_from("<H", w, o + 14)[0], struct.unpack_from("<I", w, o + 16)[0]
+            if ref_id != st.names.index(chrom):
+                return 77
+            out.append((pos, l_seq, flag))
+            qids.append(int(qid[k]))
+            pad += (l_seq + 31) & ~31
+        state["total"] += nbytes
+        return 0 if pad == padded and tag_bytes > 0 else 78
+
+    rc = L.bam_stream_pump(h, None, ctypes.cast(wait, ctypes.c_void_p), ctypes.cast(window, ctypes.c_void_p), ptr[0], ptr[1],
+                           cap, rec_cap)
+    assert rc == 0, (rc, L.bam_stream_error(h))
+    total = state["total"]
+    assert state["waits"] >= 1
+    assert total <= bound.value + (1 << 16)
+    uniq = bool(L.bam_stream_unique_names(h))
+    inflated = st.inflated_bytes()
+    assert (L.bam_stream_scan_parts(h) > 1) == st.indexed      # the test lowers the size from which the scan is split
+    st.close()
+    return out, qids, uniq, inflated
+
+
+@pytest.mark.parametrize("index", [True, False])
+def test_stream_lists_the_contigs_records(tmp_path, monkeypatch, index):
+    """The host half of the device-side ingest (bam_stream_*): block table (made by several threads from the index's
+    hints, or serially), seek, windows whose inflate runs ahead of the hop, records cut by a window boundary."""
+    cfg = dict(depth=12.0, read_len_mean=2500, read_len_sd=600, read_len_min=800, read_len_max=5000)
+    s1 = synth.generate(synth.SynthConfig(seed=71, contig_len=400_000, name="chr2", **cfg))
+    s2 = synth.generate(synth.SynthConfig(seed=72, contig_len=250_000, name="chr10", **cfg))
+    s2.batch.qid[9] = 4
+    path = str(tmp_path / "s.bam")
+    bamio.write_bam(path, [s1.batch, s2.batch], sample="smp")
+    if not index:
+        monkeypatch.setenv("HIMUT_INGEST_NO_INDEX", "1")
+    monkeypatch.setenv("HIMUT_INGEST_WINDOW_KB", "96")
+    monkeypatch.setenv("HIMUT_INGEST_SCAN_MIN_KB", "64")
+    host = bamio.BamFile(path, threads=2)
+    whole = None
+    for chrom, b in (("chr10", s2.batch), ("chr2", s1.batch)):
+        for window in (96 << 10, 1 << 20):
+            recs, qids, uniq, inflated = _stream_records(path, chrom, window)
+            hb = host.batches[chrom]
+            assert [r[0] for r in recs] == hb.tstart.tolist()
+            assert [r[1] for r in recs] == hb.qlen.tolist() and [r[2] for r in recs] == hb.flag.tolist()
+            assert qids == hb.qid.tolist() and uniq == (chrom == "chr2")
+            whole = inflated if (not index and chrom == "chr2") else whole
+            if index and chrom == "chr10":
+                assert inflated < 0.6 * sum(x.total_read_bases() for x in (s1.batch, s2.batch)) * 1.5
