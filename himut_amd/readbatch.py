@@ -147,6 +147,6 @@ def batch_from_records(name, length, records) -> ReadBatch:
         packed = (nib[0::2] << 4) | nib[1::2]
         seq[qoff[i] // 2: qoff[i] // 2 + packed.shape[0]] = packed
         bq[qoff[i]: qoff[i] + len(s)] = np.asarray(r["bq"], dtype=np.uint8)
-        cs[cs_off[i]: cs_off[i + 1]] = np.frombuffer(r["cs"].encode("ascii"), dtype=np.uint8)
+        cs[cs_off[i]: cs_off[i + 1]] = np.frombuffer(r["cs"].encode("latin-1"), dtype=np.uint8)
     return ReadBatch(name=name, length=length, tstart=tstart, tend=tend, qstart=qstart, qlen=qlen, mapq=mapq,
                      flag=flag, qid=qid, qoff=qoff, cs_off=cs_off, seq=seq, bq=bq, cs=cs, tp=tp, qnames=qnames)
