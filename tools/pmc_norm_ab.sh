@@ -1,0 +1,22 @@
+#!/bin/bash
+# SQ counters of k_norm_tile for several builds of the library.  usage: bash tools/pmc_norm_ab.sh lib_a.so lib_b.so ...
+export TMPDIR=/tmp
+for v in "$@"; do
+  echo "== $v"
+  for c in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
+    tag=$(echo $c | tr ' ' '_')
+    rm -rf gpurun_out/pmcab_$tag
+    HIMUT_HIP_LIB_OVERRIDE=$PWD/$v timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcab_$tag -- python3 tools/bench_normcounts.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcab.log 2>&1 || echo "failed $c"
+  done
+  python3 - <<'PY'
+import csv, glob, collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmcab_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"].split("(")[0].replace("void ","")
+        if "k_norm_tile" in k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,v in acc.items():
+    print(k+" "+" ".join("%s=%.4g"%(c,sum(x)/len(x)) for c,x in sorted(v.items())))
+PY
+  rm -rf gpurun_out/pmcab_*
+done
