@@ -73,7 +73,7 @@ void upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
 template <class T>
 void upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) { upload(b, v.data(), v.size(), st); }
 
-enum { EV_START = 0, EV_SIDE, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COUNT };
+enum { EV_START = 0, EV_SIDE, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV_SWEEP, EV_FINAL, EV_COPIED, EV_COUNT };
 
 }  // namespace
 
@@ -108,6 +108,7 @@ struct himut_ctx {
     int64_t n = 0, cs_bytes = 0, seq_bytes = 0, bq_bytes = 0, read_bases = 0;
     std::vector<int32_t> h_tstart, h_tend, h_prefmax;
     bool unique_qnames = true, any_longcs = false;
+    size_t lead_clean_bytes = 0;      // bytes of the position bitmap (and the scalars) a call run left empty for the next one
     DevBuf d_tstart, d_tend, d_qstart, d_qlen, d_mapq, d_flag, d_qid, d_qoff, d_csoff, d_seq, d_bq, d_cs, d_prefmax;
     // derived
     DevBuf d_bqsum, d_nseg, d_nmis, d_nnsub, d_segs, d_mis, d_mq, d_meta, d_rflag, d_ccs, d_order;
@@ -352,19 +353,23 @@ inline void stage_event(himut_ctx* c, int ev, int level, hipStream_t st) {
 }
 
 template <bool WITH_BQ>
-void launch_parse(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, uint32_t* posbits, int64_t nposwords) {
+void launch_parse(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, uint32_t* posbits, int64_t nposwords,
+                  void* fill = nullptr, int64_t fill_slots = 0) {
+    // fill: the column store, to be left EMPTY (fill_slots 16-bit slots) by the decode's waves on their way
+    const int64_t fill16 = (fill_slots * 2 + 15) / 16;
+    const int fill_per = fill ? (int)((fill16 + c->n * 64 - 1) / (c->n * 64)) : 0;
     hipLaunchKernelGGL(k_parse_cs<WITH_BQ>, dim3(blocks_for(c->n, 4)), dim3(256), 0, c->stream, R, D, c->params, &sc->err,
-                       c->d_ccs.as<uint8_t>(), posbits, nposwords);
+                       c->d_ccs.as<uint8_t>(), posbits, nposwords, (uint4*)fill, fill16, fill_per);
 }
 
 // side_work: work for the second stream, done while the quality stream + cs decode run
 template <bool WITH_BQ, class F>
 void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc, F side_work, uint32_t* posbits = nullptr,
-                     int64_t nposwords = 0) {
+                     int64_t nposwords = 0, void* fill = nullptr, int64_t fill_slots = 0) {
     hipStream_t st = c->stream;
     // the side stream takes the work that needs nothing from the decode (it starts behind EV_START: the
     // previous run on this context is over by then)
-    launch_parse<WITH_BQ>(c, R, D, sc, posbits, nposwords);
+    launch_parse<WITH_BQ>(c, R, D, sc, posbits, nposwords, fill, fill_slots);
     HCHECK(hipStreamWaitEvent(c->side, c->ev[EV_START], 0));
     side_work(c->side);
     HCHECK(hipEventRecord(c->ev[EV_SIDE], c->side));
@@ -447,22 +452,27 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     for (int32_t e : c->cend) maxpos = std::max(maxpos, e);
     const int64_t nblk = ((int64_t)maxpos >> WIN_SHIFT) + 2;
     const int64_t nwords = nblk * 8;
-    size_t scan_tiles = 0, scan3 = 0;
+    size_t scan_tiles = 0;
     BlockCount BC;
-    auto blk_in = [&]() { return rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), BC); };
+    // the column index: a thread per `idx_per` consecutive blocks, at most 1024 workgroups (k_block_sums / k_block_table3)
+    const int idx_per = (int)std::max<int64_t>(1, (nblk + 256 * 1024 - 1) / (256 * 1024));
+    const unsigned idx_wgs = blocks_for(nblk, 256 * idx_per);
     {   // buffers and scan scratch whose sizes the host knows now: sized before anything is queued (growing a
         // buffer in the middle of a run would free it under the kernels already queued on it)
         c->d_winlo.reserve((size_t)nblk * 4 + 64);
         c->d_winhi.reserve((size_t)nblk * 4 + 64);
+        const void* bits_was = c->d_posbits_c.p;
         c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
-        c->d_posrank.reserve((size_t)nblk * sizeof(uint2) + 256);          // the scan's output: (first rank, slot offset) per block
+        if (bits_was != c->d_posbits_c.p) c->lead_clean_bytes = 0;
+        c->d_posrank.reserve((size_t)idx_wgs * sizeof(uint4) + 256);      // per-workgroup totals of the column index
         c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
         c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
         BC.bits = c->d_posbits_c.as<uint32_t>(); BC.winlo = c->d_winlo.as<int32_t>(); BC.winhi = c->d_winhi.as<int32_t>();
-        uint32_t* nul = nullptr;
-        HCHECK(rocprim::exclusive_scan(nullptr, scan_tiles, nul, nul, 0u, (size_t)std::max<unsigned>(mtiles, 1u), rocprim::plus<uint32_t>(), st));
-        HCHECK(rocprim::exclusive_scan(nullptr, scan3, blk_in(), c->d_posrank.as<uint2>(), make_uint2(0u, 0u), (size_t)nblk, PlusU2(), st));
-        c->d_tmp2.reserve(std::max(scan_tiles, scan3) + 256);
+        if (mtiles > 65536u) {                                             // (else one workgroup scans the tile counts: k_scan_small)
+            uint32_t* nul = nullptr;
+            HCHECK(rocprim::exclusive_scan(nullptr, scan_tiles, nul, nul, 0u, (size_t)mtiles, rocprim::plus<uint32_t>(), st));
+        }
+        c->d_tmp2.reserve(scan_tiles + 256);
     }
 
     Reads R = make_reads(c);
@@ -473,14 +483,24 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     Scalars& hs = *reinterpret_cast<Scalars*>(c->h_scalars);
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
-    HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
-    // the cs decode sets the bits of the column positions: the bitmap is empty before it starts
-    HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
+    // The cs decode sets the bits of the column positions and every kernel adds to the scalars: both are empty before
+    // the run starts.  A run leaves them so (it clears them behind its last copy, while the host is already reading
+    // the results): only a context that has not just been through a run of this kind pays for the fills here.
+    const size_t lead_bytes = (size_t)(nwords + 2) * 4;
+    if (c->lead_clean_bytes < lead_bytes) {
+        HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+        HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, lead_bytes, st));
+    }
+    c->lead_clean_bytes = 0;
     // The read windows per 256 positions depend on the pushed reads only (like a BAM index they are made once per
     // batch: the first run after himut_push_reads).  That kernel and the fills of a mask that is not known to be
     // empty need nothing from the cs decode: they run beside it on the second stream.  A context that has been
     // through a run has neither to do, and the second stream stays idle.
     const bool need_win = c->n > 0 && c->win_nblk != nblk;
+    // (on kept capacities the column store's size is known before the decode has run: the decode's waves fill it)
+    const bool fill_early = spec;
+    if (fill_early) c->d_colstore.reserve((size_t)c->cap_slots * 2 + 256);
+    void* fill_p = fill_early ? c->d_colstore.p : nullptr;
     auto side_work = [&](hipStream_t side) {
         if (clear_all) {
             HCHECK(hipMemsetAsync(c->d_mask.p, 0, c->d_mask.cap, side));
@@ -492,9 +512,9 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     };
     if (c->n > 0) {
         if (clear_all || need_win)
-            run_parse_stage<false>(c, R, D, sc, side_work, c->d_posbits_c.as<uint32_t>(), nwords);
+            run_parse_stage<false>(c, R, D, sc, side_work, c->d_posbits_c.as<uint32_t>(), nwords, fill_p, c->cap_slots);
         else {
-            launch_parse<false>(c, R, D, sc, c->d_posbits_c.as<uint32_t>(), nwords);
+            launch_parse<false>(c, R, D, sc, c->d_posbits_c.as<uint32_t>(), nwords, fill_p, c->cap_slots);
             if (c->any_longcs)
                 hipLaunchKernelGGL(k_check_longcs, dim3(blocks_for(c->n, 256)), dim3(256), 0, st, R, D, &sc->err);
             stage_event(c, EV_PARSE, 2, st);
@@ -514,9 +534,8 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = nullptr; X.nwords = nwords;
     X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
     if (c->n > 0) {
-        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, blk_in(), c->d_posrank.as<uint2>(), make_uint2(0u, 0u), (size_t)nblk,
-                                       PlusU2(), st));
-        hipLaunchKernelGGL(k_block_table2, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, BC, c->d_posrank.as<uint2>(), nblk,
+        hipLaunchKernelGGL(k_block_sums, dim3(idx_wgs), dim3(256), 0, st, BC, nblk, idx_per, c->d_posrank.as<uint4>());
+        hipLaunchKernelGGL(k_block_table3, dim3(idx_wgs), dim3(256), 0, st, BC, nblk, idx_per, c->d_posrank.as<uint4>(),
                            c->d_blktab.as<BlockTab>(), c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), &sc->err);
         size_t slot_reserve = (size_t)c->cap_slots;
         slot_cap = (size_t)c->cap_slots;
@@ -530,8 +549,10 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
             slot_cap = (size_t)last_off + last_n;
             slot_reserve = slot_cap + slot_cap / 4 + 4096;
         }
-        c->d_colstore.reserve(slot_reserve * 2 + 256);
-        if (slot_cap) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, slot_cap, st));
+        if (!fill_early) {
+            c->d_colstore.reserve(slot_reserve * 2 + 256);
+            if (slot_cap) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, slot_cap, st));
+        }
         CaptureArgs G;
         G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)slot_cap;
         G.r_begin = 0; G.r_end = c->n; G.callable = nullptr; G.bqsum = c->d_bqsum.as<uint32_t>(); G.err = &sc->err;
@@ -548,8 +569,11 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     // the candidates = the set bits of the mask; k_propose counted them per tile: the scan places the tiles
     uint32_t last_tcnt = 0, last_toff = 0;
     if (anyw > 0) {
-        HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
-                                       (size_t)mtiles, rocprim::plus<uint32_t>(), st));
+        if (mtiles <= 65536u)
+            hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), (int)mtiles);
+        else
+            HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan_tiles, c->d_tilecnt.as<uint32_t>(), c->d_tileoff2.as<uint32_t>(), 0u,
+                                           (size_t)mtiles, rocprim::plus<uint32_t>(), st));
         if (!spec) {
             HCHECK(hipMemcpyAsync(&last_tcnt, c->d_tilecnt.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
             HCHECK(hipMemcpyAsync(&last_toff, c->d_tileoff2.as<uint32_t>() + (mtiles - 1), 4, hipMemcpyDeviceToHost, st));
@@ -569,24 +593,21 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     c->d_recs_out.reserve((size_t)(nreserve + 1) * sizeof(himut_record));
     const unsigned long long* ncand_dev = &sc->ncand;
 
-    size_t sort_tmp = 0, scan_tmp = 0;
+    size_t sort_tmp = 0;
     if (ncap > 0) {
         // candidates in the order of the final records (tpos, chunk, ref, alt)
         c->d_keys.reserve((size_t)nreserve * 8); c->d_keys2.reserve((size_t)nreserve * 8);
         c->d_cands.reserve((size_t)nreserve * sizeof(Cand) + 256);
         c->d_cands2.reserve((size_t)nreserve * sizeof(Cand) + 256);
-        c->d_emit.reserve((size_t)nreserve * 4); c->d_pos.reserve((size_t)nreserve * 4);
-        HCHECK(rocprim::exclusive_scan(nullptr, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
-                                       (size_t)ncap, rocprim::plus<uint32_t>(), st));
+        c->d_emit.reserve((size_t)nreserve * 4);
         if (c->chunks_in_order) {
-            c->d_tmp.reserve(scan_tmp + 256);
             hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(), (int64_t)T.positions,
                                c->d_mask.as<uint16_t>(), c->d_tileoff2.as<uint32_t>(), C, c->d_cands2.as<Cand>(),
                                c->d_keys2.as<uint64_t>(), ncap, &sc->ncand, c->d_tilecnt.as<uint32_t>());
         } else {
             HCHECK(rocprim::radix_sort_pairs(nullptr, sort_tmp, c->d_keys.as<uint64_t>(), c->d_keys2.as<uint64_t>(),
                                              c->d_cands.as<uint64_t>(), c->d_cands2.as<uint64_t>(), (size_t)ncap, 0, 60, st));
-            c->d_tmp.reserve(std::max(sort_tmp, scan_tmp) + 256);
+            c->d_tmp.reserve(sort_tmp + 256);
             hipLaunchKernelGGL(k_mask_emit, dim3(mtiles), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(), (int64_t)T.positions,
                                c->d_mask.as<uint16_t>(), c->d_tileoff2.as<uint32_t>(), C, c->d_cands.as<Cand>(),
                                c->d_keys.as<uint64_t>(), ncap, &sc->ncand, c->d_tilecnt.as<uint32_t>());
@@ -614,27 +635,28 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     // ---- finalisation: order, cross-chunk som_seen, counters, compaction (every set mask bit is one evaluation)
     if (ncap > 0) {
         const unsigned nb = blocks_for(ncap, 256);
-        hipLaunchKernelGGL(k_resolve_seen, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
-                           c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, ncand_dev, ncap);
         c->d_logpart.reserve((size_t)nb * 16 * 4 + 64);
+        c->d_pos.reserve((size_t)nb * 4 + 64);          // where each workgroup's emitted records begin
         hipLaunchKernelGGL(k_finalize_flags, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(),
                            c->d_keys2.as<uint64_t>(), (const uint32_t*)nullptr, ncand_dev, ncap, c->d_emit.as<uint32_t>(),
                            c->d_logpart.as<uint32_t>(), c->d_ccs.as<uint8_t>(), c->n);
-        HCHECK(rocprim::exclusive_scan(c->d_tmp.p, scan_tmp, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), 0u,
-                                       (size_t)ncap, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(k_run_totals, dim3(1), dim3(1024), 0, st, ncap, c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), nblk,
+                           &sc->nrec, &sc->reserved0, c->d_logpart.as<uint32_t>(), (int64_t)nb, sc->log, c->d_pos.as<uint32_t>());
         hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, st, c->d_recs.as<himut_record>(), (const uint32_t*)nullptr,
                            c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), ncand_dev, ncap, c->d_recs_out.as<himut_record>());
-        hipLaunchKernelGGL(k_run_totals, dim3(1), dim3(1024), 0, st, c->d_emit.as<uint32_t>(), c->d_pos.as<uint32_t>(), ncap,
-                           c->d_blkoff.as<uint32_t>(), c->d_blkslots.as<uint32_t>(), nblk, &sc->nrec, &sc->reserved0,
-                           c->d_logpart.as<uint32_t>(), (int64_t)nb, sc->log);
     }
     if (c->n > 0 && ncap <= 0)   // no mask sweep ran: count the flagged reads here
         hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, st, c->d_ccs.as<uint8_t>(), c->n, &sc->nccs);
     HCHECK(hipEventRecord(c->ev[EV_FINAL], st));
 
     HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
-    HCHECK(hipStreamSynchronize(st));
+    HCHECK(hipEventRecord(c->ev[EV_COPIED], st));
+    // behind the copy: the scalars and the bitmap empty for the next run (the host does not wait for these)
+    HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+    HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, lead_bytes, st));
+    HCHECK(hipEventSynchronize(c->ev[EV_COPIED]));
     if (hs.err) return check_device_err(c, hs.err);
+    c->lead_clean_bytes = lead_bytes;
     const int64_t ncand = ncap > 0 ? (int64_t)hs.ncand : 0;
     const int64_t nslots = ncap > 0 ? (int64_t)hs.reserved0 : (int64_t)slot_cap;
     if (ncand > ncap || nslots > (int64_t)slot_cap) {   // only a run on kept capacities can get here
@@ -1167,6 +1189,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
     Phase H = make_phase(c);
     Scalars* sc = c->d_scalars.as<Scalars>();
+    c->lead_clean_bytes = 0;           // (the call path's scalars and bitmap are used here)
     const int K = c->ref_K;
     const size_t ntri = (size_t)K * K * K;
     c->d_tri.reserve((2 * ntri + 16) * 8);
@@ -1344,6 +1367,7 @@ int himut_run_edges(himut_ctx* c, const int32_t* hpos, const uint8_t* href, int6
         Reads R = make_reads(c);
         Derived D = make_derived(c);
         Scalars* sc = c->d_scalars.as<Scalars>();
+    c->lead_clean_bytes = 0;           // (the call path's scalars and bitmap are used here)
         const size_t nc = (size_t)std::max<int64_t>(n_het, 1) * (size_t)band * 4;
         c->d_tmp.reserve(nc * 4 + 256);
         upload(c->d_hpos, hpos, (size_t)n_het, st);
@@ -1447,6 +1471,7 @@ int himut_pile_counts(himut_ctx* c, int32_t p0, int32_t p1, uint32_t* counts, ui
         Derived D = make_derived(c);
         Chunks C = make_chunks(c, 1);
         Scalars* sc = c->d_scalars.as<Scalars>();
+    c->lead_clean_bytes = 0;           // (the call path's scalars and bitmap are used here)
         HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
         if (c->n > 0) run_parse_stage(c, R, D, sc);
         c->d_dense_counts.reserve((size_t)T.positions * 6 * 4 + 64);

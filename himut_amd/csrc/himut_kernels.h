@@ -379,7 +379,7 @@ constexpr int MARK_CAP = 128;
 template <bool WITH_BQ>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(HIMUT_PARSE_SGPR)))
 k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbits,
-                                                  int64_t nposwords) {
+                                                  int64_t nposwords, uint4* fill, int64_t fill16, int fill_per) {
     __shared__ __align__(16) uint8_t s_txt[4][32 + PB + 32];   // 32 bytes of the previous step, then this step
     __shared__ uint16_t s_start[4][PB + 8];                      // operation starts, relative to the step (an operation carried
                                                                  // over from an earlier step keeps its start in a register)
@@ -387,6 +387,14 @@ k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbi
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
+    // The column store must be EMPTY before the capture writes into it (fill: its fill16 16-byte pieces, or null).  The
+    // decode is bound by latency and leaves the memory system idle: every wave stores its share, fill_per pieces per lane,
+    // and neither a fill between the decode and the capture nor a second stream is needed.
+    if (fill) {
+        const uint4 e = make_uint4(0x00070007u, 0x00070007u, 0x00070007u, 0x00070007u);   // CELL_EMPTY
+        const int64_t f0 = r * 64 * fill_per;
+        for (int k = 0; k < fill_per; k++) { const int64_t o = f0 + 64 * k + lane; if (o < fill16) fill[o] = e; }
+    }
     if (lane == 0) ccs[r] = 0;               // the flag k_propose raises for a read that may propose (num_ccs)
     const int64_t cs0 = uni(R.cs_off[r]);
     const int64_t sb = (cs0 >> 1) + r;
@@ -1087,6 +1095,123 @@ __global__ void __launch_bounds__(256) k_block_table2(BlockCount F, const uint2*
     if (nr > BT_N_MASK || s > 0xffffffffULL || (unsigned long long)o.y + s > 0xffffffffULL) set_err(err, HIMUT_ERR_DEPTH);
 }
 
+// ---- the same index without a library scan.  rocPRIM's scan is two launches (state initialisation, look-back scan)
+// of ~14 us for a quarter of a million elements, most of it launch and drain; here the prefix sums are two plain
+// kernels: per-workgroup totals, then every workgroup adds up the (at most 1024) totals in front of it and scans its
+// own blocks.  A thread takes `per` consecutive blocks (1 unless the contig has more than 2^18 blocks).
+__device__ __forceinline__ void block_counts(const BlockCount& F, int64_t b, uint32_t& cnt, uint32_t& nr, unsigned long long& slots) {
+    const uint4* wp = reinterpret_cast<const uint4*>(F.bits + (b << 3));
+    const uint4 x = wp[0], y = wp[1];
+    cnt = (uint32_t)(__popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w));
+    nr = (uint32_t)(F.winhi[b] - F.winlo[b]);
+    slots = ((unsigned long long)cnt * (unsigned long long)nr + 15ULL) & ~15ULL;   // every block starts on a 32-byte boundary of the column store
+}
+// sums of (a, b) over the workgroup (256 threads), the same value in every thread
+__device__ __forceinline__ void wg_sum2(uint32_t& a, unsigned long long& b, uint32_t* s_a, unsigned long long* s_b) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_a[wv] = a; s_b[wv] = b; }
+    __syncthreads();
+    a = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+    b = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+}
+__global__ void __launch_bounds__(256) k_block_sums(BlockCount F, int64_t nblk, int per, uint4* part) {
+    __shared__ uint32_t s_a[4];
+    __shared__ unsigned long long s_b[4];
+    const int64_t b0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * per;
+    uint32_t c = 0;
+    unsigned long long s = 0;
+    for (int k = 0; k < per; k++)
+        if (b0 + k < nblk) { uint32_t cnt, nr; unsigned long long sl; block_counts(F, b0 + k, cnt, nr, sl); c += cnt; s += sl; }
+    wg_sum2(c, s, s_a, s_b);
+    if (threadIdx.x == 0) part[blockIdx.x] = make_uint4(c, 0u, (uint32_t)s, (uint32_t)(s >> 32));
+}
+// BlockTab (first rank, slot offset) of every block; also leaves the slot offsets / counts as plain arrays (the run's
+// totals).  err: HIMUT_ERR_DEPTH when the column store of the contig needs more than 2^32 slots or a window holds more
+// than 2^22 reads.
+__global__ void __launch_bounds__(256) k_block_table3(BlockCount F, int64_t nblk, int per, const uint4* part, BlockTab* bt,
+                                                      uint32_t* blkoff, uint32_t* blkslots, int* err) {
+    __shared__ uint32_t s_a[4];
+    __shared__ unsigned long long s_b[4];
+    // what the workgroups in front of this one hold
+    uint32_t pc = 0;
+    unsigned long long ps = 0;
+    for (int w = threadIdx.x; w < (int)blockIdx.x; w += 256) {
+        const uint4 v = part[w];
+        pc += v.x; ps += (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+    }
+    wg_sum2(pc, ps, s_a, s_b);
+    // this thread's blocks, then the threads in front of it
+    const int64_t b0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * per;
+    uint32_t tc = 0;
+    unsigned long long ts = 0;
+    for (int k = 0; k < per; k++)
+        if (b0 + k < nblk) { uint32_t cnt, nr; unsigned long long sl; block_counts(F, b0 + k, cnt, nr, sl); tc += cnt; ts += sl; }
+    uint32_t ic = tc;
+    unsigned long long is = ts;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t uc = __shfl_up(ic, d, 64);
+        const unsigned long long us = __shfl_up(is, d, 64);
+        if (lane >= d) { ic += uc; is += us; }
+    }
+    __syncthreads();
+    if (lane == 63) { s_a[wv] = ic; s_b[wv] = is; }
+    __syncthreads();
+    uint32_t rc = pc + ic - tc;
+    unsigned long long rs = ps + is - ts;
+    for (int w = 0; w < wv; w++) { rc += s_a[w]; rs += s_b[w]; }
+    bool deep = false;
+    for (int k = 0; k < per; k++) {
+        const int64_t b = b0 + k;
+        if (b >= nblk) break;
+        uint32_t cnt, nr;
+        unsigned long long sl;
+        block_counts(F, b, cnt, nr, sl);
+        BlockTab t;
+        t.lo = F.winlo[b]; t.ncnt = nr | (cnt << 22); t.boff = (uint32_t)rs; t.ufirst = rc;
+        bt[b] = t;
+        blkoff[b] = (uint32_t)rs; blkslots[b] = (uint32_t)sl;
+        if (nr > BT_N_MASK || rs + sl > 0xffffffffULL) deep = true;
+        rc += cnt; rs += sl;
+    }
+    if (deep) set_err(err, HIMUT_ERR_DEPTH);
+}
+
+// exclusive prefix sums of a few thousand counts by one workgroup of 1024 threads (the candidate counts of the mask
+// tiles), 16 k at a time through LDS: coalesced loads, eight or sixteen consecutive counts per thread, coalesced stores
+constexpr int SCAN_SMALL_CHUNK = 16384;
+__global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* in, uint32_t* out, int n) {
+    __shared__ uint32_t s_v[SCAN_SMALL_CHUNK];
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    for (int c0 = 0; c0 < n; c0 += SCAN_SMALL_CHUNK) {
+        const int m = min(SCAN_SMALL_CHUNK, n - c0);
+        for (int i = threadIdx.x; i < m; i += 1024) s_v[i] = in[c0 + i];
+        __syncthreads();
+        const int per = (m + 1023) / 1024, i0 = (int)threadIdx.x * per;
+        uint32_t t = 0;
+        for (int k = 0; k < per; k++) if (i0 + k < m) t += s_v[i0 + k];
+        uint32_t inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t run = s_carry + inc - t;
+        for (int w = 0; w < wv; w++) run += s_w[w];
+        for (int k = 0; k < per; k++) if (i0 + k < m) { const uint32_t v = s_v[i0 + k]; s_v[i0 + k] = run; run += v; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += 1024) out[c0 + i] = s_v[i];
+        if (threadIdx.x == 1023) s_carry = run;          // (the last thread's running sum is the chunk's total + carry)
+        __syncthreads();
+    }
+}
+
 // The kernels behind the candidate count take it from device memory (*n_dev, clamped to the capacity the
 // grid was sized for): the host need not have seen it yet.
 __device__ __forceinline__ int64_t dev_count(const unsigned long long* n_dev, int64_t cap) {
@@ -1180,7 +1305,7 @@ constexpr int CPD = 2;      // windows in flight (register sets, at most 4); the
 #define HIMUT_CAP_WAVES 7
 #endif
 template <bool NORM>
-__global__ void __launch_bounds__(256, NORM ? 1 : HIMUT_CAP_WAVES) k_stream_capture(CaptureArgs A) {
+__device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     __shared__ __align__(16) uint8_t s_bq[4][CWQ];
     __shared__ __align__(16) uint8_t s_sq[4][CWQ / 2];
     __shared__ __align__(16) int4 s_seg[4][CSG + 1];
@@ -1579,6 +1704,9 @@ __global__ void __launch_bounds__(256, NORM ? 1 : HIMUT_CAP_WAVES) k_stream_capt
 #undef CAP_LANDED4
 #undef CAP_LANDED2
 }
+
+template <bool NORM>
+__global__ void __launch_bounds__(256, NORM ? 1 : HIMUT_CAP_WAVES) k_stream_capture(CaptureArgs A) { capture_wave<NORM>(A); }
 
 // ---------------------------------------------------------------------------------------
 // k_eval_columns: one THREAD per candidate column: walks the column's slots in fetch
@@ -2083,37 +2211,39 @@ __global__ void __launch_bounds__(NT) k_pile_dense(DenseArgs A) {
 // ---------------------------------------------------------------------------------------
 // finalisation
 
-// som_seen across chunks (caller.py:244,347; bamlib.py:77): a candidate whose
-// tpos was already added by an EARLIER chunk is never proposed again.
-__global__ void __launch_bounds__(256) k_resolve_seen(himut_record* recs, const uint64_t* keys, const uint32_t* vals,
-                                                      const unsigned long long* n_dev, int64_t cap) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = dev_count(n_dev, cap);
-    if (i >= n) return;
+// som_seen across chunks (caller.py:244,347; bamlib.py:77): a candidate whose tpos was already added by an EARLIER
+// chunk is never proposed again.  Whether record i is suppressed: the records of one tpos are neighbours, ordered by
+// chunk; a chunk's records are suppressed when a chunk in front of it kept a non-germline candidate there.  Nearly
+// every record is alone at its tpos (two key loads); the others replay their group from its head.
+__device__ __forceinline__ bool seen_in_earlier_chunk(const himut_record* recs, const uint64_t* keys, const uint32_t* vals, int64_t i,
+                                                      int64_t n) {
     const uint64_t tp = keys[i] >> 28;
-    if (i > 0 && (keys[i - 1] >> 28) == tp) return;  // not a group head
-    if (i + 1 >= n || (keys[i + 1] >> 28) != tp) return;  // single record: nothing to resolve
-    bool seen = false;
+    const bool first = i == 0 || (keys[i - 1] >> 28) != tp;
+    if (first) return false;                       // the group's first chunk (or a record alone) has nothing in front
+    const uint64_t mych = (keys[i] >> 4) & 0xffffff;
     int64_t j = i;
+    while (j > 0 && (keys[j - 1] >> 28) == tp) j--;
+    bool seen = false;
     while (j < n && (keys[j] >> 28) == tp) {
         const uint64_t ch = (keys[j] >> 4) & 0xffffff;
+        if (ch == mych) break;
         bool nongerm = false;
         int64_t k = j;
         while (k < n && (keys[k] >> 28) == tp && ((keys[k] >> 4) & 0xffffff) == ch) {
-            himut_record& rec = recs[vals ? vals[k] : (uint32_t)k];
-            if (seen) rec.flags |= REC_SUPPRESSED;
-            else if (!(rec.flags & REC_GERM)) nongerm = true;
+            if (!(recs[vals ? vals[k] : (uint32_t)k].flags & REC_GERM)) nongerm = true;
             k++;
         }
-        if (!seen && nongerm) seen = true;
+        if (nongerm) seen = true;
         j = k;
     }
+    return seen;
 }
 
 // counters (caller.py:625-641) + output flags in sorted order
 // emit[] is written for the whole capacity (zeros past the count), so that its scan can run over the capacity.
 // Counters: one ballot per counter and wave, one shared-memory add per wave, one global add per block.
-// Counter 0 (num_ccs, caller.py:318-320) = the reads k_propose flagged: ccs[0 .. nreads).
+// Counter 0 (num_ccs, caller.py:318-320) = the reads the proposals flagged: ccs[0 .. nreads).  Slot 15 of a
+// workgroup's partial counters: how many of its records are emitted (k_run_totals turns those into offsets).
 __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, const uint64_t* keys, const uint32_t* vals,
                                                         const unsigned long long* n_dev, int64_t cap, uint32_t* emit,
                                                         uint32_t* logpart, const uint8_t* ccs, int64_t nreads) {
@@ -2131,11 +2261,12 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
     const int64_t n = dev_count(n_dev, cap);
     if (i >= n && i < cap) emit[i] = 0;
     int slot = -1, slot2 = -1;     // the counters this record adds to (besides num_sbs, slot 1)
-    bool counted = false;
+    bool counted = false, emitted = false;
     if (i < n) {
         himut_record& rec = recs[vals ? vals[i] : (uint32_t)i];
         uint32_t e = 0;
-        if (!(rec.flags & REC_SUPPRESSED)) {
+        const bool suppressed = seen_in_earlier_chunk(recs, keys, vals, i, n);
+        if (!suppressed) {
             counted = true;  // num_sbs
             if (rec.flags & REC_GERM) {
                 if (rec.gt_state == 1) slot = 2;
@@ -2161,17 +2292,21 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
                     const uint64_t m = ~(uint64_t)3;
                     if ((keys[i - 1] & m) == (keys[i] & m)) {
                         const himut_record& prev = recs[vals ? vals[i - 1] : (uint32_t)(i - 1)];
-                        if (prev.status == HIMUT_ST_HETALT && !(prev.flags & (REC_SUPPRESSED | REC_GERM))) { e = 0; rec.flags |= REC_DUP; }
+                        // (the neighbour is of this record's tpos and chunk: suppressed or not like this one, i.e. not)
+                        if (prev.status == HIMUT_ST_HETALT && !(prev.flags & REC_GERM)) { e = 0; rec.flags |= REC_DUP; }
                     }
                 }
             }
         }
         emit[i] = e;
+        emitted = e != 0;
     }
     const int lane = threadIdx.x & 63;
     {
         const unsigned long long b = __ballot(counted);
         if (lane == 0 && b) atomicAdd(&s_log[1], (unsigned int)__popcll(b));
+        const unsigned long long be = __ballot(emitted);
+        if (lane == 0 && be) atomicAdd(&s_log[15], (unsigned int)__popcll(be));
     }
     if (__ballot(slot >= 0 || slot2 >= 0)) {
 #pragma unroll
@@ -2181,20 +2316,30 @@ __global__ void __launch_bounds__(256) k_finalize_flags(himut_record* recs, cons
         }
     }
     __syncthreads();
-    // per-block partial counters: k_run_totals adds them up (one global atomic per block and counter would be
-    // ~10^4 atomics on two cache lines, which cost more than the rest of this kernel)
+    // per-workgroup partial counters (one global atomic per workgroup and counter would be ~10^4 atomics on two cache
+    // lines, which cost more than the rest of this kernel): the last workgroup adds them up
     if (threadIdx.x < 16) logpart[(int64_t)blockIdx.x * 16 + threadIdx.x] = s_log[threadIdx.x];
 }
 
+// The emitted records, in order, to the front of `out`: where a workgroup's records begin comes from k_run_totals
+// (wgoff), the place inside the workgroup from a ballot per wave.
 __global__ void __launch_bounds__(256) k_compact(const himut_record* recs, const uint32_t* vals, const uint32_t* emit,
-                                                 const uint32_t* pos, const unsigned long long* n_dev, int64_t cap, himut_record* out) {
+                                                 const uint32_t* wgoff, const unsigned long long* n_dev, int64_t cap, himut_record* out) {
+    __shared__ uint32_t s_w[4];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= dev_count(n_dev, cap) || !emit[i]) return;
+    const bool e = i < dev_count(n_dev, cap) && emit[i] != 0;
+    const unsigned long long b = __ballot(e);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) s_w[wv] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (!e) return;
+    uint32_t pos = wgoff[blockIdx.x] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wv; w++) pos += s_w[w];
     const uint4* src = reinterpret_cast<const uint4*>(recs + (vals ? vals[i] : (uint32_t)i));
-    uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-    b.y &= 0xff00ffffu;  // flags byte (offset 22) -> 0
-    uint4* dst = reinterpret_cast<uint4*>(out + pos[i]);
-    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+    uint4 a = src[0], bb = src[1], c = src[2], d = src[3];
+    bb.y &= 0xff00ffffu;  // flags byte (offset 22) -> 0
+    uint4* dst = reinterpret_cast<uint4*>(out + pos);
+    dst[0] = a; dst[1] = bb; dst[2] = c; dst[3] = d;
 }
 
 __global__ void __launch_bounds__(256) k_count_flags(const uint8_t* flags, int64_t n, unsigned long long* out) {
@@ -2205,13 +2350,14 @@ __global__ void __launch_bounds__(256) k_count_flags(const uint8_t* flags, int64
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, (unsigned long long)local);
 }
 
-// the totals the host reads once at the end of a run: records out (the scan of emit[] over the capacity),
-// column slots (the scan of the block slot counts), the 15 counters (sums of k_finalize_flags' per-block partials)
-__global__ void __launch_bounds__(1024) k_run_totals(const uint32_t* emit, const uint32_t* pos, int64_t cap, const uint32_t* blkoff,
-                                                     const uint32_t* blkslots, int64_t nblk, unsigned long long* nrec,
-                                                     unsigned long long* nslots, const uint32_t* logpart, int64_t nparts,
-                                                     unsigned long long* log) {
+// the totals the host reads once at the end of a run: the 15 counters (sums of k_finalize_flags' per-workgroup
+// partials), records out and where each workgroup's emitted records begin (the prefix sums of slot 15 of the
+// partials), column slots (the end of the last block)
+__global__ void __launch_bounds__(1024) k_run_totals(int64_t cap, const uint32_t* blkoff, const uint32_t* blkslots, int64_t nblk,
+                                                     unsigned long long* nrec, unsigned long long* nslots, const uint32_t* logpart,
+                                                     int64_t nparts, unsigned long long* log, uint32_t* wgoff) {
     __shared__ unsigned long long s_log[16];
+    __shared__ uint32_t s_w[16];
     if (threadIdx.x < 16) s_log[threadIdx.x] = 0;
     __syncthreads();
     // thread = (row phase, quarter of the 16 counters): 256 rows of partials per pass, 16-byte loads, a few passes
@@ -2231,10 +2377,23 @@ __global__ void __launch_bounds__(1024) k_run_totals(const uint32_t* emit, const
         atomicAdd(&s_log[q * 4 + 0], a0); atomicAdd(&s_log[q * 4 + 1], a1);
         atomicAdd(&s_log[q * 4 + 2], a2); atomicAdd(&s_log[q * 4 + 3], a3);
     }
+    // exclusive prefix sums of the workgroups' emitted-record counts
+    const int per = (int)((nparts + 1023) / 1024);
+    const int64_t p0 = (int64_t)threadIdx.x * per;
+    uint32_t t = 0;
+    for (int k = 0; k < per; k++) if (p0 + k < nparts) t += logpart[(p0 + k) * 16 + 15];
+    uint32_t inc = t;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+    if (lane == 63) s_w[wv] = inc;
     __syncthreads();
+    uint32_t run = inc - t;
+    for (int w = 0; w < wv; w++) run += s_w[w];
+    for (int k = 0; k < per; k++) if (p0 + k < nparts) { wgoff[p0 + k] = run; run += logpart[(p0 + k) * 16 + 15]; }
     if (threadIdx.x < 15) log[threadIdx.x] = s_log[threadIdx.x];
     if (threadIdx.x == 0) {
-        *nrec = cap > 0 ? (unsigned long long)pos[cap - 1] + emit[cap - 1] : 0ull;
+        *nrec = cap > 0 ? s_log[15] : 0ull;
         *nslots = nblk > 0 ? (unsigned long long)blkoff[nblk - 1] + blkslots[nblk - 1] : 0ull;
     }
 }
