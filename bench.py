@@ -32,14 +32,15 @@ def algorithmic_bytes(stage, st, cs_bytes):
     if stage == "ms_capture":    # every quality byte + every packed base once, one 2-byte slot per pile cell kept; the read's
         # proposals ride on the same wave: its mismatch list in, a mask word per candidate
         return rb * 1.5 + slots * 2.0 + cs_bytes / 4.0 * 8.0 + cand * 8.0
-    if stage == "ms_parse":      # cs text in, ~16 B per cs operation out (segments + mismatch list), one bitmap word per mark
-        return cs_bytes * 1.0 + cs_bytes / 4.0 * 16.0
+    if stage == "ms_parse":      # cs text in, ~16 B per cs operation out (segments + mismatch list), one bitmap word per mark;
+        # the decode's waves also leave the column store empty for the capture (2 B per slot)
+        return cs_bytes * 1.0 + cs_bytes / 4.0 * 16.0 + slots * 2.0
     if stage == "ms_emit":       # the sweep reads the position bitmap and the marked mask cells, writes candidate + key
         return pos / 8.0 + cand * (2.0 + 16.0)
     if stage == "ms_eval":       # column slots in, one 64-byte record out
         return slots * 2.0 + cand * 64.0
-    if stage == "ms_index":      # position bitmap in, block table + empty column store out
-        return pos / 8.0 + pos / 256.0 * 16.0 + slots * 2.0
+    if stage == "ms_index":      # position bitmap in (twice: totals, then the table), block table out
+        return 2.0 * pos / 8.0 + pos / 256.0 * 24.0
     if stage == "ms_finalize":   # records in and out, keys in
         return cand * (64.0 * 2 + 8.0)
     return 0.0

@@ -1755,8 +1755,11 @@ struct EvalArgs {
     int* err;
 };
 
+#ifndef HIMUT_EVAL_WAVES
+#define HIMUT_EVAL_WAVES 4
+#endif
 template <bool PHASE>
-__global__ void __launch_bounds__(256) k_eval_columns(EvalArgs A) {
+__global__ void __launch_bounds__(256, HIMUT_EVAL_WAVES) k_eval_columns(EvalArgs A) {
     __shared__ double s_lut[3 * 256];
     __shared__ double s_prior[4];
     const int tid = threadIdx.x;

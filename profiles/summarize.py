@@ -46,7 +46,7 @@ def pmc_avg(d, counter):
 # text, 16 bytes per lane as well.)
 STREAMING = ("k_parse_cs", "k_stream_capture")
 # the kernels of one himut_run (bench.py's step): their sum is roofline_step's counter figure
-STEP_KERNELS = ("k_parse_cs", "k_stream_capture", "k_mask_emit", "k_eval_columns", "k_block_table2", "k_resolve_seen",
+STEP_KERNELS = ("k_parse_cs", "k_stream_capture", "k_mask_emit", "k_eval_columns", "k_block_sums", "k_block_table3", "k_scan_small",
                 "k_finalize_flags", "k_compact", "k_run_totals", "k_window_index", "k_read_hap")
 
 
