@@ -53,7 +53,8 @@ EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_err
            "himut_run", "himut_get_records", "himut_get_log", "himut_get_stats", "himut_records_device",
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
            "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing", "himut_sbs96_counts", "himut_ingest_begin", "himut_ingest_buffer",
-           "himut_ingest_wait", "himut_ingest_window", "himut_ingest_end", "himut_ingest_read_meta", "himut_download_reads"]
+           "himut_ingest_wait", "himut_ingest_window", "himut_ingest_end", "himut_ingest_read_meta", "himut_download_reads",
+           "himut_inflate_blocks"]
 
 _lib = None
 
@@ -118,6 +119,8 @@ def lib():
                                      ctypes.c_void_p]
     L.himut_run_edges.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int64, ctypes.c_void_p]
+    L.himut_inflate_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
     L.himut_ingest_begin.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
     L.himut_ingest_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.himut_ingest_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -293,6 +296,17 @@ class Context:
 
     def raise_for(self, rc):
         self._check(rc)
+
+    def inflate_blocks(self, comp, blocks, out_bytes):
+        """BGZF blocks inflated on the device: comp = bytes-like of the compressed bytes, blocks = numpy structured array
+        (uoff u8, coff u4, clen u4, isize u4, pad u4).  Returns (inflated bytes as uint8 array, status bits, kernel ms)."""
+        comp = np.frombuffer(comp, np.uint8)
+        blocks = np.ascontiguousarray(blocks)
+        out = np.zeros(int(out_bytes), np.uint8)
+        status, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        self._check(self._L.himut_inflate_blocks(self._h, comp.ctypes.data, comp.shape[0], blocks.ctypes.data, blocks.shape[0],
+                                                 out.ctypes.data, out.shape[0], ctypes.byref(status), ctypes.byref(ms)))
+        return out, status.value, ms.value
 
     def ingest_wait(self, slot):
         self._check(self._L.himut_ingest_wait(self._h, int(slot)))

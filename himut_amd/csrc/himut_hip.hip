@@ -1073,6 +1073,45 @@ int himut_ingest_end(himut_ctx* c, int unique_qnames, himut_ingest_result* out) 
     });
 }
 
+// ---- the BGZF inflate on the device (csrc/himut_inflate.h), as a call of its own: host buffers in, host buffers out.
+// What the tests and tools/bench_inflate.py use; the ingest path keeps everything on the device.
+int himut_inflate_blocks(himut_ctx* c, const void* comp, int64_t comp_bytes, const himut_bgzf_block* blocks, int64_t n_blocks,
+                         void* out, int64_t out_bytes, int* status, double* kernel_ms) {
+    if (!c || !comp || !blocks || !out || !status || comp_bytes < 0 || n_blocks < 0 || out_bytes < 0) return fail(c, HIMUT_ERR_ARG, "bad inflate arguments");
+    for (int64_t k = 0; k < n_blocks; k++)
+        if ((int64_t)blocks[k].coff + blocks[k].clen > comp_bytes || (int64_t)blocks[k].uoff + blocks[k].isize > out_bytes)
+            return fail(c, HIMUT_ERR_ARG, "BGZF block outside its buffer");
+    return guarded(c, [&]() -> int {
+        HCHECK(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        static_assert(sizeof(himut_bgzf_block) == sizeof(BgzfBlock), "the C ABI's block descriptor is the kernel's");
+        c->d_stage[0].reserve((size_t)comp_bytes + 256);
+        c->d_stage[1].reserve((size_t)out_bytes + 256);
+        c->d_desc.reserve((size_t)n_blocks * sizeof(BgzfBlock) + 256);
+        c->d_istate.reserve(256);
+        c->d_offs.reserve((size_t)std::max<int64_t>(n_blocks, 1) * 288 * 2 + 256);
+        HCHECK(hipMemcpyAsync(c->d_stage[0].p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+        HCHECK(hipMemsetAsync((uint8_t*)c->d_stage[0].p + comp_bytes, 0, 192, st));
+        HCHECK(hipMemcpyAsync(c->d_desc.p, blocks, (size_t)n_blocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
+        HCHECK(hipMemsetAsync(c->d_istate.p, 0, 4, st));
+        hipEvent_t e0, e1;
+        HCHECK(hipEventCreate(&e0)); HCHECK(hipEventCreate(&e1));
+        HCHECK(hipEventRecord(e0, st));
+        if (n_blocks)
+            hipLaunchKernelGGL(k_bgzf_inflate, dim3(blocks_for(n_blocks, 64)), dim3(64), 0, st, c->d_stage[0].as<uint8_t>(),
+                               c->d_desc.as<BgzfBlock>(), n_blocks, c->d_stage[1].as<uint8_t>(), c->d_istate.as<int>(), c->d_offs.as<uint16_t>());
+        HCHECK(hipEventRecord(e1, st));
+        HCHECK(hipMemcpyAsync(status, c->d_istate.p, 4, hipMemcpyDeviceToHost, st));
+        HCHECK(hipMemcpyAsync(out, c->d_stage[1].p, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
+        HCHECK(hipStreamSynchronize(st));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (kernel_ms) *kernel_ms = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return HIMUT_OK;
+    });
+}
+
 int himut_ingest_read_meta(himut_ctx* c, int32_t* tstart, int32_t* tend, int32_t* qlen, uint8_t* mapq, uint8_t* tp) {
     if (!c) return HIMUT_ERR_ARG;
     return guarded(c, [&]() -> int {

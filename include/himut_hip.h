@@ -218,6 +218,17 @@ int himut_ingest_wait(himut_ctx* ctx, int slot);
 int himut_ingest_window(himut_ctx* ctx, int slot, int64_t start, int64_t nbytes, const uint32_t* rec_off, const int32_t* qid,
                         int64_t n_rec, int64_t padded_bases, int64_t tag_bytes);
 int himut_ingest_end(himut_ctx* ctx, int unique_qnames, himut_ingest_result* out);
+/* The BGZF inflate on the device, one lane per block (csrc/himut_inflate.h; the reference reads BAM through htslib,
+ * caller.py:267): comp = the blocks' compressed bytes, blocks[k] = where block k's raw DEFLATE stream sits in comp, its
+ * length, the number of bytes it inflates to (ISIZE) and where they go in out.  *status = OR of 1 << error over the blocks
+ * (0: every block inflated to exactly its ISIZE), *kernel_ms = the kernel's time.  Host buffers in and out: for tests and
+ * measurements; the ingest keeps the bytes on the device. */
+typedef struct himut_bgzf_block {
+    uint64_t uoff;
+    uint32_t coff, clen, isize, pad;
+} himut_bgzf_block;
+int himut_inflate_blocks(himut_ctx* ctx, const void* comp, int64_t comp_bytes, const himut_bgzf_block* blocks, int64_t n_blocks,
+                         void* out, int64_t out_bytes, int* status, double* kernel_ms);
 /* per-read fields the host needs for bamlib.get_thresholds (bamlib.py:137-178); any pointer may be null */
 int himut_ingest_read_meta(himut_ctx* ctx, int32_t* tstart, int32_t* tend, int32_t* qlen, uint8_t* mapq, uint8_t* tp);
 /* the resident read batch back on the host (arrays of the caller, sized by the fields of `batch` on entry) */
