@@ -210,3 +210,37 @@ def test_sbs96_counts_on_device_match_reference(worker, tmp_path):
     dev = {"{}[{}]{}".format("ACGT"[u], subs[s6], "ACGT"[d]): int(h[s6 * 16 + u * 4 + d]) for s6 in range(6) for u in range(4) for d in range(4)}
     assert dev == want and int(h[96]) == n_drop and int(h[97]) == n_key and n_drop > 0 and n_key > 0 and int(h[98]) == 0
     assert int(worker.ctx.sbs96_counts([len(seq) - 1], [ord("C")], [ord("T")])[98]) == 1          # IndexError in the reference
+
+
+def test_call_and_normcounts_interleaved_on_one_context(worker):
+    """A call run leaves its scalars and position bitmap empty for the next call run; the normcounts sweep and the edge
+    counts use the same buffers in between: every run gives what it gives on a fresh context, in any order."""
+    from himut_amd import normcounts, synth, util as hutil
+    s = synth.generate(synth.SynthConfig(seed=35, contig_len=260_000, name="chrI"), want_ref=True)
+    s2 = synth.generate(synth.SynthConfig(seed=36, contig_len=900_000, name="chrJ"))
+    refseq = bytes(s.ref)
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((s.batch.name, 0, s.batch.length))]
+    chunks2 = [(c[1], c[2]) for c in hutil.chunkloci((s2.batch.name, 0, s2.batch.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=9000, qlen_upper_limit=22500, md_threshold=52)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+
+    def call(b, ch):
+        _configure(worker, p)
+        recs, log = worker.call_contig(b, ch)
+        return recs.tobytes(), list(log)
+
+    def norm():
+        _configure(worker, p)
+        return normcounts.norm_contig(worker, s.batch, chunks, refseq, None, None, False, order)
+
+    c1, n1, c2 = call(s.batch, chunks), norm(), call(s2.batch, chunks2)
+    assert len(c1[0]) > 64 * 100 and n1[2][13] > 0
+    for k in range(3):
+        assert norm() == n1
+        assert call(s2.batch, chunks2) == c2            # a longer contig: more bitmap than the run before left empty
+        assert call(s.batch, chunks) == c1
+        worker.ctx.run()                                  # the same reads again: nothing pushed, nothing cleared up front
+        assert (worker.ctx.records().tobytes(), list(worker.ctx.log())) == c1
+        assert norm() == n1
+        assert call(s.batch, chunks) == c1
