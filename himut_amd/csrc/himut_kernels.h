@@ -1,41 +1,36 @@
 // Device code of libhimut_hip.so: hand-written HIP kernels for gfx950 (MI355X).
 //
-// Pipeline for one contig (himut_run in himut_hip.hip launches them in order):
+// Pipeline for one contig (himut_run in himut_hip.hip launches them in order; DESIGN.md sections 2-4):
 //
-//   k_parse_cs         one wave per read: first the sum of BQ over the whole query with 16-byte
-//                      coalesced loads (np.mean, bamlib.py:34-36), then a wave-parallel tokenizer:
-//                      cs tag -> gapless segments + mismatch list + identity (cslib.py:7-64,
-//                      bamlib.py:47-63)
+//   k_parse_cs         one wave per read, a wave-parallel tokenizer: cs tag -> gapless segments + mismatch list +
+//                      identity (cslib.py:7-64, bamlib.py:47-63); sets the bitmap of column positions (the
+//                      substitutions of the reads that pass the filters known so far); checks the cs bases against
+//                      SEQ; on its way every wave stores its share of the EMPTY column store
 //   k_read_hap         (--phase) one thread per (chunk, read): haplib.py:46-83
-//   k_propose          one wave per read: read filters of caller.py:310-317, cs vs SEQ check of
-//                      every substitution; lanes = mismatch entries: trim / mismatch-window
-//                      filters (bamlib.py:69-86,222-282); every surviving (chunk, tpos, ref, alt)
-//                      sets its bit in a per-chunk mask (the set() of caller.py:324)
-//   k_mask_count / k_mask_emit + scan
-//                      the set bits of the mask, enumerated in (chunk, tpos, ref, alt) order =
-//                      the candidate list; radix-sorted afterwards only when the chunks are
-//                      not already in coordinate order
-//   k_window_index     per 256-position block: the range of reads that can cover it
-//   k_candpos_set / k_word_popc / k_block_slots / k_block_table + scans
-//                      bitmap of candidate positions, its rank index, and per 256-position
-//                      block the read window and the offset of its columns
-//   k_stream_capture   one wave per read, a software pipeline over windows of 2048 query bases:
-//                      streams the read's qualities and packed bases once (16-byte coalesced
-//                      loads, two windows ahead), enumerates the candidate positions under
-//                      each window from the bitmap, one per lane, and drops their
-//                      (allele, BQ) cells into the column store
-//   k_eval_columns     one THREAD per candidate column: allele counts, BQ sums, the
-//                      genotype likelihood sums added in fetch order exactly as the
-//                      reference's python sum() does, genotype, filter cascade
+//   k_window_index     per 256-position block: the range of reads that can cover it (once per pushed batch)
+//   k_block_sums / k_block_table3
+//                      per 256-position block the number of column positions and of column-store slots, their
+//                      prefix sums (first rank, slot offset) and the block table
+//   k_stream_capture   one wave per read, a software pipeline over windows of 2048 query bases: streams the read's
+//                      qualities and packed bases once (16-byte coalesced loads, two windows ahead), sums the
+//                      qualities (np.mean of the whole query, bamlib.py:34-36), enumerates the column positions
+//                      under each window from the bitmap, one per lane, and drops their (allele, BQ) cells into the
+//                      column store; then the read's proposals (propose_read): read filters of caller.py:310-317,
+//                      trim / mismatch-window filters (bamlib.py:69-86,222-282); every surviving (chunk, tpos, ref,
+//                      alt) sets its bit in a per-chunk mask (the set() of caller.py:324)
+//   k_scan_small / k_mask_emit
+//                      the set bits of the mask, enumerated in (chunk, tpos, ref, alt) order = the candidate list;
+//                      radix-sorted afterwards only when the chunks are not already in coordinate order
+//   k_eval_columns     one THREAD per candidate column: allele counts, BQ sums, the genotype likelihood sums added in
+//                      fetch order exactly as the reference's python sum() does, genotype, filter cascade
 //                      (caller.py:44-72,324-621, bamlib.py:181-219, gtlib.py:72-174)
-//   k_resolve_seen / k_finalize_flags / k_compact
-//                      sorted order, cross-chunk som_seen (caller.py:244,347,
-//                      bamlib.py:77), the 15 counters (caller.py:625-641), set()
-//                      de-duplication (caller.py:622-624)
-//   k_pile_dense       dense per-position pile (counts + BQ sums for EVERY position of a
-//                      range): LDS-staged base/BQ tiles, one workgroup per tile.  Used by
-//                      himut_pile_counts (the per-position sweep of normcounts.py:317-400
-//                      builds on it).
+//   k_finalize_flags / k_run_totals / k_compact
+//                      cross-chunk som_seen (caller.py:244,347, bamlib.py:77), the 15 counters (caller.py:625-641),
+//                      set() de-duplication (caller.py:622-624), the totals, the emitted records to the front
+//   k_pile_dense       dense per-position pile (counts + BQ sums for EVERY position of a range): LDS-staged base/BQ
+//                      tiles, one workgroup per tile.  Used by himut_pile_counts.
+//   k_word_popc / k_block_slots / k_block_table / k_fill_bits
+//                      the column index of the normcounts sweep's column-store form (HIMUT_NORM_SWEEP=store)
 //
 // Integer work plus a small fp64 tail; no MFMA.  Wave size 64 throughout.
 #pragma once
@@ -1061,7 +1056,7 @@ __device__ __forceinline__ uint32_t pos_rank(const PosIndex& X, int32_t rpos) {
 }
 
 // Column positions and column-store slots per 256-position block, taken straight from the bitmap and the read
-// windows: the input of ONE scan whose two sums are each block's first rank and its slot offset.
+// windows; their two prefix sums are each block's first rank and its slot offset.
 struct BlockCount {
     const uint32_t* bits;
     const int32_t *winlo, *winhi;
@@ -1077,23 +1072,6 @@ struct BlockCount {
 struct PlusU2 {
     __host__ __device__ uint2 operator()(const uint2& a, const uint2& b) const { return make_uint2(a.x + b.x, a.y + b.y); }
 };
-
-// BlockTab from that scan (first rank, slot offset).  Also leaves the slot offsets / counts as plain arrays (the run's
-// totals).  err: HIMUT_ERR_DEPTH when the column store of the contig needs more than 2^32 slots (a block's product or
-// the running offset no longer fits the 32-bit fields) or a window holds more than 2^22 reads.
-__global__ void __launch_bounds__(256) k_block_table2(BlockCount F, const uint2* scan, int64_t nblk, BlockTab* bt, uint32_t* blkoff,
-                                                      uint32_t* blkslots, int* err) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblk) return;
-    const uint2 c = F(b), o = scan[b];
-    const uint32_t nr = (uint32_t)(F.winhi[b] - F.winlo[b]);
-    BlockTab t;
-    t.lo = F.winlo[b]; t.ncnt = nr | (c.x << 22); t.boff = o.y; t.ufirst = o.x;
-    bt[b] = t;
-    blkoff[b] = o.y; blkslots[b] = c.y;
-    const unsigned long long s = ((unsigned long long)c.x * nr + 15ULL) & ~15ULL;
-    if (nr > BT_N_MASK || s > 0xffffffffULL || (unsigned long long)o.y + s > 0xffffffffULL) set_err(err, HIMUT_ERR_DEPTH);
-}
 
 // ---- the same index without a library scan.  rocPRIM's scan is two launches (state initialisation, look-back scan)
 // of ~14 us for a quarter of a million elements, most of it launch and drain; here the prefix sums are two plain
