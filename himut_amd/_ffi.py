@@ -54,7 +54,7 @@ EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_err
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
            "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing", "himut_sbs96_counts", "himut_ingest_begin", "himut_ingest_buffer",
            "himut_ingest_wait", "himut_ingest_window", "himut_ingest_end", "himut_ingest_read_meta", "himut_download_reads",
-           "himut_inflate_blocks"]
+           "himut_inflate_blocks", "himut_run_begin", "himut_run_end"]
 
 _lib = None
 
@@ -216,6 +216,13 @@ class Context:
 
     def run(self):
         self._check(self._L.himut_run(self._h))
+
+    def run_begin(self):
+        """The run queued, not waited for (run_end does that): several contexts' runs back to back on one GPU."""
+        self._check(self._L.himut_run_begin(self._h))
+
+    def run_end(self):
+        self._check(self._L.himut_run_end(self._h))
 
     def records(self):
         p = ctypes.c_void_p()

@@ -77,6 +77,12 @@ enum { EV_START = 0, EV_SIDE, EV_PARSE, EV_HAP, EV_EMIT, EV_INDEX, EV_GATHER, EV
 
 }  // namespace
 
+struct PendingRun {
+    bool active = false, spec = false;
+    int64_t ncap = 0, slot_cap = 0, nreserve = 0, positions = 0;
+    size_t lead_bytes = 0;
+};
+
 struct himut_ctx {
     int device = 0;
     int n_cus = 256;
@@ -108,6 +114,7 @@ struct himut_ctx {
     int64_t n = 0, cs_bytes = 0, seq_bytes = 0, bq_bytes = 0, read_bases = 0;
     std::vector<int32_t> h_tstart, h_tend, h_prefmax;
     bool unique_qnames = true, any_longcs = false;
+    PendingRun pending;               // a run whose host half is still to come (himut_run_begin / himut_run_end)
     size_t lead_clean_bytes = 0;      // bytes of the position bitmap (and the scalars) a call run left empty for the next one
     DevBuf d_tstart, d_tend, d_qstart, d_qlen, d_mapq, d_flag, d_qid, d_qoff, d_csoff, d_seq, d_bq, d_cs, d_prefmax;
     // derived
@@ -408,8 +415,11 @@ void alloc_derived(himut_ctx* c) {
 // column windows / offsets -> k_stream_capture (every quality and base byte of the contig exactly once: the
 // column store AND the whole-read quality sums) -> k_propose (the read filters now have the quality mean) ->
 // candidates out of the mask -> k_eval_columns -> finalisation.
-int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
+int finish_run(himut_ctx* c, bool* overflow);
+
+int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow, bool defer) {
     *overflow = false;
+    c->pending.active = false;
     if (!c->have_params) return fail(c, HIMUT_ERR_ARG, "himut_set_params has not been called");
     if (!c->have_lut) return fail(c, HIMUT_ERR_ARG, "himut_set_gt_lut has not been called");
     if (!c->have_reads) return fail(c, HIMUT_ERR_ARG, "himut_push_reads has not been called");
@@ -654,17 +664,35 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     // behind the copy: the scalars and the bitmap empty for the next run (the host does not wait for these)
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
     HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, lead_bytes, st));
+    // what the second half (finish_run) needs: himut_run_begin returns here, with everything queued
+    PendingRun& Q = c->pending;
+    Q.active = true; Q.spec = spec; Q.ncap = ncap; Q.slot_cap = (int64_t)slot_cap; Q.nreserve = nreserve; Q.positions = T.positions;
+    Q.lead_bytes = lead_bytes;
+    if (defer) return HIMUT_OK;
+    return finish_run(c, overflow);
+}
+
+// The host's half behind a run's last copy: waits for it (not for the stream), checks the device's error word and the
+// counts against the capacities, takes the counters and the stage times.
+int finish_run(himut_ctx* c, bool* overflow) {
+    *overflow = false;
+    PendingRun Q = c->pending;
+    c->pending.active = false;
+    if (!Q.active) return HIMUT_OK;
+    HCHECK(hipSetDevice(c->device));
+    const Scalars& hs = *reinterpret_cast<const Scalars*>(c->h_scalars);
     HCHECK(hipEventSynchronize(c->ev[EV_COPIED]));
     if (hs.err) return check_device_err(c, hs.err);
-    c->lead_clean_bytes = lead_bytes;
+    c->lead_clean_bytes = Q.lead_bytes;
+    const int64_t ncap = Q.ncap, slot_cap = Q.slot_cap;
     const int64_t ncand = ncap > 0 ? (int64_t)hs.ncand : 0;
-    const int64_t nslots = ncap > 0 ? (int64_t)hs.reserved0 : (int64_t)slot_cap;
-    if (ncand > ncap || nslots > (int64_t)slot_cap) {   // only a run on kept capacities can get here
+    const int64_t nslots = ncap > 0 ? (int64_t)hs.reserved0 : slot_cap;
+    if (ncand > ncap || nslots > slot_cap) {             // only a run on kept capacities can get here
         *overflow = true;                                // (mask cells past the capacity may still be set: not clean)
         return HIMUT_OK;
     }
     c->mask_clean = true;      // the emit sweep ran over every cell that was set (or nothing was set)
-    if (!spec && c->chunks_in_order) { c->cap_cand = nreserve; c->cap_slots = (int64_t)(slot_cap + slot_cap / 4 + 4096); }
+    if (!Q.spec && c->chunks_in_order) { c->cap_cand = Q.nreserve; c->cap_slots = slot_cap + slot_cap / 4 + 4096; }
     c->stats.column_slots = nslots;
     c->n_out = ncap > 0 ? (int64_t)hs.nrec : 0;
     for (int k = 0; k < 15; k++) c->log[k] = (int64_t)hs.log[k];
@@ -685,7 +713,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
     }
     S.n_reads = c->n;
     S.read_bases = c->read_bases;
-    S.positions = T.positions;
+    S.positions = Q.positions;
     S.n_unique_positions = 0;
     S.n_candidates = ncand;
     S.n_records = c->n_out;
@@ -694,10 +722,34 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow) {
 
 int do_run(himut_ctx* c) {
     bool overflow = false;
-    int rc = do_run_once(c, true, &overflow);
+    int rc = do_run_once(c, true, &overflow, false);
     if (rc == HIMUT_OK && overflow) {
         c->cap_cand = c->cap_slots = 0;
-        rc = do_run_once(c, false, &overflow);
+        rc = do_run_once(c, false, &overflow, false);
+        c->stats.reran = 1;
+    }
+    return rc;
+}
+
+// himut_run in two halves.  begin: everything queued; on kept capacities (any run but a context's first on its reads
+// and chunks) without waiting for anything.  end: the wait, the checks, and the second pass with exact sizes if a count
+// did not fit.  Between the two the context must not be touched.
+int do_run_begin(himut_ctx* c) {
+    bool overflow = false;
+    int rc = do_run_once(c, true, &overflow, true);
+    if (rc == HIMUT_OK && !c->pending.spec && c->pending.active) {     // sized with the host in the loop: nothing left to overlap
+        rc = finish_run(c, &overflow);
+        c->pending.active = false;
+    }
+    return rc;
+}
+int do_run_end(himut_ctx* c) {
+    if (!c->pending.active) return HIMUT_OK;
+    bool overflow = false;
+    int rc = finish_run(c, &overflow);
+    if (rc == HIMUT_OK && overflow) {
+        c->cap_cand = c->cap_slots = 0;
+        rc = do_run_once(c, false, &overflow, false);
         c->stats.reran = 1;
     }
     return rc;
@@ -1149,6 +1201,14 @@ int himut_download_reads(himut_ctx* c, himut_read_batch* b, uint8_t* tp) {
 int himut_run(himut_ctx* c) {
     if (!c) return HIMUT_ERR_ARG;
     return guarded(c, [&]() -> int { return do_run(c); });
+}
+int himut_run_begin(himut_ctx* c) {
+    if (!c) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int { return do_run_begin(c); });
+}
+int himut_run_end(himut_ctx* c) {
+    if (!c) return HIMUT_ERR_ARG;
+    return guarded(c, [&]() -> int { return do_run_end(c); });
 }
 
 int himut_get_records(himut_ctx* c, const himut_record** records, int64_t* n) {

@@ -180,6 +180,12 @@ int himut_set_phase(himut_ctx* ctx, const int64_t* off, const int32_t* hpos, con
                     const uint8_t* halt, const uint8_t* hbit, int64_t n_chunks);
 int himut_push_reads(himut_ctx* ctx, const himut_read_batch* batch);
 int himut_run(himut_ctx* ctx);
+/* himut_run in two halves, for a caller that scans several contigs (a context each): begin queues the whole run and --
+ * on any run but a context's first on its reads and chunks -- returns without waiting; end waits for the run's last
+ * copy, checks it and makes the results available.  Runs of different contexts begun one after the other share the GPU
+ * without the host in between.  A context must not be touched between its begin and its end. */
+int himut_run_begin(himut_ctx* ctx);
+int himut_run_end(himut_ctx* ctx);
 int himut_get_records(himut_ctx* ctx, const himut_record** records, int64_t* n);
 int himut_get_log(himut_ctx* ctx, int64_t out[15]);
 int himut_get_stats(himut_ctx* ctx, himut_run_stats* out);
