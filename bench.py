@@ -217,11 +217,11 @@ def main():
     t0 = time.perf_counter()
     # timed region: the library records only the run's start / end and the events around the column capture
     # (the dominant kernel, whose launch time the roofline needs); an event costs a barrier packet on the queue
+    stage_ms = {"ms_total": [], "ms_capture": [], "reran": []}
     for _ in range(a.steps):
         step()
-        st = ctx.stats()
-        for k in ("ms_total", "ms_capture", "reran"):
-            stage_ms.setdefault(k, []).append(st[k])
+        tot_, cap_, rr_ = ctx.stats_brief()
+        stage_ms["ms_total"].append(tot_); stage_ms["ms_capture"].append(cap_); stage_ms["reran"].append(rr_)
     gathered = ex.drain() if ex is not None else None
     barrier()
     elapsed = time.perf_counter() - t0

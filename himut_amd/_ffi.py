@@ -243,6 +243,14 @@ class Context:
         self._check(self._L.himut_get_stats(self._h, ctypes.byref(s)))
         return s.as_dict()
 
+    def stats_brief(self):
+        """(ms_total, ms_capture, reran) of the last run without building the whole dictionary: what a timed loop reads."""
+        s = getattr(self, "_st", None)
+        if s is None:
+            s = self._st = RunStats()
+        self._L.himut_get_stats(self._h, ctypes.byref(s))
+        return s.ms_total, s.ms_capture, s.reran
+
     def set_stage_timing(self, level):
         """0: total only; 1: + column capture (default); 2: every stage (costs a few microseconds per event)."""
         self._check(self._L.himut_set_stage_timing(self._h, int(level)))
