@@ -428,7 +428,7 @@ k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbi
     // wave-uniform running state
     int t = M.tstart, q = uni(R.qstart[r]);
     int ns = 0, nm = 0, bad = 0;
-    long long match = 0, mism = 0;   // per lane; summed over the wave after the last step
+    int match = 0, mism = 0;         // per lane; summed over the wave after the last step (a read's reference span fits 31 bits)
     bool have_carry = false; int carry_start = 0, carry_kind = 0;     // unfinished last operation of the previous step
     bool aligned_open = false; int run_t0 = 0, run_q0 = 0; bool run_ins = false;  // the aligned run still growing
     int last_kind = 0;                                                 // kind of the last finished operation
@@ -452,30 +452,40 @@ k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbi
         if (lane < 2) *reinterpret_cast<uint4*>(txt + 16 * lane) = pb;
         __builtin_memcpy(&vcur, cs + min(base + PB, last_base) + 16 * lane, 16);
         __builtin_amdgcn_wave_barrier();
-        // ---- operation starts in this lane's 16 bytes, four bytes at a time in the registers they came in
-        uint32_t mask16 = 0;
+        // ---- operation starts in this lane's 16 bytes, four bytes at a time in the registers they came in.  A byte's
+        // class comes from two 16-entry tables looked up with v_perm_b32, one by its high nibble (which row of the ASCII
+        // table), one by its low nibble (which rows that column belongs to): bit 0 / 1 = an operation's first byte
+        // (* + - in row 2, : = in row 3), bits 2..4 = payload (digits, upper case, lower case)
+        uint32_t stf[4];                                             // 0x80 in the bytes that start an operation
         {
             const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-            uint32_t okmask = 0;
+            const int nhere = min(max(nb - 16 * lane, 0), 16);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t st = cs_start_bytes(words[k]), ok = st | cs_payload_bytes(words[k]);
-                mask16 |= cs_pack4(st) << (4 * k);
-                okmask |= cs_pack4(ok & ~(words[k] & 0x80808080u)) << (4 * k);
+                const uint32_t w = words[k];
+                const int nv = min(max(nhere - 4 * k, 0), 4);
+                const uint32_t inside = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1u));   // bytes of the tag
+                const uint32_t rh = __builtin_amdgcn_perm(0x10081008u, 0x06010000u, (w >> 4) & 0x07070707u);
+                const uint32_t lo = w & 0x0f0f0f0fu, l7 = lo & 0x07070707u;
+                const uint32_t la = __builtin_amdgcn_perm(0x1c1c1c1cu, 0x1c1c1c14u, l7), lb = __builtin_amdgcn_perm(0x08080b08u, 0x091b1c1cu, l7);
+                const uint32_t rl = __builtin_amdgcn_perm(lb, la, 0x03020100u | ((lo >> 1) & 0x04040404u));
+                const uint32_t r = rh & rl, ascii = ~w & 0x80808080u;
+                stf[k] = ((r & 0x03030303u) + 0x7f7f7f7fu) & ascii & inside;
+                const uint32_t ok = ((r & 0x1f1f1f1fu) + 0x7f7f7f7fu) & ascii;
+                if (~ok & inside) bad = HIMUT_ERR_CS;                // a byte the reference's pattern has no place for
             }
-            const int nhere = min(max(nb - 16 * lane, 0), 16);
-            const uint32_t keep = (1u << nhere) - 1u;
-            mask16 &= keep;
-            if (~okmask & keep) bad = HIMUT_ERR_CS;                  // a byte the reference's pattern has no place for
         }
-        const int cnt = __popc(mask16);
+        const int cnt = __popc(stf[0]) + __popc(stf[1]) + __popc(stf[2]) + __popc(stf[3]);
         const int incl = wave_incl_add(cnt, lane);
         const int total = lane_val(incl, 63);
         const int off0 = have_carry ? 1 : 0;
         {
             int w = off0 + incl - cnt;
-            uint32_t mk = mask16;
-            while (mk) { const int i = __ffs((int)mk) - 1; mk &= mk - 1; starts[w++] = (uint16_t)(16 * lane + i); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t mk = stf[k];
+                while (mk) { const int i = __ffs((int)mk) - 1; mk &= mk - 1; starts[w++] = (uint16_t)(16 * lane + 4 * k + (i >> 3)); }
+            }
         }
         const int m = off0 + total;
         const bool last_block = base + PB >= n;
@@ -633,12 +643,7 @@ k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbi
     }
     if constexpr (WITH_BQ) bq_finish(Q, r, lane, D.bqsum);
     // a reduction of the lanes' error codes
-    {
-        int b = bad;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) b = max(b, __shfl_xor(b, d, 64));
-        bad = b;
-    }
+    if (__ballot(bad != 0)) bad = lane_val(wave_incl_max(bad, lane), 63);      // (rare; the code with the highest number)
     if (!bad) {
         // end of the tag: close the open run; an insertion at the very end is a marker segment
         if (lane == 0) {
@@ -648,11 +653,10 @@ k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbi
         if (aligned_open || last_kind == '+') ns++;
         if (t != M.tend || q > qlen) bad = HIMUT_ERR_CS;   // cs inconsistent with CIGAR / SEQ
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { match += __shfl_xor(match, d, 64); mism += __shfl_xor(mism, d, 64); }
-    // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow in k_propose
-    if (!bad && match + mism == 0) bad = HIMUT_ERR_CS;     // an empty tag: ZeroDivisionError in the reference (bamlib.py:62)
-    const double ident = (double)match / (double)(match + mism);
+    const long long match_all = (long long)lane_val(wave_incl_add(match, lane), 63), mism_all = (long long)lane_val(wave_incl_add(mism, lane), 63);
+    // identity filter (bamlib.py:47-63, caller.py:314); the other read filters follow behind the capture
+    if (!bad && match_all + mism_all == 0) bad = HIMUT_ERR_CS;     // an empty tag: ZeroDivisionError in the reference (bamlib.py:62)
+    const double ident = (double)match_all / (double)(match_all + mism_all);
     const bool ident_ok = !bad && !(ident < P.p.min_sequence_identity);
     if (mark && ident_ok && nmark > 0) flush_marks();
     if (lane == 0) {
