@@ -791,7 +791,10 @@ __device__ __forceinline__ void propose_read(const Reads& R, const Derived& D, c
     if (M.flags & RF_SECONDARY) return;
     const bool phase = P.p.phase != 0;
     bool live = (M.flags & RF_IDENT_OK) != 0;                             // bamlib.py:47-63, caller.py:314
-    if ((double)bqs / (double)qlen < (double)P.p.min_qv) live = false;    // bamlib.py:35
+    // np.mean(bq) < min_qv (bamlib.py:35, caller.py:310) in integers: for integers S, n, k the rounded quotient fl(S / n) is
+    // below k exactly when S < k n (a quotient below k is below it by at least 1 / n, far more than half an ulp; rounding
+    // is monotonic), and an empty query (0 / 0, not below anything) passes either way
+    if (P.p.min_qv > 0 && (unsigned long long)bqs < (unsigned long long)P.p.min_qv * (unsigned long long)(uint32_t)qlen) live = false;
     if (mapq < P.p.min_mapq) live = false;
     if (!(P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit)) live = false;
     const int32_t ts = M.tstart, te = M.tend;
