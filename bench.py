@@ -132,8 +132,22 @@ def cpu_baseline(batch, chunks, params, pon, com, sample_mb):
     return out
 
 
+def emit_line(out):
+    """The one JSON line, on the process's real stdout (see main)."""
+    os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def main():
+    global _REAL_STDOUT
     a = parse()
+    # Exactly one line goes to stdout: libraries that greet on file descriptor 1 (RCCL's version banner, gloo's
+    # "connected to peer ranks") write to stderr from here on, the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,19 +265,8 @@ def main():
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     positions, cand_sites, read_bases, n_records = [float(x) for x in totals.tolist()]
 
-    # ---- BASELINE configs[2]: the whole synthetic GRCh38, strong scaling (N > 1; HIMUT_BENCH_GENOME=1 forces it on
-    # one rank, HIMUT_BENCH_GENOME_SCALE divides the contig lengths for rehearsals)
-    genome_strong = None
-    if world > 1 or os.environ.get("HIMUT_BENCH_GENOME") == "1":
-        from himut_amd import genome
-        w.close()
-        w = None
-        del sample, batch_keep
-        if world > 1:
-            batch = None          # (only the single-rank run goes on to the CPU baseline, which needs the reads)
-        genome_strong = genome.run_genome(rank, world, local_rank, scale=float(os.environ.get("HIMUT_BENCH_GENOME_SCALE", "1")),
-                                          depth=a.depth, steps=max(1, min(a.steps, 3)), backend=backend)
-
+    want_genome = world > 1 or os.environ.get("HIMUT_BENCH_GENOME") == "1"
+    out = None
     if rank == 0:
         if gathered is not None:   # every step's exchange delivered every rank's records
             counts, last = gathered
@@ -334,11 +337,40 @@ def main():
             # capacities kept from the run before): 0 expected after the warm-up
             "reran_steps": reran_steps,
         }
-        if genome_strong is not None:
-            out["genome_strong"] = genome_strong
         if not a.no_cpu_baseline and world == 1:           # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(batch, chunks, params, pon, com, a.cpu_sample_mb)
-        print(json.dumps(out), flush=True)
+
+    # ---- BASELINE configs[2]: the whole synthetic GRCh38, strong scaling (N > 1; HIMUT_BENCH_GENOME=1 forces it on
+    # one rank, HIMUT_BENCH_GENOME_SCALE divides the contig lengths for rehearsals).  It runs behind the headline
+    # measurement and under a watchdog: whatever happens in it, the headline line is printed.
+    if want_genome:
+        import threading
+        from himut_amd import genome
+        w.close()
+        w = None
+        del sample, batch_keep
+        batch = None
+        limit = float(os.environ.get("HIMUT_BENCH_GENOME_LIMIT_S", "420"))
+
+        def give_up(why):
+            if rank == 0:
+                out["genome_strong"] = {"error": why}
+                emit_line(out)
+            os._exit(0)         # (the other ranks may sit in a collective: no teardown)
+        timer = threading.Timer(limit, give_up, args=("the genome leg did not finish within {:.0f} s".format(limit),))
+        timer.daemon = True
+        timer.start()
+        try:
+            genome_strong = genome.run_genome(rank, world, local_rank, scale=float(os.environ.get("HIMUT_BENCH_GENOME_SCALE", "1")),
+                                              depth=a.depth, steps=max(1, min(a.steps, 3)), backend=backend)
+        except Exception as e:      # noqa: BLE001 -- reported in the line, the headline stands
+            timer.cancel()
+            give_up("{}: {}".format(type(e).__name__, e))
+        timer.cancel()
+        if rank == 0:
+            out["genome_strong"] = genome_strong
+    if rank == 0:
+        emit_line(out)
     if w is not None:
         w.close()
     if dist.is_initialized():
