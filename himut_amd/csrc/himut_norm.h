@@ -621,6 +621,9 @@ __global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
 #ifndef HIMUT_NT_WAVES
 #define HIMUT_NT_WAVES 5
 #endif
+#ifndef HIMUT_NT_NSG
+#define HIMUT_NT_NSG 2
+#endif
 constexpr int NT_Q = HIMUT_NT_Q;         // workgroups per XCD class and chunk (each strides over its class's tiles)
 constexpr int NT_ROWS = 48;
 constexpr int NT_RPW = NT_ROWS / 4;    // rows per wave and batch
@@ -688,9 +691,10 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
                 while (a < e) { const int m = (a + e) >> 1; if (D.segs[M.segbase + m].t0 <= (int32_t)base) a = m + 1; else e = m; }
                 j0 = max(a - 1, 0);
             }
-            int4 sg[4];
+            constexpr int NSG = HIMUT_NT_NSG;          // segments of a row kept in registers (the rest, rarely wanted, come from memory)
+            int4 sg[NSG];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < NSG; k++) {
                 sg[k] = make_int4(0x7fffffff, 0, 0, 0);
                 if (live_row && j0 + k < M.nseg) sg[k] = *reinterpret_cast<const int4*>(D.segs + M.segbase + j0 + k);
             }
@@ -734,9 +738,10 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
                     for (int j = jf; j < ns; j++) {
                         int4 sv;
                         const int k = j - jf;
-                        if (k < 4) {
-                            const int4 c0 = sg[0], c1 = sg[1], c2 = sg[2], c3 = sg[3];
-                            const int4 c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                        if (k < NSG) {
+                            int4 c = sg[0];
+#pragma unroll
+                            for (int kk = 1; kk < NSG; kk++) if (k == kk) c = sg[kk];
                             sv = make_int4(lane_val(c.x, l), lane_val(c.y, l), lane_val(c.z, l), lane_val(c.w, l));
                         } else {
                             const Seg g = D.segs[segbase + j];
