@@ -131,9 +131,16 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
         p0 = *reinterpret_cast<const uint4*>(R.bq + qo + qn);
         p1 = *reinterpret_cast<const uint4*>(R.bq + qo + qn + 16);
     }
+    int jc = 0;      // the first segment that reaches into the window (segments are in query order: the cursor only moves on)
     for (int32_t c0 = q_first & ~2047; c0 < qlen; c0 += 2048) {
         const int32_t qa = c0 + lane * 32;
         uint32_t word = 0;
+        while (jc < ns) {
+            const int4 sg = SEG(jc);
+            const int32_t qspan = (((uint32_t)uni(sg.w) & SEG_DEL) || uni(sg.z) <= 0) ? 0 : uni(sg.z);
+            if (uni(sg.y) + qspan > c0) break;
+            jc++;
+        }
         const uint4 b0 = p0, b1 = p1;
         {
             const int32_t qn = min(c0 + 2048 + lane * 32, q_last);
@@ -155,7 +162,7 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                 okq &= (a0 <= a1) ? ((a1 - a0 >= 31 ? ~0u : ((1u << (a1 - a0 + 1)) - 1u)) << a0) : 0u;
             }
             // segments under [qa, qa + 32)
-            for (int j = 0; j < ns; j++) {
+            for (int j = jc; j < ns; j++) {
                 const int4 sg = SEG(j);
                 if (sg.y >= qa + 32) break;
                 if (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) continue;
