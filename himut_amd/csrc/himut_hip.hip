@@ -20,6 +20,7 @@
 #include "himut_kernels.h"
 #include "himut_norm.h"
 #include "himut_ingest.h"
+#include "himut_inflate_wave.h"
 
 using namespace himut;
 
@@ -1137,21 +1138,26 @@ int himut_inflate_blocks(himut_ctx* c, const void* comp, int64_t comp_bytes, con
         HCHECK(hipSetDevice(c->device));
         hipStream_t st = c->stream;
         static_assert(sizeof(himut_bgzf_block) == sizeof(BgzfBlock), "the C ABI's block descriptor is the kernel's");
-        c->d_stage[0].reserve((size_t)comp_bytes + 256);
+        c->d_stage[0].reserve((size_t)comp_bytes + 2048);
         c->d_stage[1].reserve((size_t)out_bytes + 256);
         c->d_desc.reserve((size_t)n_blocks * sizeof(BgzfBlock) + 256);
         c->d_istate.reserve(256);
         c->d_offs.reserve((size_t)std::max<int64_t>(n_blocks, 1) * 288 * 2 + 256);
         HCHECK(hipMemcpyAsync(c->d_stage[0].p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
-        HCHECK(hipMemsetAsync((uint8_t*)c->d_stage[0].p + comp_bytes, 0, 192, st));
+        HCHECK(hipMemsetAsync((uint8_t*)c->d_stage[0].p + comp_bytes, 0, 1024, st));
         HCHECK(hipMemcpyAsync(c->d_desc.p, blocks, (size_t)n_blocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
         HCHECK(hipMemsetAsync(c->d_istate.p, 0, 4, st));
         hipEvent_t e0, e1;
         HCHECK(hipEventCreate(&e0)); HCHECK(hipEventCreate(&e1));
         HCHECK(hipEventRecord(e0, st));
-        if (n_blocks)
+        // HIMUT_INFLATE=lane: the lane-per-block decoder (himut_inflate.h); default: a wave per block (himut_inflate_wave.h)
+        const char* which = getenv("HIMUT_INFLATE");
+        if (n_blocks && which && strcmp(which, "lane") == 0)
             hipLaunchKernelGGL(k_bgzf_inflate, dim3(blocks_for(n_blocks, 64)), dim3(64), 0, st, c->d_stage[0].as<uint8_t>(),
                                c->d_desc.as<BgzfBlock>(), n_blocks, c->d_stage[1].as<uint8_t>(), c->d_istate.as<int>(), c->d_offs.as<uint16_t>());
+        else if (n_blocks)
+            hipLaunchKernelGGL(k_bgzf_inflate_wave, dim3(blocks_for(n_blocks, 4)), dim3(256), 0, st, c->d_stage[0].as<uint8_t>(),
+                               c->d_desc.as<BgzfBlock>(), n_blocks, c->d_stage[1].as<uint8_t>(), c->d_istate.as<int>());
         HCHECK(hipEventRecord(e1, st));
         HCHECK(hipMemcpyAsync(status, c->d_istate.p, 4, hipMemcpyDeviceToHost, st));
         HCHECK(hipMemcpyAsync(out, c->d_stage[1].p, (size_t)out_bytes, hipMemcpyDeviceToHost, st));

@@ -1,5 +1,6 @@
-"""The BGZF inflate on the device (one lane per block, csrc/himut_inflate.h) through the C ABI: streams of every kind in
-one launch, and every block of a BAM file, against zlib."""
+"""The BGZF inflate on the device through the C ABI -- both decoders: a wave per block (csrc/himut_inflate_wave.h, the
+default) and a lane per block (csrc/himut_inflate.h, HIMUT_INFLATE=lane): streams of every kind in one launch, and every
+block of a BAM file, against zlib."""
 import struct
 import zlib
 
@@ -31,7 +32,13 @@ def _pack(streams):
     return b"".join(comp), blocks, uo
 
 
-def test_streams_of_every_kind_in_one_launch(ctx):
+@pytest.fixture(params=["wave", "lane"])
+def decoder(request, monkeypatch):
+    monkeypatch.setenv("HIMUT_INFLATE", request.param)
+    return request.param
+
+
+def test_streams_of_every_kind_in_one_launch(ctx, decoder):
     from tests.test_inflate import _raw, _samples
     want, streams = [], []
     for name, data in _samples().items():
@@ -53,7 +60,7 @@ def test_streams_of_every_kind_in_one_launch(ctx):
     assert out2[:a].tobytes() == out[:a].tobytes() and out2[b:].tobytes() == out[b:].tobytes()
 
 
-def test_every_block_of_a_bam(ctx, tmp_path):
+def test_every_block_of_a_bam(ctx, tmp_path, decoder):
     from himut_amd import bamio, synth
     s = synth.generate(synth.SynthConfig(seed=19, contig_len=3_000_000, name="chr7"))
     path = str(tmp_path / "b.bam")
