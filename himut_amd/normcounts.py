@@ -123,19 +123,25 @@ NORM_LOG_ROWS = ["num_ccs", "num_bases", "num_unphased_bases", "num_het_bases", 
 
 
 def read_fasta(path):
-    """name -> sequence exactly as the file spells it (pyfastx keeps the case; so does the worker)."""
-    seqs, name, parts = {}, None, []
-    with open(path) as fh:
-        for line in fh:
-            if line.startswith(">"):
-                if name is not None:
-                    seqs[name] = "".join(parts)
-                name, parts = line[1:].split()[0], []
-            else:
-                parts.append(line.strip())
-    if name is not None:
-        seqs[name] = "".join(parts)
+    """name -> sequence exactly as the file spells it (pyfastx keeps the case; so does the worker).  The file is taken
+    whole and the line ends are deleted record by record (bytes.translate): a 3 Gb genome in seconds, where a loop over
+    its fifty million lines takes a minute."""
+    seqs = {}
+    with open(path, "rb") as fh:
+        data = fh.read()
+    for rec in data.split(b">")[1:] if data.startswith(b">") else _fasta_records(data):
+        header, _, body = rec.partition(b"\n")
+        fields = header.split()
+        if not fields:
+            continue
+        seqs[fields[0].decode()] = body.translate(None, b"\n\r\t ").decode("latin-1")
     return seqs
+
+
+def _fasta_records(data):
+    """Records of a file that does not begin with '>' (leading blank lines): everything behind a '>' at a line start."""
+    i = data.find(b"\n>")
+    return data[i + 2:].split(b"\n>") if i >= 0 else []
 
 
 def _open_sbs(sbs_file):
