@@ -55,14 +55,37 @@ def _data_lines(path):
                 yield line
 
 
+_SIDE_CACHE = {}
+
+
+def _by_contig(vcf_file, kind, parse):
+    """The records of a side VCF that pass ``parse`` (a line -> (chrom, key) or None), grouped by contig.  The reference
+    reads the whole file again for every contig (its workers are separate processes); here one driver process asks for
+    contig after contig, and the file is parsed once per (path, size, time of modification)."""
+    import os
+    st = os.stat(vcf_file)
+    key = (os.path.abspath(vcf_file), kind, st.st_size, st.st_mtime_ns)
+    hit = _SIDE_CACHE.get(key)
+    if hit is None:
+        hit = defaultdict(set)
+        for line in _data_lines(vcf_file):
+            r = parse(line)
+            if r is not None:
+                hit[r[0]].add(r[1])
+        for k in [k for k in _SIDE_CACHE if k[:2] == key[:2]]:
+            del _SIDE_CACHE[k]                      # an older version of the same file
+        _SIDE_CACHE[key] = hit
+    return hit
+
+
+def _pon_record(line):
+    v = VcfRecord(line)
+    return (v.chrom, (v.pos, v.ref, v.alt)) if v.is_snp and v.is_pass else None
+
+
 def load_pon(chrom, vcf_file):
     """(pos, ref, alt) of PASS bi-allelic SNVs on ``chrom`` (vcflib.py:396-409)."""
-    out = set()
-    for line in _data_lines(vcf_file):
-        v = VcfRecord(line)
-        if v.chrom == chrom and v.is_snp and v.is_pass:
-            out.add((v.pos, v.ref, v.alt))
-    return out
+    return set(_by_contig(vcf_file, "pon", _pon_record).get(chrom, ()))
 
 
 def _bgz_lines(path, chrom):
@@ -101,16 +124,21 @@ def load_bgz_common_snp(chrom, vcf_file):
     return out
 
 
+def _common_record(line):
+    f = line.strip().split()
+    alts = f[4].split(",")
+    if f[6] == "PASS" and len(alts) == 1 and len(f[3]) == 1 and len(alts[0]) == 1:
+        return f[0], (int(f[1]), f[3], alts[0])
+    return None
+
+
 def load_common_snp(chrom, vcf_file):
     """(pos, ref, alt) of PASS bi-allelic SNVs -- from the OTHER contigs
     (vcflib.py:426-440: ``if chrom != arr[0] and ...``)."""
     out = set()
-    for line in _data_lines(vcf_file):
-        f = line.strip().split()
-        alts = f[4].split(",")
-        if f[0] != chrom and f[6] == "PASS" and len(alts) == 1:
-            if len(f[3]) == 1 and len(alts[0]) == 1:
-                out.add((int(f[1]), f[3], alts[0]))
+    for c, keys in _by_contig(vcf_file, "common", _common_record).items():
+        if c != chrom:
+            out |= keys
     return out
 
 
