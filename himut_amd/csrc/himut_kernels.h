@@ -1743,6 +1743,9 @@ struct EvalArgs {
 #ifndef HIMUT_EVAL_WAVES
 #define HIMUT_EVAL_WAVES 4
 #endif
+#ifndef HIMUT_EVAL_BATCH
+#define HIMUT_EVAL_BATCH 8
+#endif
 template <bool PHASE>
 __global__ void __launch_bounds__(256, HIMUT_EVAL_WAVES) k_eval_columns(EvalArgs A) {
     __shared__ double s_lut[3 * 256];
@@ -1780,12 +1783,13 @@ __global__ void __launch_bounds__(256, HIMUT_EVAL_WAVES) k_eval_columns(EvalArgs
     double R0 = 0.0, R1 = 0.0, R2 = 0.0, A0 = 0.0, A1 = 0.0, A2 = 0.0;    // the reference / alternative allele's three sums
     uint32_t Rq = 0, Aq = 0;                                              // and their quality sums
     int bad = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 8) {     // eight slots in flight: their addresses do not depend on each other
-      uint32_t vv[8];
+    constexpr int EB = HIMUT_EVAL_BATCH;
+    for (uint32_t i0 = 0; i0 < n; i0 += EB) {    // EB slots in flight: their addresses do not depend on each other
+      uint32_t vv[EB];
 #pragma unroll
-      for (int k = 0; k < 8; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
+      for (int k = 0; k < EB; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
+      for (int k = 0; k < EB; k++) {
         const uint32_t i = i0 + k;
         const uint32_t v = vv[k];
         const uint32_t cell = v & 7u;
