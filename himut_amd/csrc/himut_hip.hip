@@ -124,7 +124,7 @@ struct himut_ctx {
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2, d_logpart;
     // normcounts
-    DevBuf d_refseq, d_live, d_callable, d_tri;
+    DevBuf d_refseq, d_live, d_callable, d_cq, d_tri;
     int64_t reflen = 0;
     uint8_t ref_cls[256] = {};
     int ref_K = 0;
@@ -168,7 +168,8 @@ struct Scalars {
     unsigned long long nccs;
     unsigned long long log[16];
     int err;
-    int pad[23];             // 256 bytes: one aligned fill clears it
+    int qhigh;               // normcounts: a base quality of 128 or more was seen (k_callable)
+    int pad[22];             // 256 bytes: one aligned fill clears it
 };
 static_assert(sizeof(Scalars) == 256, "Scalars is cleared with one aligned fill");
 
@@ -1301,12 +1302,19 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     c->d_live.reserve((size_t)c->n + 64);
     const size_t cwords = (size_t)(c->bq_bytes >> 5) + 64;
     c->d_callable.reserve(cwords * 4);
+    // HIMUT_NORM_SWEEP: "tile" = cells built in LDS by the workgroup (round 2's kernel), "store" = the older sweep through a
+    // column store in HBM (capture + evaluate, in passes); otherwise a wave per 64 columns, no cells in LDS
+    const char* sweep = getenv("HIMUT_NORM_SWEEP");
+    const bool sweep_store = sweep && strcmp(sweep, "store") == 0, sweep_tile = sweep && strcmp(sweep, "tile") == 0;
+    const bool sweep_col = !sweep_store && !sweep_tile;
+    if (sweep_col) c->d_cq.reserve((size_t)c->bq_bytes + 256);       // quality | callable << 7 per base
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
     HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
     HCHECK(hipMemsetAsync(c->d_tri.p, 0, (2 * ntri + 16) * 8, st));
     HCHECK(hipMemsetAsync(c->d_callable.p, 0, cwords * 4, st));
+    if (sweep_col && getenv("HIMUT_DEBUG_FILL_CQ")) HCHECK(hipMemsetAsync(c->d_cq.p, 0, (size_t)c->bq_bytes + 256, st));   // (a base whose byte k_callable did not write shows as a zero quality)
     if (c->n > 0) run_parse_stage(c, R, D, sc);
     else stage_event(c, EV_PARSE, 2, st);
     int32_t maxend = 0;
@@ -1323,7 +1331,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
                                T.npairs, c->d_ccs.as<uint8_t>());
         }
         hipLaunchKernelGGL(k_callable, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, c->d_live.as<uint8_t>(),
-                           c->d_callable.as<uint32_t>());
+                           c->d_callable.as<uint32_t>(), sweep_col ? c->d_cq.as<uint8_t>() : (uint8_t*)nullptr, &sc->qhigh);
         hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, R, nblk, c->d_winlo.as<int32_t>(),
                            c->d_winhi.as<int32_t>());
     }
@@ -1362,14 +1370,19 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     const unsigned ex = blocks_for(maxspan, 256 * NE_TILES);
 
     int64_t slots_total = 0;
-    // HIMUT_NORM_SWEEP=store takes the older sweep through a column store in HBM (capture + evaluate, in passes)
-    const char* sweep = getenv("HIMUT_NORM_SWEEP");
-    const bool tiled = !(sweep && strcmp(sweep, "store") == 0);
-    if (c->n > 0 && T.n > 0 && tiled) {
+    if (c->n > 0 && T.n > 0 && !sweep_store) {
         A.X = PosIndex{}; A.colstore = nullptr; A.p_lo = 0; A.p_hi = 0;
         const int64_t per = ((int64_t)blocks_for(maxspan, 256) + 7) / 8;          // tiles of a chunk per XCD class: see the tile mapping
-        hipLaunchKernelGGL(k_norm_tile, dim3(8u * (unsigned)std::min<int64_t>(NT_Q, per), (unsigned)T.n), dim3(256), 0, st, A, D,
-                           c->d_callable.as<uint32_t>(), c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per);
+        const dim3 grid(8u * (unsigned)std::min<int64_t>(NT_Q, per), (unsigned)T.n);
+        if (sweep_col) {
+            if (phase) hipLaunchKernelGGL(k_norm_col<true>, grid, dim3(256), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
+                                          c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per);
+            else hipLaunchKernelGGL(k_norm_col<false>, grid, dim3(256), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
+                                    c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per);
+        }
+        // (behind k_norm_col it runs only for a contig with a base quality of 128 or more, which that kernel leaves alone)
+        hipLaunchKernelGGL(k_norm_tile, grid, dim3(256), 0, st, A, D, c->d_callable.as<uint32_t>(), c->d_winlo.as<int32_t>(),
+                           c->d_winhi.as<int32_t>(), nblk, per, sweep_col ? &sc->qhigh : (const int*)nullptr);
     } else if (c->n > 0 && T.n > 0) {
         for (int64_t p_lo = 0; p_lo < (int64_t)maxend; p_lo += NORM_PASS) {
             const int64_t p_hi = std::min<int64_t>(p_lo + NORM_PASS, maxend);

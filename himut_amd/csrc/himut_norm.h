@@ -83,14 +83,32 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
 // A substitution always counts (its three tests are evaluated and ignored, :97-109).
 constexpr int CAL_NM = 256;   // mismatch entries kept in LDS per wave
 
-__global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, const uint8_t* live, uint32_t* cbits) {
+// With `cq` the kernel also writes, for every base of every read, quality | callable << 7 -- what k_norm_col reads
+// instead of the quality array and the bit array (the bases of a read that fails the filters keep their qualities: they
+// are piled, not counted) -- and raises *qhigh when a quality does not leave that bit free.
+__global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, const uint8_t* live, uint32_t* cbits,
+                                                  uint8_t* cq, int* qhigh) {
     __shared__ int32_t s_mis[4][CAL_NM];
     __shared__ uint32_t s_mq[4][CAL_NM];
     __shared__ __align__(16) int4 s_seg[4][64];
     const int lane = threadIdx.x & 63, wv = uni((int)(threadIdx.x >> 6));
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
-    if (!uni((int)live[r])) return;
+    if (!uni((int)live[r])) {
+        if (cq) {                                             // qualities as they are (a read's bases start at a multiple of 32)
+            const int64_t qo = uni(R.qoff[r]);
+            const int32_t qlen = uni(R.qlen[r]);
+            uint32_t hb = 0;
+            for (int32_t o = lane * 32; o < qlen; o += 2048) {
+                const uint4 x0 = *reinterpret_cast<const uint4*>(R.bq + qo + o), x1 = *reinterpret_cast<const uint4*>(R.bq + qo + o + 16);
+                *reinterpret_cast<uint4*>(cq + qo + o) = x0;
+                *reinterpret_cast<uint4*>(cq + qo + o + 16) = x1;
+                hb |= x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w;
+            }
+            if (hb & 0x80808080u) atomicOr(qhigh, 1);
+        }
+        return;
+    }
     const ReadMeta Mv = D.meta[r];
     const int ns = uni(Mv.nseg);
     const int64_t segbase = uni(Mv.segbase), qo = uni(Mv.qoff);
@@ -260,6 +278,17 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                 }
             }
             cbits[((qo + qa) >> 5)] = word;
+            if (cq) {
+                uint32_t ow[8], hb = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {                 // bit j of a nibble of the word to bit 7 of byte j
+                    ow[k] = bw[k] | (((((word >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) << 7);
+                    hb |= bw[k];
+                }
+                *reinterpret_cast<uint4*>(cq + qo + qa) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                *reinterpret_cast<uint4*>(cq + qo + qa + 16) = make_uint4(ow[4], ow[5], ow[6], ow[7]);
+                if (hb & 0x80808080u) atomicOr(qhigh, 1);
+            }
         }
     }
 }
@@ -532,9 +561,13 @@ _Pragma("unroll") \
                 } \
             } \
         } \
+        NORM_TALLY(slot)
+
+// log counters and the trinucleotide bins of a classified position (SLOT: its row of norm.log)
+#define NORM_TALLY(SLOT) \
         atomicAdd(&s_log[1], tri_sum); \
-        atomicAdd(&s_log[slot], tri_sum); \
-        if (slot == 13) { \
+        atomicAdd(&s_log[(SLOT)], tri_sum); \
+        if ((SLOT) == 13) { \
             int t0 = 'N', t1 = 'N', t2 = 'N'; \
             if (rpos - 1 >= 0 && rpos + 2 <= A.reflen) { \
                 t0 = A.refseq[rpos - 1]; t1 = refc; t2 = A.refseq[rpos + 1]; \
@@ -636,7 +669,7 @@ constexpr int NT_ROWS = 48;
 constexpr int NT_RPW = NT_ROWS / 4;    // rows per wave and batch
 
 __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, Derived D, const uint32_t* callable, const int32_t* winlo,
-                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class) {
+                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class, const int* only_if) {
     __shared__ double s_lut[3 * 257];         // three tables of 256 qualities + a zero entry each (index 256)
     __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
@@ -644,6 +677,7 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
     __shared__ __align__(16) uint16_t s_cells[NT_ROWS][256];
     __shared__ int32_t s_tend[NT_ROWS];
     __shared__ uint32_t s_hap[NT_ROWS];
+    if (only_if && !*only_if) return;        // (launched behind k_norm_col: for the contig that kernel left alone)
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     for (int i = tid; i < 3 * 256; i += 256) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 255];
     if (tid < 3) s_lut[tid * 257 + 256] = 0.0;
@@ -843,6 +877,266 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
         atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
         atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
     }
+    if (bad) atomicOr(A.err, bad);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_norm_col: the sweep with no cells in LDS.  A wave owns 64 consecutive positions -- a lane is a column from the first
+// row to the last -- and the four waves of a workgroup take the four quarters of k_norm_tile's 256-position tile (same
+// launch geometry, same neighbours in an XCD's L2).  The rows of the quarter are prepared 64 at a time with a LANE per
+// ROW (read header, the segment that reaches the quarter by binary search, whether that one gapless segment spans all
+// 64 positions -- 97 rows in 100 -- and then where the row's first base lies, as a 32-bit distance from the batch's
+// first read); the wave goes through the live rows in read order (the set bits of a ballot: a read of the window index
+// that does not reach the quarter costs nothing).  A spanning row is 64 consecutive query bases from K on: one byte
+// load at a scalar base brings quality | callable << 7 (`cq`, written by k_callable: the callable bit travels with the
+// quality), one 16-bit load the packed bases -- no address arithmetic in a lane, no LDS round trip, no barrier; the
+// reference allele's three sums and two counters are a dozen vector instructions per row.  While HIMUT_NC_NB spanning
+// rows follow each other they are taken together, their loads issued before the first is used.  Everything else -- a
+// row with an indel or a read end inside the quarter, another allele -- takes the general update lane by lane, in its
+// place in the read order.  The sums of the other three alleles, touched by one row in twenty, live in LDS (a column's
+// nine doubles), not in registers.  The scalar unit and the vector units of a CU each get one instruction through per
+// cycle, and this loop is bound by their sum: what is the same for a whole row sits in a lane of a row vector and comes
+// back with one v_readlane, the counts that do not depend on the order (insertions in front of a spanning segment,
+// haplotype votes of spanning rows) are taken per 64 rows with a popcount.  Qualities of 128 and more do not fit beside
+// the callable bit: k_callable raises a flag and k_norm_tile does the contig (each of the two kernels looks at the flag
+// first).  Same counts as k_norm_tile (HIMUT_NORM_SWEEP=tile takes that one).
+#ifndef HIMUT_NC_WAVES
+#define HIMUT_NC_WAVES 5
+#endif
+#ifndef HIMUT_NC_NB
+#define HIMUT_NC_NB 4
+#endif
+
+typedef const __attribute__((address_space(1))) uint8_t* nc_gptr8;
+
+// one base of another allele than the reference's (cell 0..3): its three sums and its count in LDS.  A column has three
+// such alleles: allele c sits in slot c - (c > ref).  (Where the reference base is not one of ATGC the position is never
+// classified and the slots may mix.)
+#define NC_ALT(CELL, Q) \
+            { \
+                const uint32_t c_ = (CELL), qa_ = (Q); \
+                const uint32_t a_ = min(c_ - ((int)c_ > ref ? 1u : 0u), 2u); \
+                s_S[a_][tid] = s_S[a_][tid] + s_lut[qa_]; \
+                s_S[3 + a_][tid] = s_S[3 + a_][tid] + s_lut[257 + qa_]; \
+                s_S[6 + a_][tid] = s_S[6 + a_][tid] + s_lut[514 + qa_]; \
+                s_cnt[c_][tid] = s_cnt[c_][tid] + 1u; \
+            }
+
+// the loads of spanning row L (a scalar) into slot k: the row's first base is base K = Kb + d, d from the row vector
+#define NC_ROW_LOADS(L, k) \
+            { \
+                const uint32_t d_ = (uint32_t)lane_val(dqv, (L)); \
+                const uint32_t e_ = d_ + kb_par; \
+                kpar[k] = e_ & 1u; \
+                if (PHASE) hnone[k] = (m_hnone >> (L)) & 1; \
+                qv[k] = reinterpret_cast<nc_gptr8>(pqb + d_)[o1]; \
+                sv[k] = *reinterpret_cast<const __attribute__((address_space(1), aligned(1))) uint16_t*>(reinterpret_cast<nc_gptr8>(psb + (e_ >> 1)) + o2); \
+            }
+
+// the update of slot k: every lane holds a base of the row (a base outside ATGC ends the run with an error, a zero
+// quality ends it at the classification: what they add meanwhile does not matter)
+#define NC_ROW_UPDATE(k) \
+            { \
+                const uint32_t nib_ = (sv[k] >> (kpar[k] ? sh_odd : sh_even)) & 15u; \
+                const uint32_t cq_ = qv[k]; \
+                qmin = min(qmin, cq_ & 127u); \
+                uint32_t cb_ = cq_ >> 7; \
+                if (PHASE && hnone[k]) cb_ = 0;                          /* the read carries no haplotype in this chunk */ \
+                tri_sum += cb_; \
+                if (nib_ == refnib) { \
+                    nref++; \
+                    R0 = R0 + s_lut[cq_]; R1 = R1 + s_lut[257 + cq_]; R2 = R2 + s_lut[514 + cq_]; \
+                } else if (valid) {                                      /* rare: another allele, or a base outside ATGC */ \
+                    const uint32_t cell_ = (uint32_t)nib2allele((int)nib_); \
+                    if (cell_ > 3) s_bad = 1 << HIMUT_ERR_BASE; \
+                    else if ((cq_ & 127u) != 0) NC_ALT(cell_, cq_) \
+                } \
+            }
+
+template <bool PHASE>
+__global__ void __launch_bounds__(256, HIMUT_NC_WAVES) k_norm_col(NormArgs A, Derived D, const uint8_t* __restrict__ cq,
+                                                                   const int* __restrict__ qhigh, const int32_t* winlo,
+                                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class) {
+    __shared__ double s_lut[3 * 257];         // three tables indexed by quality | callable << 7 (the upper half repeats the lower) + a zero entry each
+    __shared__ double s_prior[4];
+    __shared__ unsigned int s_log[16];
+    __shared__ unsigned int s_ccs[32], s_ref[32];
+    __shared__ double s_S[9][256];            // [table * 3 + slot][column]: the sums of the three alleles that are not the reference's
+    __shared__ uint32_t s_cnt[4][256];        // [allele][column]: their counts
+    __shared__ int s_bad;                     // a base outside ATGC was seen (the reference raises KeyError)
+    if (*qhigh) return;                       // a quality of 128 or more somewhere: k_norm_tile does this contig
+    const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
+    for (int i = tid; i < 3 * 256; i += 256) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 127];
+    if (tid < 3) s_lut[tid * 257 + 256] = 0.0;
+    if (tid < 4) s_prior[tid] = A.lut->prior[tid];
+    if (tid < 16) s_log[tid] = 0;
+    if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    const int chunk = blockIdx.y;
+    const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
+    constexpr bool phase = PHASE;
+    const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
+    const Reads& R = A.R;
+    int bad = 0;
+    // base K + lane of a spanning row: the 16-bit load at byte (K >> 1) + (lane >> 1) holds it at one of two shifts
+    const uint32_t hoff = (uint32_t)lane >> 1;
+    const uint32_t sh_even = (lane & 1) ? 0u : 4u, sh_odd = (lane & 1) ? 12u : 0u;       // K even / K odd
+    constexpr int NB = HIMUT_NC_NB;
+    const int64_t per = tiles_per_class;
+    for (int64_t t = blockIdx.x >> 3; t < per; t += (int64_t)(gridDim.x >> 3)) {         // the tile mapping of k_norm_tile
+        const int64_t tile = (int64_t)(blockIdx.x & 7) * per + t;
+        const int64_t base = (int64_t)cs_ + tile * 256 + 64 * wv;                         // this wave's quarter
+        if (base >= ce_) break;                                   // (the later tiles of this workgroup lie further on)
+        const int64_t rpos = base + lane;
+        bool valid = rpos < ce_;
+        if (valid && (rpos < 0 || rpos >= A.reflen)) { bad |= 1 << HIMUT_ERR_ARG; valid = false; }   // IndexError in the reference
+        const int refc = valid ? (int)A.refseq[rpos] : 'N';
+        const int ref = char2allele(refc);
+        const uint32_t refnib = ref == 0 ? 1u : ref == 3 ? 2u : ref == 2 ? 4u : ref == 1 ? 8u : 0xffu;   // the BAM code of the reference base
+        uint32_t n_ins = 0, n_del = 0;
+        double R0 = 0.0, R1 = 0.0, R2 = 0.0;
+        uint32_t nref = 0, tri_sum = 0, h0 = 0, h1 = 0, qmin = 255;
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_S[k][tid] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_cnt[k][tid] = 0;
+        const int64_t b0 = min(max(base, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min((base + 63) >> WIN_SHIFT, nblk - 1);
+        const int32_t lo = uni(winlo[b0]), hi = uni(winhi[b1]);
+        const int32_t P = (int32_t)base + lane;
+        for (int32_t r0 = lo; r0 < hi; r0 += 64) {
+            // ---- a lane per row: header, the last segment that starts at or before the quarter, the spanning test
+            const int nb = min(64, hi - r0);
+            ReadMeta M;
+            M.tstart = 0; M.tend = 0; M.nseg = 0; M.flags = RF_SECONDARY; M.segbase = 0; M.qoff = 0;
+            if (lane < nb) M = D.meta[r0 + lane];
+            const bool live_row = lane < nb && !(M.flags & RF_SECONDARY) && M.nseg > 0 && M.tstart < base + 64 && M.tend >= base;
+            int j0 = 0;
+            int4 sg0 = make_int4(0x7fffffff, 0, 0, 0);
+            if (live_row) {
+                int a = 0, e = M.nseg;
+                while (a < e) { const int m = (a + e) >> 1; if (D.segs[M.segbase + m].t0 <= (int32_t)base) a = m + 1; else e = m; }
+                j0 = max(a - 1, 0);
+                sg0 = *reinterpret_cast<const int4*>(D.segs + M.segbase + j0);
+            }
+            // the bases of a batch's reads lie side by side in the arrays: a row's first base as a distance from the first
+            // read's first base (a row further away than 2^31, which does not happen, takes the general path)
+            const int64_t Kb = ((int64_t)lane_val((int)(M.qoff >> 32), 0) << 32) | (uint32_t)lane_val((int)M.qoff, 0);
+            const int64_t K0 = M.qoff + sg0.y + ((int32_t)base - sg0.x);
+            const int64_t dK = K0 - Kb;
+            const bool whole = live_row && !((uint32_t)sg0.w & SEG_DEL) && sg0.x <= (int32_t)base && (int64_t)sg0.x + sg0.z >= base + 64 &&
+                               dK >= 0 && dK < ((int64_t)1 << 31);
+            const int dqv = whole ? (int)dK : 0;
+            const uint64_t pqb = (uint64_t)cq + (uint64_t)Kb, psb = (uint64_t)R.seq + (uint64_t)(Kb >> 1);
+            const uint32_t kb_par = (uint32_t)Kb & 1u;
+            uint32_t hp = HAP_NONE;
+            if (phase && live_row && M.tstart < ce_ && M.tend > cs_) hp = A.H.hap[pairbase + r0 + lane];   // fetched by the chunk
+            const uint64_t m_live = __ballot(live_row), m_whole = __ballot(whole);
+            const uint64_t m_slow = m_live & ~m_whole;
+            const uint64_t m_hnone = phase ? __ballot(hp != HAP_0 && hp != HAP_1) : 0;
+            // counts that do not depend on the order: an insertion in front of a spanning segment that starts with the
+            // quarter is counted at its first position; every lane of a spanning row is a base of its haplotype
+            const uint64_t m_ins0 = __ballot(whole && sg0.x == (int32_t)base && ((uint32_t)sg0.w & SEG_INS));
+            if (lane == 0) n_ins += (uint32_t)__builtin_popcountll(m_ins0);
+            if (phase) {
+                h0 += (uint32_t)__builtin_popcountll(__ballot(whole && hp == HAP_0));
+                h1 += (uint32_t)__builtin_popcountll(__ballot(whole && hp == HAP_1));
+            }
+            // ---- the live rows in read order
+            uint64_t m = m_live;
+            while (m) {
+                uint32_t qv[NB], sv[NB], kpar[NB];
+                bool hnone[NB];
+                // do NB spanning rows follow each other?  (live rows in front of the next row of the other kind)
+                const uint64_t ms = m & m_slow;
+                const uint64_t front = ms ? (m & ((ms & (0 - ms)) - 1)) : m;
+                uint32_t o1 = (uint32_t)lane, o2 = hoff;          // (redefined here so that the loads below take a scalar base + this offset)
+                asm volatile("" : "+v"(o1), "+v"(o2));
+                if (__builtin_popcountll(front) >= NB) {
+#pragma unroll
+                    for (int k = 0; k < NB; k++) {
+                        const int l = (int)__builtin_ctzll(m);
+                        m &= m - 1;
+                        NC_ROW_LOADS(l, k)
+                    }
+#pragma unroll
+                    for (int k = 0; k < NB; k++) NC_ROW_UPDATE(k)
+                    continue;
+                }
+                const int l0 = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                if ((m_whole >> l0) & 1) {                               // a spanning row by itself
+                    NC_ROW_LOADS(l0, 0)
+                    NC_ROW_UPDATE(0)
+                    continue;
+                }
+                // ---- the general row: every lane finds its position in the segments from the cursor on
+                {
+                    const ReadMeta Ms = D.meta[r0 + l0];
+                    const int ns = uni(Ms.nseg), jf = lane_val(j0, l0);
+                    const int64_t segbase = uni(Ms.segbase), qoff = uni(Ms.qoff);
+                    const int32_t tend_r = uni(Ms.tend);
+                    uint32_t hps = HAP_NONE;
+                    if (phase) hps = (uint32_t)lane_val((int)hp, l0);
+                    uint32_t v = CELL_EMPTY;
+                    for (int j = jf; j < ns; j++) {
+                        const Seg g = D.segs[segbase + j];
+                        const int32_t t0 = uni(g.t0), q0 = uni(g.q0), len = uni(g.len);
+                        const uint32_t fl = uni(g.flags);
+                        if (t0 >= base + 64) break;
+                        const int32_t span = len > 0 ? len : ((fl & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
+                        if (P >= t0 && P < t0 + span) {
+                            const uint32_t insb = (P == t0 && (fl & SEG_INS)) ? (uint32_t)CELL_INS : 0u;
+                            if (fl & SEG_DEL) v = CELL_DEL | insb;
+                            else if (len == 0) v = CELL_EMPTY | CELL_INS;
+                            else {
+                                const int64_t K = qoff + q0 + (P - t0);
+                                v = (uint32_t)nib2allele(nib_at(R.seq, K)) | ((uint32_t)cq[K] << 8) | insb;    // bits 8..14 quality, bit 15 callable
+                            }
+                        }
+                    }
+                    // an EMPTY cell, or a read this chunk did not fetch (normcounts.py:289), adds nothing
+                    if (valid && (v & 15u) != CELL_EMPTY && !(rpos <= cs_ && !(tend_r > cs_))) {
+                        const uint32_t c = v & 7u, q7 = v >> 8;
+                        if (v & CELL_INS) n_ins++;
+                        if (c < 4) {
+                            qmin = min(qmin, q7 & 127u);
+                            if ((int)c == ref) { nref++; R0 = R0 + s_lut[q7]; R1 = R1 + s_lut[257 + q7]; R2 = R2 + s_lut[514 + q7]; }
+                            else NC_ALT(c, q7)
+                            uint32_t counts_here = q7 >> 7;
+                            if (phase) {
+                                h0 += hps == HAP_0 ? 1u : 0u; h1 += hps == HAP_1 ? 1u : 0u;
+                                if (hps != HAP_0 && hps != HAP_1) counts_here = 0;
+                            }
+                            tri_sum += counts_here;
+                        } else if (c == CELL_DEL) n_del++;
+                        else if (c == CELL_OTHER) s_bad = 1 << HIMUT_ERR_BASE;
+                    }
+                }
+            }
+        }
+        if (!valid) continue;
+        const bool bq0 = qmin == 0;
+        uint32_t cnt[6];
+        double S[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int a = max(min(b - (b > ref ? 1 : 0), 2), 0);     // (the reference allele's own entries are replaced below)
+            cnt[b] = s_cnt[b][tid];
+            S[0][b] = s_S[a][tid]; S[1][b] = s_S[3 + a][tid]; S[2][b] = s_S[6 + a][tid];
+        }
+        cnt[4] = n_ins; cnt[5] = n_del;
+        NORM_CLASSIFY()
+    }
+    __syncthreads();
+    if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
+    if (tid < 32 && (s_ccs[tid] || s_ref[tid])) {
+        const int cl[4] = {A.cA, A.cC, A.cG, A.cT};
+        const int64_t k = ((int64_t)cl[tid >> 3] * A.K + ((tid & 4) ? A.cT : A.cC)) * A.K + cl[tid & 3];
+        atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
+        atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
+    }
+    if (tid == 0 && s_bad) bad |= s_bad;
     if (bad) atomicOr(A.err, bad);
 }
 

@@ -14,7 +14,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmcab_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"].split("(")[0].replace("void ","")
-        if "k_norm_tile" in k or "k_callable" in k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "k_norm_" in k or "k_callable" in k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in acc.items():
     print(k+" "+" ".join("%s=%.4g"%(c,sum(x)/len(x)) for c,x in sorted(v.items())))
 PY
