@@ -23,7 +23,7 @@ def avg(d, counter):
 f, w = avg("$out/${tag}_norm_fetch", "FETCH_SIZE"), avg("$out/${tag}_norm_write", "WRITE_SIZE")
 doc = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/bench_normcounts.py, chr20-sized 30x contig; KiB per launch as counted. "
                "FETCH_SIZE reports half of the bytes of wide coalesced streaming reads on gfx950 (MI355X_MICROARCH.md): doubled for k_parse_cs and k_callable "
-               "(16-byte streaming loads), not for k_norm_tile (4-byte unaligned loads)",
+               "(16-byte streaming loads), not for k_norm_col (1- and 2-byte loads per lane: uncalibrated width, counted as is) or k_norm_tile (4-byte unaligned loads)",
        "collected": "profiles/collect_normcounts.sh $tag", "raw_kib_per_launch": {k: {"FETCH_SIZE": f.get(k, 0.0), "WRITE_SIZE": w.get(k, 0.0)} for k in sorted(set(f) | set(w))}}
 for k in sorted(set(f) | set(w)):
     doc[k] = int(f.get(k, 0.0) * 1024 * (2.0 if k in ("k_parse_cs", "k_callable") else 1.0) + w.get(k, 0.0) * 1024)
