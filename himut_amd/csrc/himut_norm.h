@@ -168,11 +168,22 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
         if (qa < qlen) {
             // qualities of the lane's 32 bases
             const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            uint32_t okq = 0;    // quality and trim tests per base, four bytes at a time (qualities are < 128)
+            uint32_t okq = 0;    // quality and trim tests per base, four bytes at a time: the low seven bits compared, bit 7 by itself
+            const uint32_t hb = (bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) & 0x80808080u;   // a quality of 128 or more among them
+            if (min_bq <= 127 && !hb) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) okq |= cs_pack4(cs_ge_bytes(bw[k], (uint32_t)min_bq_c) & ~(bw[k] & 0x80808080u)) << (4 * k);
+                for (int k = 0; k < 8; k++) okq |= cs_pack4(cs_ge_bytes(bw[k], (uint32_t)min_bq_c)) << (4 * k);
+            } else if (min_bq <= 127) {
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    okq |= cs_pack4(cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)min_bq_c) | (bw[k] & 0x80808080u)) << (4 * k);
+            } else if (min_bq <= 255) {                           // (a threshold above 127: only a quality of 128 or more can pass)
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    okq |= cs_pack4((min_bq > 128 ? cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)(min_bq - 128)) : 0x80808080u) &
+                                    (bw[k] & 0x80808080u)) << (4 * k);
+            }
             if (min_bq <= 0) okq = ~0u;
-            if (min_bq > 127) okq = 0;
             {
                 // not trimmed: trim_lo <= q <= trim_hi (the two bounds are whole numbers), and q < qlen
                 const int32_t lo_q = max(trim_lo, 0), hi_q = min(trim_hi, qlen - 1);
@@ -279,15 +290,13 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
             }
             cbits[((qo + qa) >> 5)] = word;
             if (cq) {
-                uint32_t ow[8], hb = 0;
+                uint32_t ow[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {                 // bit j of a nibble of the word to bit 7 of byte j
+                for (int k = 0; k < 8; k++)                   // bit j of a nibble of the word to bit 7 of byte j
                     ow[k] = bw[k] | (((((word >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) << 7);
-                    hb |= bw[k];
-                }
                 *reinterpret_cast<uint4*>(cq + qo + qa) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                 *reinterpret_cast<uint4*>(cq + qo + qa + 16) = make_uint4(ow[4], ow[5], ow[6], ow[7]);
-                if (hb & 0x80808080u) atomicOr(qhigh, 1);
+                if (hb) atomicOr(qhigh, 1);
             }
         }
     }

@@ -93,6 +93,51 @@ def test_normcounts_oracle_parity(worker, seed, length, chunks):
     assert log[13] > 0 and log[11] + log[12] > 0
 
 
+@pytest.mark.parametrize("case", ["norm_dense", "norm_phase", "norm_nsub"])
+def test_normcounts_golden_tile_sweep(worker, case, monkeypatch):
+    """k_norm_tile (cells built in LDS by the workgroup, HIMUT_NORM_SWEEP=tile) stays in the library: it does the
+    contigs k_norm_col leaves alone.  The same golden vectors."""
+    from himut_amd import normcounts
+    monkeypatch.setenv("HIMUT_NORM_SWEEP", "tile")
+    batch, exp, p, refseq, pon, com = load_norm_case(case)
+    _configure(worker, p, util.phase_of(exp) is not None)
+    ccs, rf, log = normcounts.norm_contig(worker, batch, util.chunks_of(exp), refseq, pon, com,
+                                          exp["non_human_sample"], exp["alt_order"], phase_sets=util.phase_of(exp))
+    assert log == exp["log"]
+    assert ccs == {k: int(v) for k, v in exp["ccs_tri2count"].items()}
+    assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
+
+
+def test_normcounts_qualities_of_128_and_more(worker):
+    """k_norm_col reads quality | callable << 7 from one byte; a contig with a quality that does not leave the bit free
+    is done by k_norm_tile (k_callable raises a flag, each kernel looks at it first).  Qualities up to 255 in passing
+    and in failing reads, against the oracle (its tables have 256 entries like the reference's); then the same context
+    takes an ordinary contig again."""
+    from oracle import oracle as O
+    from himut_amd import normcounts, synth, util as hutil
+    from himut_amd.readbatch import ReadBatch
+    s = synth.generate(synth.SynthConfig(seed=35, contig_len=150_000, name="chrQ"), want_ref=True)
+    b = s.batch
+    refseq = bytes(s.ref)
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((b.name, 0, b.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=9000, qlen_upper_limit=22500, md_threshold=52)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+    rs = np.random.RandomState(35)
+    bq = b.bq.copy()
+    for r in rs.choice(len(b.qlen), 40, replace=False):          # a few bases each of forty reads
+        o = int(b.qoff[r]) + rs.randint(0, int(b.qlen[r]), 25)
+        bq[o] = rs.randint(128, 256, 25)
+    hi = ReadBatch(name=b.name, length=b.length, tstart=b.tstart, tend=b.tend, qstart=b.qstart, qlen=b.qlen, mapq=b.mapq,
+                   flag=b.flag, qid=b.qid, qoff=b.qoff, cs_off=b.cs_off, seq=b.seq, bq=bq, cs=b.cs, tp=b.tp)
+    _configure(worker, p)
+    for batch in (hi, b, hi):
+        o_ccs, o_ref, o_log = O.normcounts(batch, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+        ccs, rf, log = normcounts.norm_contig(worker, batch, chunks, refseq, alt_order=order)
+        assert log == o_log and ccs == o_ccs and rf == o_ref
+        assert log[13] > 0
+
+
 def test_normcounts_phase_oracle_parity(worker, tmp_path):
     """--phase: chunks are the phase-set spans, reads need haplotype 0/1 there, positions need both haplotypes."""
     from oracle import oracle as O
