@@ -138,6 +138,31 @@ def test_normcounts_qualities_of_128_and_more(worker):
         assert log[13] > 0
 
 
+@pytest.mark.parametrize("seed,depth,extra", [
+    (41, 150.0, {}),                                          # more than 64 rows over a quarter: several row batches
+    (42, 40.0, dict(ins_rate=4e-3, del_rate=4e-3, sub_rate=5e-3, frac_softclip=0.5, softclip_max=300)),   # few spanning rows
+    (43, 90.0, dict(pile_frac=0.05, pile_mult=8.0, read_len_mean=3000.0, read_len_sd=800.0, read_len_min=600,
+                    read_len_max=6000)),                      # short reads, piles several hundred deep
+])
+def test_normcounts_deep_and_ragged_piles_oracle_parity(worker, seed, depth, extra):
+    """k_norm_col's row batches (64 reads of the window index at a time) and its general rows (an indel or a read end
+    inside a 64-position quarter) against the oracle where they are the rule, not the exception."""
+    from oracle import oracle as O
+    from himut_amd import normcounts, synth, util as hutil
+    s = synth.generate(synth.SynthConfig(seed=seed, contig_len=60_000, depth=depth, name="chrD", **extra), want_ref=True)
+    refseq = bytes(s.ref)
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((s.batch.name, 0, s.batch.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=500, qlen_upper_limit=30000, md_threshold=1000, min_sequence_identity=0.9)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+    o_ccs, o_ref, o_log = O.normcounts(s.batch, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+    _configure(worker, p)
+    ccs, rf, log = normcounts.norm_contig(worker, s.batch, chunks, refseq, alt_order=order)
+    assert log == o_log
+    assert ccs == o_ccs and rf == o_ref
+    assert log[1] > 0
+
+
 def test_normcounts_phase_oracle_parity(worker, tmp_path):
     """--phase: chunks are the phase-set spans, reads need haplotype 0/1 there, positions need both haplotypes."""
     from oracle import oracle as O
