@@ -124,7 +124,7 @@ struct himut_ctx {
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2, d_logpart;
     // normcounts
-    DevBuf d_refseq, d_live, d_callable, d_cq, d_tri;
+    DevBuf d_refseq, d_live, d_callable, d_cq, d_dirty, d_dcount, d_tri;
     int64_t reflen = 0;
     uint8_t ref_cls[256] = {};
     int ref_K = 0;
@@ -169,7 +169,8 @@ struct Scalars {
     unsigned long long log[16];
     int err;
     int qhigh;               // normcounts: a base quality of 128 or more was seen (k_callable)
-    int pad[22];             // 256 bytes: one aligned fill clears it
+    int dirty_over;          // normcounts: k_norm_col left more positions to k_norm_dirty than a part of the list holds
+    int pad[21];             // 256 bytes: one aligned fill clears it
 };
 static_assert(sizeof(Scalars) == 256, "Scalars is cleared with one aligned fill");
 
@@ -1269,7 +1270,7 @@ int himut_copy_records_to_device(himut_ctx* c, void* dst, int64_t capacity_recor
 
 namespace {
 
-int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
+int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool force_tile = false) {
     if (!c->have_params) return fail(c, HIMUT_ERR_ARG, "himut_set_params has not been called");
     if (!c->have_lut) return fail(c, HIMUT_ERR_ARG, "himut_set_gt_lut has not been called");
     if (!c->have_reads) return fail(c, HIMUT_ERR_ARG, "himut_push_reads has not been called");
@@ -1305,15 +1306,25 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     // HIMUT_NORM_SWEEP: "tile" = cells built in LDS by the workgroup (round 2's kernel), "store" = the older sweep through a
     // column store in HBM (capture + evaluate, in passes); otherwise a wave per 64 columns, no cells in LDS
     const char* sweep = getenv("HIMUT_NORM_SWEEP");
-    const bool sweep_store = sweep && strcmp(sweep, "store") == 0, sweep_tile = sweep && strcmp(sweep, "tile") == 0;
+    const bool sweep_store = !force_tile && sweep && strcmp(sweep, "store") == 0;
+    const bool sweep_tile = force_tile || (sweep && strcmp(sweep, "tile") == 0);
     const bool sweep_col = !sweep_store && !sweep_tile;
-    if (sweep_col) c->d_cq.reserve((size_t)c->bq_bytes + 256);       // quality | callable << 7 per base
+    // the positions k_norm_col leaves to k_norm_dirty (a column with another allele: one in thirty): room for one in eight,
+    // in NORM_DIRTY_REGIONS parts that the workgroups are dealt over
+    int64_t dirty_cap = std::max<int64_t>(T.positions / 8 / NORM_DIRTY_REGIONS, 256);
+    if (const char* e = getenv("HIMUT_NORM_DIRTY_CAP")) dirty_cap = std::max<int64_t>(atoll(e), 1);   // (tests: the overflow path)
+    if (sweep_col) {
+        c->d_cq.reserve((size_t)c->bq_bytes + 256);                  // quality | callable << 7 per base
+        c->d_dirty.reserve((size_t)dirty_cap * NORM_DIRTY_REGIONS * sizeof(NormDirty) + 256);
+        c->d_dcount.reserve((size_t)NORM_DIRTY_REGIONS * 128);
+    }
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
     HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
     HCHECK(hipMemsetAsync(c->d_tri.p, 0, (2 * ntri + 16) * 8, st));
     HCHECK(hipMemsetAsync(c->d_callable.p, 0, cwords * 4, st));
+    if (sweep_col) HCHECK(hipMemsetAsync(c->d_dcount.p, 0, (size_t)NORM_DIRTY_REGIONS * 128, st));
     if (sweep_col && getenv("HIMUT_DEBUG_FILL_CQ")) HCHECK(hipMemsetAsync(c->d_cq.p, 0, (size_t)c->bq_bytes + 256, st));   // (a base whose byte k_callable did not write shows as a zero quality)
     if (c->n > 0) run_parse_stage(c, R, D, sc);
     else stage_event(c, EV_PARSE, 2, st);
@@ -1376,9 +1387,13 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
         const dim3 grid(8u * (unsigned)std::min<int64_t>(NT_Q, per), (unsigned)T.n);
         if (sweep_col) {
             if (phase) hipLaunchKernelGGL(k_norm_col<true>, grid, dim3(256), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
-                                          c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per);
+                                          c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per, c->d_dirty.as<NormDirty>(),
+                                          c->d_dcount.as<unsigned long long>(), dirty_cap, &sc->dirty_over);
             else hipLaunchKernelGGL(k_norm_col<false>, grid, dim3(256), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
-                                    c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per);
+                                    c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per, c->d_dirty.as<NormDirty>(),
+                                    c->d_dcount.as<unsigned long long>(), dirty_cap, &sc->dirty_over);
+            hipLaunchKernelGGL(k_norm_dirty, dim3(8, NORM_DIRTY_REGIONS), dim3(256), 0, st, A, c->d_dirty.as<NormDirty>(),
+                               c->d_dcount.as<unsigned long long>(), dirty_cap);
         }
         // (behind k_norm_col it runs only for a contig with a base quality of 128 or more, which that kernel leaves alone)
         hipLaunchKernelGGL(k_norm_tile, grid, dim3(256), 0, st, A, D, c->d_callable.as<uint32_t>(), c->d_winlo.as<int32_t>(),
@@ -1441,6 +1456,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human) {
     HCHECK(hipMemcpyAsync(c->h_tri.data(), c->d_tri.p, (2 * ntri + 16) * 8, hipMemcpyDeviceToHost, st));
     HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
     HCHECK(hipStreamSynchronize(st));
+    if (hs.dirty_over && !force_tile) return do_normcounts(c, alt_order, non_human, true);   // (the list of left-over positions was too short)
     if (hs.err) return check_device_err(c, hs.err);
     c->h_tri[2 * ntri + 0] = hs.nccs;
     float f = 0;

@@ -577,6 +577,11 @@ _Pragma("unroll") \
         atomicAdd(&s_log[1], tri_sum); \
         atomicAdd(&s_log[(SLOT)], tri_sum); \
         if ((SLOT) == 13) { \
+            NORM_TRIBINS() \
+        }
+
+// the trinucleotide bins of a callable position (row 13 of norm.log)
+#define NORM_TRIBINS() \
             int t0 = 'N', t1 = 'N', t2 = 'N'; \
             if (rpos - 1 >= 0 && rpos + 2 <= A.reflen) { \
                 t0 = A.refseq[rpos - 1]; t1 = refc; t2 = A.refseq[rpos + 1]; \
@@ -597,8 +602,7 @@ _Pragma("unroll") \
                 const int64_t k = ((int64_t)A.cls[t0] * A.K + A.cls[t1]) * A.K + A.cls[t2]; \
                 atomicAdd(&A.ccs_tri[k], (unsigned long long)tri_sum); \
                 atomicAdd(&A.ref_tri[k], 1ULL); \
-            } \
-        }
+            }
 
 constexpr int NE_TILES = 16;     // 256-position tiles per workgroup
 
@@ -890,6 +894,64 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
 }
 
 // ---------------------------------------------------------------------------------------
+// A position k_norm_col does not classify itself -- its column holds a base of another allele than the reference's, or
+// hom-ref is not the smallest of its genotype sums by itself: everything the column walk knows about it.  One position in
+// thirty; k_norm_dirty takes them a lane each, where inside k_norm_col the general classification would run for a lane or
+// two of a wave, every other wave, and set the kernel's registers.
+struct NormDirty {
+    int64_t rpos;
+    uint32_t nref, tri_sum, n_ins, n_del, h0, h1;
+    uint32_t cnt[4];          // bases of A, T, G, C that are not the reference allele's
+    double R[3];              // the reference allele's three sums
+    double S[9];              // [table * 3 + slot]: the other alleles', allele c in slot c - (c > ref)
+};
+
+constexpr int NORM_DIRTY_REGIONS = 256;   // the list in as many parts, each with a counter of its own (16 words apart) and room for `cap` entries
+
+__global__ void __launch_bounds__(256) k_norm_dirty(NormArgs A, const NormDirty* recs, const unsigned long long* dcount, int64_t cap) {
+    __shared__ double s_prior[4];
+    __shared__ unsigned int s_log[16];
+    __shared__ unsigned int s_ccs[32], s_ref[32];
+    const int tid = threadIdx.x;
+    if (tid < 4) s_prior[tid] = A.lut->prior[tid];
+    if (tid < 16) s_log[tid] = 0;
+    if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
+    __syncthreads();
+    const bool phase = A.P.p.phase != 0;
+    const int64_t n = min((int64_t)dcount[blockIdx.y * 16], cap);       // region blockIdx.y
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+        const NormDirty d = recs[(int64_t)blockIdx.y * cap + i];
+        const int64_t rpos = d.rpos;
+        const int refc = (int)A.refseq[rpos];
+        const int ref = char2allele(refc);
+        uint32_t cnt[6] = {d.cnt[0], d.cnt[1], d.cnt[2], d.cnt[3], d.n_ins, d.n_del};
+        double S[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int a = max(min(b - (b > ref ? 1 : 0), 2), 0);     // (the reference allele's own entries are replaced in the classification)
+            double v0 = d.S[0], v1 = d.S[3], v2 = d.S[6];
+            if (a == 1) { v0 = d.S[1]; v1 = d.S[4]; v2 = d.S[7]; }
+            if (a == 2) { v0 = d.S[2]; v1 = d.S[5]; v2 = d.S[8]; }
+            S[0][b] = v0; S[1][b] = v1; S[2][b] = v2;
+        }
+        double R0 = d.R[0], R1 = d.R[1], R2 = d.R[2];
+        uint32_t nref = d.nref, tri_sum = d.tri_sum, h0 = d.h0, h1 = d.h1;
+        const bool bq0 = false;                                       // (a zero quality ended the column in k_norm_col)
+        NORM_CLASSIFY()
+    }
+    __syncthreads();
+    if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
+    if (tid < 32 && (s_ccs[tid] || s_ref[tid])) {
+        const int cl[4] = {A.cA, A.cC, A.cG, A.cT};
+        const int64_t k = ((int64_t)cl[tid >> 3] * A.K + ((tid & 4) ? A.cT : A.cC)) * A.K + cl[tid & 3];
+        atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
+        atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
+    }
+    if (bad) atomicOr(A.err, bad);
+}
+
+// ---------------------------------------------------------------------------------------
 // k_norm_col: the sweep with no cells in LDS.  A wave owns 64 consecutive positions -- a lane is a column from the first
 // row to the last -- and the four waves of a workgroup take the four quarters of k_norm_tile's 256-position tile (same
 // launch geometry, same neighbours in an XCD's L2).  The rows of the quarter are prepared 64 at a time with a LANE per
@@ -965,7 +1027,9 @@ typedef const __attribute__((address_space(1))) uint8_t* nc_gptr8;
 template <bool PHASE>
 __global__ void __launch_bounds__(256, HIMUT_NC_WAVES) k_norm_col(NormArgs A, Derived D, const uint8_t* __restrict__ cq,
                                                                    const int* __restrict__ qhigh, const int32_t* winlo,
-                                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class) {
+                                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class,
+                                                                   NormDirty* dirty, unsigned long long* dcount, int64_t dirty_cap,
+                                                                   int* dirty_over) {
     __shared__ double s_lut[3 * 257];         // three tables indexed by quality | callable << 7 (the upper half repeats the lower) + a zero entry each
     __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
@@ -983,6 +1047,7 @@ __global__ void __launch_bounds__(256, HIMUT_NC_WAVES) k_norm_col(NormArgs A, De
     if (tid == 0) s_bad = 0;
     __syncthreads();
     const int chunk = blockIdx.y;
+    const int64_t dregion = (int64_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NORM_DIRTY_REGIONS - 1));   // this workgroup's part of the list
     const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
     constexpr bool phase = PHASE;
     const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
@@ -1124,18 +1189,62 @@ __global__ void __launch_bounds__(256, HIMUT_NC_WAVES) k_norm_col(NormArgs A, De
                 }
             }
         }
-        if (!valid) continue;
-        const bool bq0 = qmin == 0;
-        uint32_t cnt[6];
-        double S[3][4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int a = max(min(b - (b > ref ? 1 : 0), 2), 0);     // (the reference allele's own entries are replaced below)
-            cnt[b] = s_cnt[b][tid];
-            S[0][b] = s_S[a][tid]; S[1][b] = s_S[3 + a][tid]; S[2][b] = s_S[6 + a][tid];
+        // ---- the position's class (normcounts.py:317-402), in the order of the general text (NORM_CLASSIFY).  No lane leaves
+        //      early: the three counters nearly every position adds to are summed over the wave first -- 64 lanes adding
+        //      to one LDS word take their turns one by one, and that was two fifths of this kernel's time
+        const bool cls = valid && ref >= 0 && tri_sum != 0;
+        const bool hapfail = phase && cls && !((int64_t)h0 >= A.P.p.min_hap_count && (int64_t)h1 >= A.P.p.min_hap_count);
+        const bool q0 = cls && !hapfail && qmin == 0;
+        if (q0) bad |= 1 << HIMUT_ERR_BQ0;
+        const bool open = cls && !hapfail && !q0;
+        const uint32_t ca0 = s_cnt[0][tid], ca1 = s_cnt[1][tid], ca2 = s_cnt[2][tid], ca3 = s_cnt[3][tid];
+        // Nothing but the reference allele in the column (29 in 30): the ten genotype sums are four numbers -- an allele
+        // that was not seen adds +0.0 to a sum, which leaves it bit for bit what it was -- hom-ref's, the three
+        // genotypes' with one reference allele, the three of two different other alleles and the three of one other
+        // allele twice.  When hom-ref is the smallest by itself it is the genotype and the quality is the gap to the
+        // smallest of the rest; any other outcome, and any column with another allele, goes to k_norm_dirty.
+        const double pa = -10.0 * (R0 + s_prior[0]), pb = -10.0 * (R1 + s_prior[1]);
+        const double pc = -10.0 * (R2 + s_prior[2]), pd = -10.0 * (R2 + s_prior[3]);
+        const double nxt = fmin(pb, fmin(pc, pd));
+        const bool mine = open && (ca0 | ca1 | ca2 | ca3) == 0 && pa < nxt;
+        const double gqf = nxt - pa;
+        const int gq = (gqf < 99.0) ? (int)gqf : 99;
+        int slot = 13;
+        if (n_del != 0 || n_ins != 0) slot = 7;
+        else if ((int64_t)nref > A.P.p.md_threshold) slot = 8;
+        else if (gq < A.P.p.min_gq) slot = 10;
+        else if ((int64_t)nref < A.P.p.min_ref_count) slot = 9;
+        {
+            const uint32_t w1 = (uint32_t)lane_val(wave_incl_add((int)((mine || hapfail) ? tri_sum : 0u), lane), 63);
+            const uint32_t w6 = (uint32_t)lane_val(wave_incl_add((int)(mine ? tri_sum : 0u), lane), 63);
+            const uint32_t w13 = (uint32_t)lane_val(wave_incl_add((int)((mine && slot == 13) ? tri_sum : 0u), lane), 63);
+            uint32_t w2 = 0;
+            if (phase) w2 = (uint32_t)lane_val(wave_incl_add((int)(hapfail ? tri_sum : 0u), lane), 63);
+            if (lane == 0) {
+                if (w1) atomicAdd(&s_log[1], w1);
+                if (w2) atomicAdd(&s_log[2], w2);
+                if (w6) atomicAdd(&s_log[6], w6);
+                if (w13) atomicAdd(&s_log[13], w13);
+            }
         }
-        cnt[4] = n_ins; cnt[5] = n_del;
-        NORM_CLASSIFY()
+        if (mine && slot != 13) atomicAdd(&s_log[slot], tri_sum);
+        if (mine && slot == 13) {
+            NORM_TRIBINS()
+        }
+        if (open && !mine) {
+            // a place in the workgroup's region of the list: one atomic per wave, on one of NORM_DIRTY_REGIONS counters (a single
+            // counter takes about 300 additions a microsecond, and every other wave of this kernel has a position to leave)
+            const int64_t at = (int64_t)wave_reserve(dcount + dregion * 16);
+            if (at < dirty_cap) {
+                NormDirty d;
+                d.rpos = rpos; d.nref = nref; d.tri_sum = tri_sum; d.n_ins = n_ins; d.n_del = n_del; d.h0 = h0; d.h1 = h1;
+                d.cnt[0] = ca0; d.cnt[1] = ca1; d.cnt[2] = ca2; d.cnt[3] = ca3;
+                d.R[0] = R0; d.R[1] = R1; d.R[2] = R2;
+#pragma unroll
+                for (int k = 0; k < 9; k++) d.S[k] = s_S[k][tid];
+                dirty[dregion * dirty_cap + at] = d;
+            } else *dirty_over = 1;              // more of them than there is room for: the host repeats the contig with k_norm_tile
+        }
     }
     __syncthreads();
     if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);

@@ -108,6 +108,22 @@ def test_normcounts_golden_tile_sweep(worker, case, monkeypatch):
     assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
 
 
+@pytest.mark.parametrize("case", ["norm_dense", "norm_sets"])
+def test_normcounts_left_over_positions_do_not_fit(worker, case, monkeypatch):
+    """k_norm_col hands the positions it does not classify itself (a column with another allele) to k_norm_dirty through
+    a list sized for one position in eight; when the list is too short the contig is repeated with k_norm_tile.  A list
+    with one entry per part, the same golden vectors."""
+    from himut_amd import normcounts
+    monkeypatch.setenv("HIMUT_NORM_DIRTY_CAP", "1")
+    batch, exp, p, refseq, pon, com = load_norm_case(case)
+    _configure(worker, p, util.phase_of(exp) is not None)
+    ccs, rf, log = normcounts.norm_contig(worker, batch, util.chunks_of(exp), refseq, pon, com,
+                                          exp["non_human_sample"], exp["alt_order"], phase_sets=util.phase_of(exp))
+    assert log == exp["log"]
+    assert ccs == {k: int(v) for k, v in exp["ccs_tri2count"].items()}
+    assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
+
+
 def test_normcounts_qualities_of_128_and_more(worker):
     """k_norm_col reads quality | callable << 7 from one byte; a contig with a quality that does not leave the bit free
     is done by k_norm_tile (k_callable raises a flag, each kernel looks at it first).  Qualities up to 255 in passing
