@@ -1386,10 +1386,12 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
         const int64_t per = ((int64_t)blocks_for(maxspan, 256) + 7) / 8;          // tiles of a chunk per XCD class: see the tile mapping
         const dim3 grid(8u * (unsigned)std::min<int64_t>(NT_Q, per), (unsigned)T.n);
         if (sweep_col) {
-            if (phase) hipLaunchKernelGGL(k_norm_col<true>, grid, dim3(256), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
+            const int64_t per = ((int64_t)blocks_for(maxspan, NC_THREADS) + 7) / 8;
+            const dim3 grid(8u * (unsigned)std::min<int64_t>(NC_Q, per), (unsigned)T.n);
+            if (phase) hipLaunchKernelGGL(k_norm_col<true>, grid, dim3(NC_THREADS), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
                                           c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per, c->d_dirty.as<NormDirty>(),
                                           c->d_dcount.as<unsigned long long>(), dirty_cap, &sc->dirty_over);
-            else hipLaunchKernelGGL(k_norm_col<false>, grid, dim3(256), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
+            else hipLaunchKernelGGL(k_norm_col<false>, grid, dim3(NC_THREADS), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
                                     c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per, c->d_dirty.as<NormDirty>(),
                                     c->d_dcount.as<unsigned long long>(), dirty_cap, &sc->dirty_over);
             hipLaunchKernelGGL(k_norm_dirty, dim3(8, NORM_DIRTY_REGIONS), dim3(256), 0, st, A, c->d_dirty.as<NormDirty>(),

@@ -953,30 +953,42 @@ __global__ void __launch_bounds__(256) k_norm_dirty(NormArgs A, const NormDirty*
 
 // ---------------------------------------------------------------------------------------
 // k_norm_col: the sweep with no cells in LDS.  A wave owns 64 consecutive positions -- a lane is a column from the first
-// row to the last -- and the four waves of a workgroup take the four quarters of k_norm_tile's 256-position tile (same
-// launch geometry, same neighbours in an XCD's L2).  The rows of the quarter are prepared 64 at a time with a LANE per
-// ROW (read header, the segment that reaches the quarter by binary search, whether that one gapless segment spans all
-// 64 positions -- 97 rows in 100 -- and then where the row's first base lies, as a 32-bit distance from the batch's
-// first read); the wave goes through the live rows in read order (the set bits of a ballot: a read of the window index
-// that does not reach the quarter costs nothing).  A spanning row is 64 consecutive query bases from K on: one byte
-// load at a scalar base brings quality | callable << 7 (`cq`, written by k_callable: the callable bit travels with the
-// quality), one 16-bit load the packed bases -- no address arithmetic in a lane, no LDS round trip, no barrier; the
+// row to the last -- and the eight waves of a workgroup take the eight parts of a 512-position tile (k_norm_tile's
+// mapping of tiles to workgroups: neighbours share an XCD's L2).  The rows of a wave's 64 positions are prepared 64 at a
+// time with a LANE per ROW (read header, the segment that reaches the positions by binary search, whether that one gapless
+// segment spans all 64 -- 97 rows in 100 -- and then where the row's first base lies, as a 32-bit distance from the
+// batch's first read); the wave goes through the live rows in read order (the set bits of a ballot: a read of the window
+// index that does not reach these positions costs nothing).  A spanning row is 64 consecutive query bases from K on: one
+// byte load at a scalar base brings quality | callable << 7 (`cq`, written by k_callable: the callable bit travels with
+// the quality), one 16-bit load the packed bases -- no address arithmetic in a lane, no LDS round trip, no barrier; the
 // reference allele's three sums and two counters are a dozen vector instructions per row.  While HIMUT_NC_NB spanning
 // rows follow each other they are taken together, their loads issued before the first is used.  Everything else -- a
-// row with an indel or a read end inside the quarter, another allele -- takes the general update lane by lane, in its
-// place in the read order.  The sums of the other three alleles, touched by one row in twenty, live in LDS (a column's
-// nine doubles), not in registers.  The scalar unit and the vector units of a CU each get one instruction through per
-// cycle, and this loop is bound by their sum: what is the same for a whole row sits in a lane of a row vector and comes
-// back with one v_readlane, the counts that do not depend on the order (insertions in front of a spanning segment,
-// haplotype votes of spanning rows) are taken per 64 rows with a popcount.  Qualities of 128 and more do not fit beside
-// the callable bit: k_callable raises a flag and k_norm_tile does the contig (each of the two kernels looks at the flag
-// first).  Same counts as k_norm_tile (HIMUT_NORM_SWEEP=tile takes that one).
+// row with an indel or a read end inside the 64 positions, another allele -- takes the general update lane by lane, in
+// its place in the read order.  The sums of the other three alleles, touched by one row in twenty, live in LDS (a column's
+// nine doubles), not in registers.  What is the same for a whole row sits in a lane of a row vector and comes back with
+// one v_readlane; the counts that do not depend on the order (insertions in front of a spanning segment, haplotype votes
+// of spanning rows) are taken per 64 rows with a popcount.  At the end of a column: nothing but the reference allele in
+// it (29 columns in 30) makes the ten genotype sums four numbers, and the kernel classifies the position itself; the
+// others go into a list for k_norm_dirty.  Qualities of 128 and more do not fit beside the callable bit: k_callable
+// raises a flag and k_norm_tile does the contig (each of the two kernels looks at the flag first).  Same counts as
+// k_norm_tile (HIMUT_NORM_SWEEP=tile takes that one).
 #ifndef HIMUT_NC_WAVES
-#define HIMUT_NC_WAVES 5
+#define HIMUT_NC_WAVES 6
 #endif
 #ifndef HIMUT_NC_NB
 #define HIMUT_NC_NB 4
 #endif
+#ifndef HIMUT_NC_THREADS
+#define HIMUT_NC_THREADS 512
+#endif
+#ifndef HIMUT_NC_Q
+#define HIMUT_NC_Q 8
+#endif
+// A workgroup's positions per tile (64 per wave).  The other alleles' sums take 44 bytes of LDS a column, so 512 columns
+// with the tables are 51 KB: three workgroups of eight waves on a CU are six waves per SIMD, where five workgroups of four
+// waves were five (3.92 -> 3.55 ms); NC_Q workgroups per XCD class and chunk take neighbouring tiles (2 to 8 measure the same).
+constexpr int NC_THREADS = HIMUT_NC_THREADS;
+constexpr int NC_Q = HIMUT_NC_Q;
 
 typedef const __attribute__((address_space(1))) uint8_t* nc_gptr8;
 
@@ -1025,7 +1037,7 @@ typedef const __attribute__((address_space(1))) uint8_t* nc_gptr8;
             }
 
 template <bool PHASE>
-__global__ void __launch_bounds__(256, HIMUT_NC_WAVES) k_norm_col(NormArgs A, Derived D, const uint8_t* __restrict__ cq,
+__global__ void __launch_bounds__(NC_THREADS, HIMUT_NC_WAVES) k_norm_col(NormArgs A, Derived D, const uint8_t* __restrict__ cq,
                                                                    const int* __restrict__ qhigh, const int32_t* winlo,
                                                                    const int32_t* winhi, int64_t nblk, int64_t tiles_per_class,
                                                                    NormDirty* dirty, unsigned long long* dcount, int64_t dirty_cap,
@@ -1034,12 +1046,12 @@ __global__ void __launch_bounds__(256, HIMUT_NC_WAVES) k_norm_col(NormArgs A, De
     __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
     __shared__ unsigned int s_ccs[32], s_ref[32];
-    __shared__ double s_S[9][256];            // [table * 3 + slot][column]: the sums of the three alleles that are not the reference's
-    __shared__ uint32_t s_cnt[4][256];        // [allele][column]: their counts
+    __shared__ double s_S[9][NC_THREADS];     // [table * 3 + slot][column]: the sums of the three alleles that are not the reference's
+    __shared__ uint32_t s_cnt[4][NC_THREADS]; // [allele][column]: their counts
     __shared__ int s_bad;                     // a base outside ATGC was seen (the reference raises KeyError)
     if (*qhigh) return;                       // a quality of 128 or more somewhere: k_norm_tile does this contig
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
-    for (int i = tid; i < 3 * 256; i += 256) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 127];
+    for (int i = tid; i < 3 * 256; i += NC_THREADS) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 127];
     if (tid < 3) s_lut[tid * 257 + 256] = 0.0;
     if (tid < 4) s_prior[tid] = A.lut->prior[tid];
     if (tid < 16) s_log[tid] = 0;
@@ -1060,7 +1072,7 @@ __global__ void __launch_bounds__(256, HIMUT_NC_WAVES) k_norm_col(NormArgs A, De
     const int64_t per = tiles_per_class;
     for (int64_t t = blockIdx.x >> 3; t < per; t += (int64_t)(gridDim.x >> 3)) {         // the tile mapping of k_norm_tile
         const int64_t tile = (int64_t)(blockIdx.x & 7) * per + t;
-        const int64_t base = (int64_t)cs_ + tile * 256 + 64 * wv;                         // this wave's quarter
+        const int64_t base = (int64_t)cs_ + tile * NC_THREADS + 64 * wv;                  // this wave's 64 positions
         if (base >= ce_) break;                                   // (the later tiles of this workgroup lie further on)
         const int64_t rpos = base + lane;
         bool valid = rpos < ce_;
