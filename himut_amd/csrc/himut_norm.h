@@ -1100,8 +1100,19 @@ __global__ void __launch_bounds__(NC_THREADS, HIMUT_NC_WAVES) k_norm_col(NormArg
             int j0 = 0;
             int4 sg0 = make_int4(0x7fffffff, 0, 0, 0);
             if (live_row) {
-                int a = 0, e = M.nseg;
-                while (a < e) { const int m = (a + e) >> 1; if (D.segs[M.segbase + m].t0 <= (int32_t)base) a = m + 1; else e = m; }
+                // the starts of the read's first eight segments in one round trip (a read has about as many); the binary search,
+                // a round trip a step, only where the segment lies further on
+                constexpr int NP = 8;
+                int32_t tp[NP];
+#pragma unroll
+                for (int k = 0; k < NP; k++) tp[k] = D.segs[M.segbase + min(k, M.nseg - 1)].t0;
+                int a = 0;
+#pragma unroll
+                for (int k = 0; k < NP; k++) a += (k < M.nseg && tp[k] <= (int32_t)base) ? 1 : 0;       // (starts ascend: the first `a` of them)
+                if (a == NP && M.nseg > NP) {
+                    int e = M.nseg;
+                    while (a < e) { const int m = (a + e) >> 1; if (D.segs[M.segbase + m].t0 <= (int32_t)base) a = m + 1; else e = m; }
+                }
                 j0 = max(a - 1, 0);
                 sg0 = *reinterpret_cast<const int4*>(D.segs + M.segbase + j0);
             }
@@ -1158,17 +1169,22 @@ __global__ void __launch_bounds__(NC_THREADS, HIMUT_NC_WAVES) k_norm_col(NormArg
                 }
                 // ---- the general row: every lane finds its position in the segments from the cursor on
                 {
-                    const ReadMeta Ms = D.meta[r0 + l0];
-                    const int ns = uni(Ms.nseg), jf = lane_val(j0, l0);
-                    const int64_t segbase = uni(Ms.segbase), qoff = uni(Ms.qoff);
-                    const int32_t tend_r = uni(Ms.tend);
+                    const int ns = lane_val(M.nseg, l0), jf = lane_val(j0, l0);
+                    const int64_t segbase = ((int64_t)lane_val((int)(M.segbase >> 32), l0) << 32) | (uint32_t)lane_val((int)M.segbase, l0);
+                    const int64_t qoff = ((int64_t)lane_val((int)(M.qoff >> 32), l0) << 32) | (uint32_t)lane_val((int)M.qoff, l0);
+                    const int32_t tend_r = lane_val(M.tend, l0);
                     uint32_t hps = HAP_NONE;
                     if (phase) hps = (uint32_t)lane_val((int)hp, l0);
                     uint32_t v = CELL_EMPTY;
                     for (int j = jf; j < ns; j++) {
-                        const Seg g = D.segs[segbase + j];
-                        const int32_t t0 = uni(g.t0), q0 = uni(g.q0), len = uni(g.len);
-                        const uint32_t fl = uni(g.flags);
+                        int32_t t0, q0, len;
+                        uint32_t fl;
+                        if (j == jf) {                                   // (the row vector holds it)
+                            t0 = lane_val(sg0.x, l0); q0 = lane_val(sg0.y, l0); len = lane_val(sg0.z, l0); fl = (uint32_t)lane_val(sg0.w, l0);
+                        } else {
+                            const Seg g = D.segs[segbase + j];
+                            t0 = uni(g.t0); q0 = uni(g.q0); len = uni(g.len); fl = uni(g.flags);
+                        }
                         if (t0 >= base + 64) break;
                         const int32_t span = len > 0 ? len : ((fl & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
                         if (P >= t0 && P < t0 + span) {
