@@ -72,8 +72,8 @@ def main():
            "roofline": {"bound": "hbm", "achieved": st["read_bases"] * 5.5 / (np.mean(ms) * 1e-3) / 1e9, "peak": 8000.0,
                         "unit": "GB/s", "frac": st["read_bases"] * 5.5 / (np.mean(ms) * 1e-3) / 1e9 / 8000.0,
                         "note": "whole pass against the SURVEY's 5.5 B per read base (qualities twice, packed bases once, one "
-                                "2-byte cell written and read); the tiled sweep keeps the cells in LDS and is bound by "
-                                "instructions per cell, not by these bytes (DESIGN.md section 8)"}}
+                                "2-byte cell written and read); the column sweep (k_norm_col) builds no cells at all and "
+                                "waits on dependent loads more than it moves bytes (DESIGN.md section 8)"}}
     if not a.no_cpu_baseline:
         from oracle import oracle as O
         nch = max(1, int(a.cpu_sample_mb * 1e6 / 200000))
