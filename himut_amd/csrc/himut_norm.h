@@ -212,7 +212,9 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                     continue;
                 }
                 // the few entries near these bases, in registers (value, query offset | substitution flag)
-                constexpr int NE = 8;
+                // (four: the slots are filled and counted for all of them whatever a lane holds, and a lane with more nearby
+                //  -- 0.1 are expected -- takes the exact loop over its bases below; 8: 1.62 ms, 4: 1.39, 3: 1.38, 2: 1.54)
+                constexpr int NE = 4;
                 int32_t ev[NE];
                 uint32_t eq[NE];
                 int ne = 0;
