@@ -108,7 +108,7 @@ def test_normcounts_golden_tile_sweep(worker, case, monkeypatch):
     assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
 
 
-@pytest.mark.parametrize("case", ["norm_dense", "norm_sets"])
+@pytest.mark.parametrize("case", ["norm_dense", "norm_sets", "norm_phase"])
 def test_normcounts_left_over_positions_do_not_fit(worker, case, monkeypatch):
     """k_norm_col hands the positions it does not classify itself (a column with another allele) to k_norm_dirty through
     a list sized for one position in eight; when the list is too short the contig is repeated with k_norm_tile.  A list
@@ -122,6 +122,27 @@ def test_normcounts_left_over_positions_do_not_fit(worker, case, monkeypatch):
     assert log == exp["log"]
     assert ccs == {k: int(v) for k, v in exp["ccs_tri2count"].items()}
     assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
+
+
+def test_normcounts_every_piled_base_has_its_cq_byte(worker, monkeypatch):
+    """k_callable writes quality | callable << 7 for every base the sweep can reach (also of reads that fail the filters,
+    and of bases behind a soft clip's first 2 KB); with the array cleared first (HIMUT_DEBUG_FILL_CQ) a byte it left out
+    would read as a zero quality and end the run with the BQ 0 error."""
+    from oracle import oracle as O
+    from himut_amd import normcounts, synth, util as hutil
+    monkeypatch.setenv("HIMUT_DEBUG_FILL_CQ", "1")
+    s = synth.generate(synth.SynthConfig(seed=44, contig_len=80_000, depth=35.0, frac_softclip=0.6, softclip_max=5000,
+                                         frac_lowbq=0.2, frac_lowmapq=0.2, name="chrF"), want_ref=True)
+    refseq = bytes(s.ref)
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((s.batch.name, 0, s.batch.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=9000, qlen_upper_limit=22500, md_threshold=60)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+    o_ccs, o_ref, o_log = O.normcounts(s.batch, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+    _configure(worker, p)
+    ccs, rf, log = normcounts.norm_contig(worker, s.batch, chunks, refseq, alt_order=order)
+    assert log == o_log and ccs == o_ccs and rf == o_ref
+    assert log[13] > 0
 
 
 def test_normcounts_qualities_of_128_and_more(worker):
