@@ -986,8 +986,8 @@ __global__ void __launch_bounds__(256) k_norm_dirty(NormArgs A, const NormDirty*
 #ifndef HIMUT_NC_Q
 #define HIMUT_NC_Q 8
 #endif
-// A workgroup's positions per tile (64 per wave).  The other alleles' sums take 44 bytes of LDS a column, so 512 columns
-// with the tables are 51 KB: three workgroups of eight waves on a CU are six waves per SIMD, where five workgroups of four
+// A workgroup's positions per tile (64 per wave).  The other alleles' sums and counts take 88 bytes of LDS a column, so 512
+// columns with the tables are 51 KB: three workgroups of eight waves on a CU are six waves per SIMD, where five workgroups of four
 // waves were five (3.92 -> 3.55 ms); NC_Q workgroups per XCD class and chunk take neighbouring tiles (2 to 8 measure the same).
 constexpr int NC_THREADS = HIMUT_NC_THREADS;
 constexpr int NC_Q = HIMUT_NC_Q;
