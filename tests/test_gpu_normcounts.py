@@ -200,6 +200,45 @@ def test_normcounts_deep_and_ragged_piles_oracle_parity(worker, seed, depth, ext
     assert log[1] > 0
 
 
+_SWEEP = [
+    dict(min_bq=0), dict(min_bq=1, min_trim=0.0), dict(min_bq=60, max_mismatch_count=1), dict(min_bq=93, max_mismatch_count=2, mismatch_window_size=5),
+    dict(min_bq=30, max_mismatch_count=5, mismatch_window_size=50), dict(min_bq=127, min_trim=0.2), dict(min_bq=128), dict(min_bq=200, min_qv=0),
+    dict(min_bq=20, mismatch_window_size=0), dict(min_gq=0, min_ref_count=0, md_threshold=25), dict(min_gq=99, min_ref_count=40),
+    dict(min_qv=93, min_mapq=0), dict(min_sequence_identity=0.0, min_mapq=0, max_mismatch_count=8, mismatch_window_size=100),
+]
+
+
+@pytest.mark.parametrize("k", range(len(_SWEEP)))
+def test_normcounts_parameter_sweep_oracle_parity(worker, k):
+    """The filters' parameters away from their defaults (quality thresholds on both sides of 128, mismatch windows from 0
+    to 100 with up to 8 mismatches allowed, trimming, genotype-quality and depth thresholds), qualities up to 255 in every
+    other case (those contigs are k_norm_tile's), against the oracle."""
+    from oracle import oracle as O
+    from himut_amd import normcounts, synth, util as hutil
+    from himut_amd.readbatch import ReadBatch
+    s = synth.generate(synth.SynthConfig(seed=60 + k, contig_len=50_000, depth=32.0, sub_rate=1e-3, frac_noisy=0.05,
+                                         name="chrW"), want_ref=True)
+    b = s.batch
+    if k & 1:
+        rs = np.random.RandomState(k)
+        bq = b.bq.copy()
+        idx = rs.randint(0, len(bq), 3000)
+        bq[idx] = rs.randint(94, 256, 3000)
+        b = ReadBatch(name=b.name, length=b.length, tstart=b.tstart, tend=b.tend, qstart=b.qstart, qlen=b.qlen, mapq=b.mapq,
+                      flag=b.flag, qid=b.qid, qoff=b.qoff, cs_off=b.cs_off, seq=b.seq, bq=bq, cs=b.cs, tp=b.tp)
+    refseq = bytes(s.ref)
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((b.name, 0, b.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=9000, qlen_upper_limit=22500, md_threshold=60)
+    p.update(_SWEEP[k])
+    order = {"A": ["G", "C", "T"], "T": ["A", "G", "C"], "G": ["T", "C", "A"], "C": ["T", "A", "G"]}
+    o_ccs, o_ref, o_log = O.normcounts(b, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+    _configure(worker, p)
+    ccs, rf, log = normcounts.norm_contig(worker, b, chunks, refseq, alt_order=order)
+    assert log == o_log
+    assert ccs == o_ccs and rf == o_ref
+
+
 def test_normcounts_phase_oracle_parity(worker, tmp_path):
     """--phase: chunks are the phase-set spans, reads need haplotype 0/1 there, positions need both haplotypes."""
     from oracle import oracle as O
