@@ -1326,7 +1326,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     HCHECK(hipMemsetAsync(c->d_callable.p, 0, cwords * 4, st));
     if (sweep_col) HCHECK(hipMemsetAsync(c->d_dcount.p, 0, (size_t)NORM_DIRTY_REGIONS * 128, st));
     if (sweep_col && getenv("HIMUT_DEBUG_FILL_CQ")) HCHECK(hipMemsetAsync(c->d_cq.p, 0, (size_t)c->bq_bytes + 256, st));   // (a base whose byte k_callable did not write shows as a zero quality)
-    if (c->n > 0) run_parse_stage(c, R, D, sc);
+    if (c->n > 0) run_parse_stage<false>(c, R, D, sc, [](hipStream_t) {});   // (the quality sums are k_callable's)
     else stage_event(c, EV_PARSE, 2, st);
     int32_t maxend = 0;
     for (int32_t e : c->cend) maxend = std::max(maxend, e);
@@ -1336,13 +1336,15 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     if (c->n > 0 && T.n > 0) {
         hipLaunchKernelGGL(k_read_live, dim3(blocks_for(c->n, 16)), dim3(256), 0, st, R, D, C, c->params,
                            c->d_live.as<uint8_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
+        // (k_callable takes the reads with a low mean quality out of `live`: before the phased runs' count of the reads)
+        hipLaunchKernelGGL(k_callable, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, c->d_live.as<uint8_t>(),
+                           c->d_callable.as<uint32_t>(), sweep_col ? c->d_cq.as<uint8_t>() : (uint8_t*)nullptr, &sc->qhigh,
+                           c->d_ccs.as<uint8_t>());
         if (phase && T.npairs > 0) {
             hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
             hipLaunchKernelGGL(k_pair_ccs, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, C, H, R, c->d_live.as<uint8_t>(),
                                T.npairs, c->d_ccs.as<uint8_t>());
         }
-        hipLaunchKernelGGL(k_callable, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, c->d_live.as<uint8_t>(),
-                           c->d_callable.as<uint32_t>(), sweep_col ? c->d_cq.as<uint8_t>() : (uint8_t*)nullptr, &sc->qhigh);
         hipLaunchKernelGGL(k_window_index, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, R, nblk, c->d_winlo.as<int32_t>(),
                            c->d_winhi.as<int32_t>());
     }

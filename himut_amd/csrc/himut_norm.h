@@ -5,16 +5,20 @@
 // trinucleotide context.  A pile cell is the 16-bit value of the call path (CELL_* code, CELL_INS, BQ) with one
 // more bit: "this base counts as callable for its read" (update_tri2count, normcounts.py:66-110).
 //
-//   k_read_live    sixteen lanes per read: read filters (normcounts.py:302-309), cs-vs-SEQ check, num_ccs
-//   k_callable     wave per read: one bit per query base (the mismatch-window / trim / BQ rules)
-//   k_norm_tile    workgroup per 256-position tile of a chunk: the cells of the reads over the tile are built in
-//                  LDS, 48 rows at a time, and every thread runs down its column (pile, genotype, classification,
-//                  histograms) -- the sweep in use
+//   k_read_live    sixteen lanes per read: the read filters but the mean quality (normcounts.py:302-309), cs-vs-SEQ check
+//   k_callable     wave per read: one bit per query base (the mismatch-window / trim / BQ rules), and a byte per base,
+//                  quality | bit << 7; the mean-quality filter (it reads every quality anyway), num_ccs
+//   k_norm_col     the sweep in use: a wave per 64 positions, a lane per column, no cells in memory; classifies the
+//                  columns that hold nothing but the reference allele, lists the others
+//   k_norm_dirty   lane per listed position: the general classification (ten PLs twice, PoN / common look-ups)
+//   k_norm_tile    round 2's first sweep (HIMUT_NORM_SWEEP=tile, and behind k_norm_col for a contig with a quality of 128
+//                  or more): workgroup per 256-position tile of a chunk, the cells of the reads over the tile built in
+//                  LDS, 48 rows at a time, every thread down its column
 //   k_fill_bits, k_stream_capture<true>, k_norm_eval
-//                  the earlier sweep (HIMUT_NORM_SWEEP=store): the position bitmap is all ones inside the chunks,
+//                  the earliest sweep (HIMUT_NORM_SWEEP=store): the position bitmap is all ones inside the chunks,
 //                  the capture kernel transposes every (read, position) cell into the read-major column store in
 //                  HBM, in passes of NORM_PASS positions, and k_norm_eval (thread per (chunk, position)) reads it
-//                  back.  Kept for comparison; both evaluate a position with the same text (NORM_* macros).
+//                  back.  Kept for comparison; all of them evaluate a position with the same text (NORM_* macros).
 #pragma once
 
 #include "himut_kernels.h"
@@ -60,7 +64,7 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
         if (gl != 0) return;
         const int32_t qlen = R.qlen[r];
         bool ok = (M.flags & RF_IDENT_OK) != 0;
-        if ((double)D.bqsum[r] / (double)qlen < (double)P.p.min_qv) ok = false;
+        // (the mean quality, the last of the read filters, is k_callable's: it is the kernel that reads every quality)
         if ((int)R.mapq[r] < P.p.min_mapq) ok = false;
         if (!(P.p.qlen_lower_limit < qlen && qlen < P.p.qlen_upper_limit)) ok = false;
         if (ok) {
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
             while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (C.rec[m].start < M.tend) lo = m + 1; else hi = m; }
             ok = lo > 0 && C.rec[lo - 1].pmaxend > M.tstart;
         }
-        if (ok) { lv = 1; if (!P.p.phase) ccs_flag[R.qid[r]] = 1; }
+        if (ok) lv = 1;
     }
     if (gl == 0) live[r] = lv;
 }
@@ -86,8 +90,11 @@ constexpr int CAL_NM = 256;   // mismatch entries kept in LDS per wave
 // With `cq` the kernel also writes, for every base of every read, quality | callable << 7 -- what k_norm_col reads
 // instead of the quality array and the bit array (the bases of a read that fails the filters keep their qualities: they
 // are piled, not counted) -- and raises *qhigh when a quality does not leave that bit free.
-__global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, const uint8_t* live, uint32_t* cbits,
-                                                  uint8_t* cq, int* qhigh) {
+// The read filter's mean quality (normcounts.py:302, bamlib.py:34-36) is decided here as well: the kernel sums the
+// qualities it reads anyway, and a read whose mean is too low gets its bits cleared and its plain qualities back, its
+// `live` flag taken away; a read that stays is counted (num_ccs: ccs_flag, unless the run is phased -- k_pair_ccs then).
+__global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, uint8_t* live, uint32_t* cbits,
+                                                  uint8_t* cq, int* qhigh, uint8_t* ccs_flag) {
     __shared__ int32_t s_mis[4][CAL_NM];
     __shared__ uint32_t s_mq[4][CAL_NM];
     __shared__ __align__(16) int4 s_seg[4][64];
@@ -145,12 +152,14 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
     const int32_t q_last = (max(qlen, 1) - 1) & ~31;
     uint4 p0, p1;
     {
-        const int32_t qn = min((q_first & ~2047) + lane * 32, q_last);
+        const int32_t qn = min(lane * 32, q_last);
         p0 = *reinterpret_cast<const uint4*>(R.bq + qo + qn);
         p1 = *reinterpret_cast<const uint4*>(R.bq + qo + qn + 16);
     }
+    (void)q_first;
+    uint32_t qsum = 0;   // this lane's share of the sum of the read's qualities (from offset 0: the mean is over the whole query)
     int jc = 0;      // the first segment that reaches into the window (segments are in query order: the cursor only moves on)
-    for (int32_t c0 = q_first & ~2047; c0 < qlen; c0 += 2048) {
+    for (int32_t c0 = 0; c0 < qlen; c0 += 2048) {
         const int32_t qa = c0 + lane * 32;
         uint32_t word = 0;
         while (jc < ns) {
@@ -168,6 +177,17 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
         if (qa < qlen) {
             // qualities of the lane's 32 bases
             const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            if (qa + 32 <= qlen) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) qsum = __builtin_amdgcn_sad_u8(bw[k], 0u, qsum);
+            } else {                                              // the read's last bases: the bytes behind them are padding
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int rb = qlen - (qa + 4 * k);           // bytes of the word inside the read
+                    const uint32_t x = rb >= 4 ? bw[k] : rb <= 0 ? 0u : (bw[k] & (0xffffffffu >> (8 * (4 - rb))));
+                    qsum = __builtin_amdgcn_sad_u8(x, 0u, qsum);
+                }
+            }
             uint32_t okq = 0;    // quality and trim tests per base, four bytes at a time: the low seven bits compared, bit 7 by itself
             const uint32_t hb = (bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) & 0x80808080u;   // a quality of 128 or more among them
             if (min_bq <= 127 && !hb) {
@@ -302,6 +322,18 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
             }
         }
     }
+    // ---- the mean quality (np.mean of the whole query against min_qv, as in k_read_live's other tests)
+    const uint32_t qtot = (uint32_t)lane_val(wave_incl_add((int)qsum, lane), 63);
+    if ((double)qtot / (double)qlen < (double)P.p.min_qv) {
+        if (lane == 0) live[r] = 0;
+        for (int32_t o = lane * 32; o < qlen; o += 2048) {            // no base of it counts: bits cleared, plain qualities
+            cbits[(qo + o) >> 5] = 0;
+            if (cq) {
+                *reinterpret_cast<uint4*>(cq + qo + o) = *reinterpret_cast<const uint4*>(R.bq + qo + o);
+                *reinterpret_cast<uint4*>(cq + qo + o + 16) = *reinterpret_cast<const uint4*>(R.bq + qo + o + 16);
+            }
+        }
+    } else if (!P.p.phase && lane == 0) ccs_flag[R.qid[r]] = 1;
 }
 
 // ---------------------------------------------------------------------------------------
