@@ -611,14 +611,14 @@ _Pragma("unroll") \
         atomicAdd(&s_log[1], tri_sum); \
         atomicAdd(&s_log[(SLOT)], tri_sum); \
         if ((SLOT) == 13) { \
-            NORM_TRIBINS() \
+            NORM_TRIBINS(A.refseq[rpos - 1], A.refseq[rpos + 1]) \
         }
 
-// the trinucleotide bins of a callable position (row 13 of norm.log)
-#define NORM_TRIBINS() \
+// the trinucleotide bins of a callable position (row 13 of norm.log); PREV, NEXT: the reference's letters beside it
+#define NORM_TRIBINS(PREV, NEXT) \
             int t0 = 'N', t1 = 'N', t2 = 'N'; \
             if (rpos - 1 >= 0 && rpos + 2 <= A.reflen) { \
-                t0 = A.refseq[rpos - 1]; t1 = refc; t2 = A.refseq[rpos + 1]; \
+                t0 = (PREV); t1 = refc; t2 = (NEXT); \
                 if (t1 == 'A' || t1 == 'G') { \
                     const int a0 = t2, a2 = t0; \
                     t0 = a0 == 'A' ? 'T' : a0 == 'T' ? 'A' : a0 == 'G' ? 'C' : a0 == 'C' ? 'G' : 'N'; \
@@ -1111,7 +1111,13 @@ __global__ void __launch_bounds__(NC_THREADS, HIMUT_NC_WAVES) k_norm_col(NormArg
         const int64_t rpos = base + lane;
         bool valid = rpos < ce_;
         if (valid && (rpos < 0 || rpos >= A.reflen)) { bad |= 1 << HIMUT_ERR_ARG; valid = false; }   // IndexError in the reference
-        const int refc = valid ? (int)A.refseq[rpos] : 'N';
+        // the reference's letter and its two neighbours (the trinucleotide at the end needs them) in one unaligned load
+        uint32_t ref3 = 0x4e4e4eu;                                // "NNN"
+        if (valid) {
+            if (rpos >= 1 && rpos + 2 <= A.reflen) __builtin_memcpy(&ref3, A.refseq + rpos - 1, 4);   // (the array has slack behind it)
+            else ref3 = 0x4e004eu | ((uint32_t)A.refseq[rpos] << 8);
+        }
+        const int refc = (int)((ref3 >> 8) & 255u);
         const int ref = char2allele(refc);
         const uint32_t refnib = ref == 0 ? 1u : ref == 3 ? 2u : ref == 2 ? 4u : ref == 1 ? 8u : 0xffu;   // the BAM code of the reference base
         uint32_t n_ins = 0, n_del = 0;
@@ -1291,7 +1297,7 @@ __global__ void __launch_bounds__(NC_THREADS, HIMUT_NC_WAVES) k_norm_col(NormArg
         }
         if (mine && slot != 13) atomicAdd(&s_log[slot], tri_sum);
         if (mine && slot == 13) {
-            NORM_TRIBINS()
+            NORM_TRIBINS((int)(ref3 & 255u), (int)((ref3 >> 16) & 255u))
         }
         if (open && !mine) {
             // a place in the workgroup's region of the list: one atomic per wave, on one of NORM_DIRTY_REGIONS counters (a single
