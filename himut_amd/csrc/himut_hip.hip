@@ -388,8 +388,8 @@ void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc
     HCHECK(hipStreamWaitEvent(st, c->ev[EV_SIDE], 0));
     stage_event(c, EV_PARSE, 2, st);
 }
-void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {   // with the quality sums
-    run_parse_stage<true>(c, R, D, sc, [](hipStream_t) {});
+void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc) {   // the decode alone
+    run_parse_stage<false>(c, R, D, sc, [](hipStream_t) {});
 }
 
 void alloc_derived(himut_ctx* c) {
@@ -1326,7 +1326,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     HCHECK(hipMemsetAsync(c->d_callable.p, 0, cwords * 4, st));
     if (sweep_col) HCHECK(hipMemsetAsync(c->d_dcount.p, 0, (size_t)NORM_DIRTY_REGIONS * 128, st));
     if (sweep_col && getenv("HIMUT_DEBUG_FILL_CQ")) HCHECK(hipMemsetAsync(c->d_cq.p, 0, (size_t)c->bq_bytes + 256, st));   // (a base whose byte k_callable did not write shows as a zero quality)
-    if (c->n > 0) run_parse_stage<false>(c, R, D, sc, [](hipStream_t) {});   // (the quality sums are k_callable's)
+    if (c->n > 0) run_parse_stage(c, R, D, sc);   // (the quality sums are k_callable's)
     else stage_event(c, EV_PARSE, 2, st);
     int32_t maxend = 0;
     for (int32_t e : c->cend) maxend = std::max(maxend, e);

@@ -349,10 +349,11 @@ __device__ __forceinline__ uint32_t cs_pack4(uint32_t f) {                      
 }
 
 
-// WITH_BQ (normcounts, edge counts): the wave also issues the first rows of its read's qualities (bq_issue)
-// behind the first KB of the tag, decodes the tag while they are in flight, then sums the qualities
-// (bq_finish): waves in that phase are bound by HBM, waves in the decode by VALU, and a CU holds both kinds at
-// any time.  The call path takes the sum from k_stream_capture, which streams the qualities anyway.
+// WITH_BQ: the wave also issues the first rows of its read's qualities (bq_issue) behind the first KB of the tag,
+// decodes the tag while they are in flight, then sums the qualities (bq_finish): waves in that phase are bound by
+// HBM, waves in the decode by VALU, and a CU holds both kinds at any time.  No caller asks for it any more: the call
+// path takes the sum from k_stream_capture and normcounts from k_callable, which stream the qualities anyway, and
+// the edge counts and the dense pile never looked at it (0.24 ms a contig each).
 //
 // posbits (call path; else null): the bitmap of reference positions at which a column must be captured = every
 // substitution of every read that passes the filters known before the qualities have been streamed (identity,
