@@ -1323,7 +1323,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
     HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
     HCHECK(hipMemsetAsync(c->d_tri.p, 0, (2 * ntri + 16) * 8, st));
-    HCHECK(hipMemsetAsync(c->d_callable.p, 0, cwords * 4, st));
+    // (d_callable is not cleared: k_callable writes the words of every read)
     if (sweep_col) HCHECK(hipMemsetAsync(c->d_dcount.p, 0, (size_t)NORM_DIRTY_REGIONS * 128, st));
     if (sweep_col && getenv("HIMUT_DEBUG_FILL_CQ")) HCHECK(hipMemsetAsync(c->d_cq.p, 0, (size_t)c->bq_bytes + 256, st));   // (a base whose byte k_callable did not write shows as a zero quality)
     if (c->n > 0) run_parse_stage(c, R, D, sc);   // (the quality sums are k_callable's)

@@ -101,19 +101,20 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
     const int lane = threadIdx.x & 63, wv = uni((int)(threadIdx.x >> 6));
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
-    if (!uni((int)live[r])) {
-        if (cq) {                                             // qualities as they are (a read's bases start at a multiple of 32)
-            const int64_t qo = uni(R.qoff[r]);
-            const int32_t qlen = uni(R.qlen[r]);
-            uint32_t hb = 0;
-            for (int32_t o = lane * 32; o < qlen; o += 2048) {
+    if (!uni((int)live[r])) {                                  // no base of it counts (every read's words are written: the array is not cleared first)
+        const int64_t qo = uni(R.qoff[r]);
+        const int32_t qlen = uni(R.qlen[r]);
+        uint32_t hb = 0;
+        for (int32_t o = lane * 32; o < qlen; o += 2048) {
+            cbits[(qo + o) >> 5] = 0;
+            if (cq) {                                             // qualities as they are (a read's bases start at a multiple of 32)
                 const uint4 x0 = *reinterpret_cast<const uint4*>(R.bq + qo + o), x1 = *reinterpret_cast<const uint4*>(R.bq + qo + o + 16);
                 *reinterpret_cast<uint4*>(cq + qo + o) = x0;
                 *reinterpret_cast<uint4*>(cq + qo + o + 16) = x1;
                 hb |= x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w;
             }
-            if (hb & 0x80808080u) atomicOr(qhigh, 1);
         }
+        if (hb & 0x80808080u) atomicOr(qhigh, 1);
         return;
     }
     const ReadMeta Mv = D.meta[r];
