@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=24.0)
+    ap.add_argument("--legs", default="normcounts,edges,e2e",
+                    help="the SURVEY 8f rows measured behind the headline on the single-GPU run (comma list; '' for none)")
+    ap.add_argument("--legs-limit-s", type=float, default=240.0, help="watchdog over all the legs")
     return ap.parse_args()
 
 
@@ -132,6 +135,236 @@ def cpu_baseline(batch, chunks, params, pon, com, sample_mb):
     return out
 
 
+# ---------------------------------------------------------------------------------------
+# The SURVEY 8f rows, measured behind the headline on the single-GPU run (their own keys of the line; the headline's
+# keys stay what they are).  Each leg: inputs resident in HBM, device time from the library's hipEvents on its stream,
+# a roofline against the bytes the leg's design has to move, the oracle timed on a bounded sample beside it.
+
+NORM_ALT_ORDER = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+# algorithmic HBM bytes per read base of one normcounts pass: the qualities read by the read pass
+# (mean-quality filter, callable bits) and again by the sweep, the packed bases read by the sweep, the callable bit
+# written and read
+NORM_BYTES_PER_BASE = {"prepass": 1.0 + 1.0 / 8.0, "sweep": 1.0 + 0.5 + 1.0 / 8.0}
+
+
+def _prefix_batch(batch, end):
+    """The reads that start in front of reference position `end`, with the arrays cut to them."""
+    import numpy as np
+    from himut_amd.readbatch import ReadBatch
+    n = max(1, int(np.searchsorted(batch.tstart, end, side="left")))
+    tot = int(batch.qoff[n - 1] + ((int(batch.qlen[n - 1]) + 31) & ~31))
+    return n, ReadBatch(name=batch.name, length=batch.length, tstart=batch.tstart[:n], tend=batch.tend[:n],
+                        qstart=batch.qstart[:n], qlen=batch.qlen[:n], mapq=batch.mapq[:n], flag=batch.flag[:n],
+                        qid=batch.qid[:n], qoff=batch.qoff[:n], cs_off=batch.cs_off[:n + 1], seq=batch.seq[:tot // 2],
+                        bq=batch.bq[:tot], cs=batch.cs[:int(batch.cs_off[n])], tp=batch.tp[:n])
+
+
+def _pmc(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def leg_normcounts(ctx, sample, chunks, params, pon, com, steps, cpu=True, cpu_sample_mb=2.0):
+    """himut normcounts' per-contig worker (normcounts.py:206-421) on the resident contig: K passes of
+    himut_run_normcounts."""
+    import numpy as np
+    from himut_amd import normcounts
+    batch = sample.batch
+    refseq = bytes(sample.ref)
+    chars, cls = normcounts.tri_classes(refseq)
+    ctx.set_reference(refseq, cls, len(chars))
+    tab = normcounts.alt_order_table(NORM_ALT_ORDER)
+    ctx.set_stage_timing(2)
+    ctx.run_normcounts(tab)
+    ctx.run_normcounts(tab)
+    ms, pre, sweep = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run_normcounts(tab)
+        st = ctx.stats()
+        ms.append(st["ms_total"]); pre.append(st["ms_parse"] + st["ms_index"]); sweep.append(st["ms_eval"])
+    wall = (time.perf_counter() - t0) / steps
+    ctx.set_stage_timing(1)
+    st = ctx.stats()
+    ccs, ref, log = ctx.normcounts()
+    positions = sum(e - s for s, e in chunks)
+    dev_s, sweep_s = float(np.mean(ms)) * 1e-3, float(np.mean(sweep)) * 1e-3
+    rb = st["read_bases"]
+    by_pass = rb * (NORM_BYTES_PER_BASE["prepass"] + NORM_BYTES_PER_BASE["sweep"])
+    by_sweep = rb * NORM_BYTES_PER_BASE["sweep"]
+    t = _pmc("pmc_traffic_normcounts.json")
+    out = {"metric": "Mbp swept/sec at 30x CCS (himut normcounts callable-tricount sweep)", "unit": "Mbp/s",
+           "value": positions / 1e6 / wall, "ms_per_contig": wall * 1e3, "device_ms": dev_s * 1e3, "steps": steps,
+           "stage_ms": {"decode_and_read_pass": float(np.mean(pre)), "sweep": float(np.mean(sweep))},
+           "callable_bases": log[13], "num_bases": log[1], "positions": positions,
+           "roofline": {"bound": "hbm", "kernel": "the position sweep (k_norm_quad + k_norm_dirty)", "achieved": by_sweep / sweep_s / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_sweep / sweep_s / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": by_sweep, "avg_launch_ms": sweep_s * 1e3,
+                        "traffic": (t or {}).get("sweep_total"),
+                        "traffic_source": ("profiles/pmc_traffic_normcounts.json (" + str(t.get("collected")) + ")") if t else None},
+           "roofline_pass": {"bound": "hbm", "bytes_per_pass": by_pass, "achieved": by_pass / dev_s / 1e9,
+                             "frac": by_pass / dev_s / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "survey_convention_frac": rb * 5.5 / dev_s / 1e9 / HBM_PEAK_GBS,
+                             "note": "bytes_per_pass = read bases x ({prepass} + {sweep}) B (qualities twice, packed bases once, the "
+                                     "callable bit written and read); survey_convention = 5.5 B per read base (SURVEY 8d: "
+                                     "1.5 in, a 2-byte cell written and read), a throughput in the survey's unit".format(**NORM_BYTES_PER_BASE)}}
+    if cpu:
+        from oracle import oracle as O
+        nch = max(1, int(cpu_sample_mb * 1e6 / 200000))
+        sub_chunks = chunks[:nch]
+        n, sub = _prefix_batch(batch, sub_chunks[-1][1])
+        t1 = time.perf_counter()
+        O.normcounts(sub, sub_chunks, params, refseq, 1 / (10 ** 3), pon, com, alt_order=NORM_ALT_ORDER)
+        dt = time.perf_counter() - t1
+        span = sum(e - s for s, e in sub_chunks)
+        out["cpu_baseline"] = {"value": span / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "port",
+                               "sample": "first {} reference chunks ({:.1f} Mb, {} reads), oracle/himut_oracle.c "
+                                         "orc_normcounts single thread, {:.1f} s".format(nch, span / 1e6, n, dt)}
+    return out
+
+
+def leg_edges(ctx, sample, steps, cpu=True):
+    """himut phase's pair counting (phaselib.get_edges, phaselib.py:16-67) on the resident contig."""
+    import numpy as np
+    from himut_amd import phaselib
+    b = sample.batch
+    hets = sorted(set((int(p) + 1, chr(r), chr(al)) for p, r, al, g in zip(sample.snp_pos, sample.snp_ref, sample.snp_alt,
+                                                                             sample.snp_gt) if g in (1, 2)))
+    hpos = np.array([h[0] for h in hets], np.int32)
+    href = np.array([ord(h[1]) for h in hets], np.uint8)
+    band = phaselib.edge_band(b, hpos)
+    ctx.run_edges(hpos, href, 20, 20, band)
+    ms = []
+    for _ in range(steps):
+        counts = ctx.run_edges(hpos, href, 20, 20, band)
+        ms.append(ctx.stats()["ms_total"])
+    dev_s = float(np.mean(ms)) * 1e-3
+    pairs = int(counts.sum())
+    # bytes the design has to move: the cs text in and ~16 B per cs operation out (the decode), per usable (read, hetSNP)
+    # a 64-byte sector of bases and one of qualities, one 4-byte atomic per pair
+    nhits = int(np.sum(np.searchsorted(hpos, b.tend, side="right") - np.searchsorted(hpos, b.tstart, side="right")))
+    alg = float(b.cs.shape[0]) * 5.0 + nhits * 128.0 + pairs * 4.0
+    out = {"metric": "Mbp pair-counted/sec at 30x CCS (himut phase get_edges)", "unit": "Mbp/s",
+           "value": b.length / 1e6 / dev_s, "device_ms": dev_s * 1e3, "steps": steps, "hetsnps": len(hets), "band": int(band),
+           "pair_counts": pairs, "read_hetsnp_lookups": nhits,
+           "roofline": {"bound": "hbm", "kernel": "k_parse_cs + k_edges", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
+                        "avg_launch_ms": dev_s * 1e3, "traffic": None,
+                        "note": "scattered 64-byte sectors and atomics: bound by the random-access rate, not by bytes"}}
+    if cpu:
+        from oracle import oracle as O
+        n, sub = _prefix_batch(b, 8_000_000)
+        sh = [h for h in hets if h[0] < 8_100_000]
+        t0 = time.perf_counter()
+        O.edges(sub, sh, 20, 20)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": min(8.0, b.length / 1e6) / dt, "unit": "Mbp/s", "cores": 1, "kind": "port",
+                               "sample": "reads of the first 8 Mb ({}), oracle orc_edges single thread, {:.1f} s".format(n, dt)}
+    return out
+
+
+def leg_e2e(sample, device, repeat=2):
+    """BAM on disk -> VCF on disk for the same contig (the ingest in front of the path): host inflate into
+    pinned windows || H2D || device-side record parse, thresholds, the scan, records back, VCF text.  PCIe-inclusive: never
+    `value` of the headline."""
+    import tempfile
+    import threading
+    from himut_amd import bamio, bamlib, caller, synth, util as hutil, vcflib
+    name = sample.batch.name
+    runs = []
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "x.bam")
+        t0 = time.perf_counter()
+        bamio.write_bam(path, [sample.batch], sample="SMP")
+        com, pon = os.path.join(d, "c.vcf"), os.path.join(d, "p.vcf")
+        synth.write_common_snps_vcf(com, sample, seed=1)
+        synth.write_pon_vcf(pon, sample, seed=1)
+        t_write = time.perf_counter() - t0
+        for rep in range(repeat):
+            t = {}
+            w = caller.Worker(device)
+            ctx = w.ctx
+            t_all = time.perf_counter()
+            st = bamio.BamStream(path, 0)
+            t["open_s"] = time.perf_counter() - t_all
+            side = {}
+
+            def parse_side():
+                side["pk"] = caller.site_keys(vcflib.load_pon(name, pon))
+                side["ck"] = caller.site_keys(vcflib.load_common_snp(name, com))
+            th = threading.Thread(target=parse_side)
+            th.start()
+            t0 = time.perf_counter()
+            res = st.ingest_contig(ctx, name)
+            t["ingest_inflate_h2d_parse_s"] = time.perf_counter() - t0
+            th.join()
+            t0 = time.perf_counter()
+            chrom_lst, c2c = hutil.load_loci(None, None, st.tname2tsize)
+            ts, te, ql_, mq_, tp_ = ctx.ingest_read_meta(res["n_reads"])
+            starts = bamlib.sample_starts(chrom_lst, st.tname2tsize)
+            ql, qu, md = bamlib.thresholds_from_samples({name: bamlib.sample_qlens(ts, te, ql_, mq_, tp_, starts[name])}, chrom_lst)
+            t["thresholds_s"] = time.perf_counter() - t0
+            w.configure(30, 60, ql, qu, 0.99, 20, 93, 0.01, 0, 20, md, 3, 1, 3, 1e-3, False)
+            t0 = time.perf_counter()
+            ctx.set_chunks([(x[1], x[2]) for x in c2c[name]]); ctx.set_site_set(0, side["pk"]); ctx.set_site_set(1, side["ck"])
+            ctx.run()
+            t["first_run_s"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            recs = ctx.records()
+            t["d2h_s"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            vcflib.dump_records(os.path.join(d, "o.vcf"), "#HEADER", [name], {name: recs}, False)
+            t["format_write_s"] = time.perf_counter() - t0
+            t["end_to_end_s"] = time.perf_counter() - t_all
+            t["records"] = int(len(recs))
+            t["inflated_GB_per_s"] = (res["bases_padded"] * 1.5 + res["cs_bytes"]) / 1e9 / t["ingest_inflate_h2d_parse_s"]
+            w.close()
+            st.close()
+            runs.append(t)
+        bam_mb = os.path.getsize(path) / 1e6
+    best = min(runs, key=lambda r: r["end_to_end_s"])
+    return {"metric": "Mbp/sec, BAM on disk -> VCF on disk (himut call, one contig)", "unit": "Mbp/s",
+            "value": sample.batch.length / 1e6 / best["end_to_end_s"], "best_of": repeat, "stages_s": best,
+            "first_in_process": runs[0]["end_to_end_s"], "bam_MB": bam_mb, "bam_write_s_untimed": t_write,
+            "host_threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+            "note": "PCIe- and inflate-inclusive; the host's BGZF inflate is the floor (DESIGN.md section 11)"}
+
+
+def run_legs(out, legs, a, ctx, w, sample, chunks, params, pon, com, device):
+    """The 8f legs under one watchdog: a leg that raises is reported in its key; a leg that hangs ends the process with the
+    line printed and a non-zero exit code."""
+    import threading
+
+    def give_up():
+        out.setdefault("legs_error", "the legs did not finish within {:.0f} s".format(a.legs_limit_s))
+        emit_line(out)
+        os._exit(3)
+    timer = threading.Timer(a.legs_limit_s, give_up)
+    timer.daemon = True
+    timer.start()
+    cpu = not a.no_cpu_baseline
+    steps = max(3, min(a.steps, 10))
+    for leg in legs:
+        t0 = time.perf_counter()
+        try:
+            if leg == "normcounts":
+                r = leg_normcounts(ctx, sample, chunks, params, pon, com, steps, cpu)
+            elif leg == "edges":
+                r = leg_edges(ctx, sample, steps, cpu)
+            elif leg == "e2e":
+                w.close()               # (the leg makes its own contexts: a real call starts from the file)
+                r = leg_e2e(sample, device)
+            else:
+                r = {"error": "unknown leg"}
+        except Exception as e:          # noqa: BLE001 -- reported in the line, the headline stands
+            r = {"error": "{}: {}".format(type(e).__name__, e)}
+        r["leg_wall_s"] = time.perf_counter() - t0
+        out[leg] = r
+    timer.cancel()
+
+
 def emit_line(out):
     """The one JSON line, on the process's real stdout (see main)."""
     os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
@@ -173,7 +406,8 @@ def main():
     t_gen = time.perf_counter()
     names = ["chr{}".format(20 + k) for k in range(world)]   # one chr20-sized contig per rank
     cfg = synth.SynthConfig(seed=2 + rank, contig_len=a.contig_len, depth=a.depth, name=names[rank])
-    sample = synth.generate(cfg)
+    legs = [x for x in a.legs.split(",") if x] if world == 1 else []
+    sample = synth.generate(cfg, want_ref="normcounts" in legs)
     batch = batch_keep = sample.batch
     chunks = [(c[1], c[2]) for c in hutil.chunkloci((batch.name, 0, batch.length))]
     ql, qu, md = bamlib.get_thresholds({batch.name: batch}, [batch.name], {batch.name: batch.length})
@@ -339,6 +573,9 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:           # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(batch, chunks, params, pon, com, a.cpu_sample_mb)
+        if legs:
+            run_legs(out, legs, a, ctx, w, sample, chunks, params, pon, com, local_rank)
+            w = None if "e2e" in legs else w
 
     # ---- BASELINE configs[2]: the whole synthetic GRCh38, strong scaling (N > 1; HIMUT_BENCH_GENOME=1 forces it on
     # one rank, HIMUT_BENCH_GENOME_SCALE divides the contig lengths for rehearsals).  It runs behind the headline
@@ -356,7 +593,7 @@ def main():
             if rank == 0:
                 out["genome_strong"] = {"error": why}
                 emit_line(out)
-            os._exit(0)         # (the other ranks may sit in a collective: no teardown)
+            os._exit(3)         # (the other ranks may sit in a collective: no teardown; non-zero: the run record shows it)
         timer = threading.Timer(limit, give_up, args=("the genome leg did not finish within {:.0f} s".format(limit),))
         timer.daemon = True
         timer.start()

@@ -1469,7 +1469,11 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     if (c->timing >= 2) {   // recorded by run_parse_stage only then (an unrecorded event leaves a sticky HIP error)
         (void)hipEventElapsedTime(&f, c->ev[EV_START], c->ev[EV_PARSE]);
         c->stats.ms_parse = (double)f;
+        (void)hipEventElapsedTime(&f, c->ev[EV_PARSE], c->ev[EV_EMIT]);
+        c->stats.ms_index = (double)f;      // the read pass: filters, callable bits, window index
     }
+    (void)hipEventElapsedTime(&f, c->ev[EV_EMIT], c->ev[EV_FINAL]);
+    c->stats.ms_eval = (double)f;           // the position sweep
     c->stats.n_reads = c->n; c->stats.read_bases = c->read_bases; c->stats.positions = T.positions;
     c->stats.column_slots = slots_total;
     c->have_norm = true;
