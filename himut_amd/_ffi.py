@@ -54,7 +54,7 @@ EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_err
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
            "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing", "himut_sbs96_counts", "himut_ingest_begin", "himut_ingest_buffer",
            "himut_ingest_wait", "himut_ingest_window", "himut_ingest_end", "himut_ingest_read_meta", "himut_download_reads",
-           "himut_inflate_blocks", "himut_run_begin", "himut_run_end"]
+           "himut_inflate_blocks", "himut_run_begin", "himut_run_end", "himut_debug_normcounts"]
 
 _lib = None
 
@@ -273,6 +273,10 @@ class Context:
     def run_normcounts(self, alt_order, non_human_sample=False):
         tab = np.ascontiguousarray(alt_order, np.uint8).reshape(12)
         self._check(self._L.himut_run_normcounts(self._h, _ptr(tab), 1 if non_human_sample else 0))
+
+    def debug_normcounts(self, sweep=0, dirty_cap=0, pool_slots=0):
+        """Test hook (himut_debug_normcounts): which sweep, the capacity of a part of the left-over list, pool slots."""
+        self._check(self._L.himut_debug_normcounts(self._h, int(sweep), ctypes.c_int64(int(dirty_cap)), int(pool_slots)))
 
     def normcounts(self):
         k3 = self._n_classes ** 3

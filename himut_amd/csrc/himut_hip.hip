@@ -19,6 +19,7 @@
 #include "himut_hip.h"
 #include "himut_kernels.h"
 #include "himut_norm.h"
+#include "himut_normq.h"
 #include "himut_ingest.h"
 #include "himut_inflate_wave.h"
 
@@ -124,7 +125,9 @@ struct himut_ctx {
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2, d_logpart;
     // normcounts
-    DevBuf d_refseq, d_live, d_callable, d_cq, d_dirty, d_dcount, d_tri;
+    DevBuf d_refseq, d_live, d_callable, d_dirty, d_dcount, d_redo, d_plan, d_plancnt, d_tri;
+    int dbg_norm_sweep = 0, dbg_norm_pool = 0;     // himut_debug_normcounts (tests)
+    int64_t dbg_norm_dirty_cap = 0;
     int64_t reflen = 0;
     uint8_t ref_cls[256] = {};
     int ref_K = 0;
@@ -168,9 +171,10 @@ struct Scalars {
     unsigned long long nccs;
     unsigned long long log[16];
     int err;
-    int qhigh;               // normcounts: a base quality of 128 or more was seen (k_callable)
-    int dirty_over;          // normcounts: k_norm_col left more positions to k_norm_dirty than a part of the list holds
-    int pad[21];             // 256 bytes: one aligned fill clears it
+    int qhigh;               // (unused)
+    int dirty_over;          // normcounts: k_norm_quad left more positions to k_norm_dirty than a part of the list holds
+    unsigned int nredo;      // normcounts: tiles k_norm_quad left to k_norm_tile
+    int pad[20];             // 256 bytes: one aligned fill clears it
 };
 static_assert(sizeof(Scalars) == 256, "Scalars is cleared with one aligned fill");
 
@@ -1303,20 +1307,26 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     c->d_live.reserve((size_t)c->n + 64);
     const size_t cwords = (size_t)(c->bq_bytes >> 5) + 64;
     c->d_callable.reserve(cwords * 4);
-    // HIMUT_NORM_SWEEP: "tile" = cells built in LDS by the workgroup (round 2's kernel), "store" = the older sweep through a
-    // column store in HBM (capture + evaluate, in passes); otherwise a wave per 64 columns, no cells in LDS
-    const char* sweep = getenv("HIMUT_NORM_SWEEP");
-    const bool sweep_store = !force_tile && sweep && strcmp(sweep, "store") == 0;
-    const bool sweep_tile = force_tile || (sweep && strcmp(sweep, "tile") == 0);
-    const bool sweep_col = !sweep_store && !sweep_tile;
-    // the positions k_norm_col leaves to k_norm_dirty (a column with another allele: one in thirty): room for one in eight,
-    // in NORM_DIRTY_REGIONS parts that the workgroups are dealt over
-    int64_t dirty_cap = std::max<int64_t>(T.positions / 8 / NORM_DIRTY_REGIONS, 256);
-    if (const char* e = getenv("HIMUT_NORM_DIRTY_CAP")) dirty_cap = std::max<int64_t>(atoll(e), 1);   // (tests: the overflow path)
-    if (sweep_col) {
-        c->d_cq.reserve((size_t)c->bq_bytes + 256);                  // quality | callable << 7 per base
-        c->d_dirty.reserve((size_t)dirty_cap * NORM_DIRTY_REGIONS * sizeof(NormDirty) + 256);
-        c->d_dcount.reserve((size_t)NORM_DIRTY_REGIONS * 128);
+    // the sweep: k_norm_quad (a wave per 256 columns), k_norm_dirty for the positions it lists, k_norm_tile for the tiles it
+    // lists; the whole contig with k_norm_tile when one of the two lists was too short (force_tile), or when a test asks
+    const bool sweep_tile = force_tile || c->dbg_norm_sweep == 1;
+    const bool sweep_quad = !sweep_tile;
+    // the sweep's grid (workgroups of NQ_WAVES waves, a wave per 256 positions; NQ_Q workgroups per XCD class and chunk),
+    // and the list of the positions k_norm_quad leaves to k_norm_dirty (a column with another allele: one in thirty): a part
+    // per workgroup, room for one of its positions in six
+    int32_t maxspan = 1;
+    for (size_t k = 0; k < c->cstart.size(); k++) maxspan = std::max(maxspan, c->cend[k] - c->cstart[k]);
+    const int64_t q_per = ((int64_t)blocks_for(maxspan, NQ_WG_COLS) + 7) / 8;             // workgroup tiles of a chunk per XCD class
+    const unsigned q_gx = 8u * (unsigned)std::min<int64_t>(NQ_Q, q_per);
+    const int64_t q_regions = (int64_t)q_gx * (int64_t)std::max<int64_t>(T.n, 1);
+    const int64_t q_tiles_per_wg = (q_per + (q_gx / 8) - 1) / (q_gx / 8);
+    int64_t dirty_cap = std::max<int64_t>(q_tiles_per_wg * NQ_WG_COLS / 6, 128);
+    if (c->dbg_norm_dirty_cap > 0) dirty_cap = c->dbg_norm_dirty_cap;           // (tests: the overflow path)
+    const unsigned redo_cap = (unsigned)std::min<int64_t>(T.positions / NQ_COLS / 16 + 1024, 1 << 24);   // tiles left to k_norm_tile: room for one in sixteen
+    if (sweep_quad) {
+        c->d_dirty.reserve((size_t)dirty_cap * (size_t)q_regions * sizeof(NormDirty) + 256);
+        c->d_dcount.reserve((size_t)q_regions * 4 + 256);
+        c->d_redo.reserve((size_t)redo_cap * sizeof(NormRedo) + 256);
     }
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
@@ -1324,8 +1334,6 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
     HCHECK(hipMemsetAsync(c->d_tri.p, 0, (2 * ntri + 16) * 8, st));
     // (d_callable is not cleared: k_callable writes the words of every read)
-    if (sweep_col) HCHECK(hipMemsetAsync(c->d_dcount.p, 0, (size_t)NORM_DIRTY_REGIONS * 128, st));
-    if (sweep_col && getenv("HIMUT_DEBUG_FILL_CQ")) HCHECK(hipMemsetAsync(c->d_cq.p, 0, (size_t)c->bq_bytes + 256, st));   // (a base whose byte k_callable did not write shows as a zero quality)
     if (c->n > 0) run_parse_stage(c, R, D, sc);   // (the quality sums are k_callable's)
     else stage_event(c, EV_PARSE, 2, st);
     int32_t maxend = 0;
@@ -1338,8 +1346,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
                            c->d_live.as<uint8_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
         // (k_callable takes the reads with a low mean quality out of `live`: before the phased runs' count of the reads)
         hipLaunchKernelGGL(k_callable, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, c->d_live.as<uint8_t>(),
-                           c->d_callable.as<uint32_t>(), sweep_col ? c->d_cq.as<uint8_t>() : (uint8_t*)nullptr, &sc->qhigh,
-                           c->d_ccs.as<uint8_t>());
+                           c->d_callable.as<uint32_t>(), (uint8_t*)nullptr, &sc->qhigh, c->d_ccs.as<uint8_t>());
         if (phase && T.npairs > 0) {
             hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
             hipLaunchKernelGGL(k_pair_ccs, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, C, H, R, c->d_live.as<uint8_t>(),
@@ -1349,21 +1356,6 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
                            c->d_winhi.as<int32_t>());
     }
     HCHECK(hipEventRecord(c->ev[EV_EMIT], st));
-
-    int32_t maxpos = c->h_prefmax.empty() ? 0 : c->h_prefmax.back();
-    maxpos = std::max(maxpos, maxend);
-    const int64_t nwords = ((int64_t)maxpos >> 5) + 2;
-    c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
-    c->d_posrank.reserve((size_t)(nwords + 2) * 4 + 256);
-    c->d_poppc.reserve((size_t)(nwords + 2) * 4 + 256);
-    c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
-    c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);
-    size_t scan2 = 0, scan3 = 0;
-    HCHECK(rocprim::exclusive_scan(nullptr, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
-                                   (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
-    HCHECK(rocprim::exclusive_scan(nullptr, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
-                                   (size_t)nblk, rocprim::plus<uint32_t>(), st));
-    c->d_tmp2.reserve(std::max(scan2, scan3) + 256);
 
     NormArgs A;
     A.P = c->params;
@@ -1378,78 +1370,40 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     A.non_human = non_human;
     A.ccs_tri = c->d_tri.as<unsigned long long>(); A.ref_tri = A.ccs_tri + ntri; A.log = A.ccs_tri + 2 * ntri;
     A.err = &sc->err;
-    int32_t maxspan = 1;
-    for (size_t k = 0; k < c->cstart.size(); k++) maxspan = std::max(maxspan, c->cend[k] - c->cstart[k]);
-    const unsigned ex = blocks_for(maxspan, 256 * NE_TILES);
-
-    int64_t slots_total = 0;
-    if (c->n > 0 && T.n > 0 && !sweep_store) {
+    if (c->n > 0 && T.n > 0) {
         A.X = PosIndex{}; A.colstore = nullptr; A.p_lo = 0; A.p_hi = 0;
-        const int64_t per = ((int64_t)blocks_for(maxspan, 256) + 7) / 8;          // tiles of a chunk per XCD class: see the tile mapping
-        const dim3 grid(8u * (unsigned)std::min<int64_t>(NT_Q, per), (unsigned)T.n);
-        if (sweep_col) {
-            const int64_t per = ((int64_t)blocks_for(maxspan, NC_THREADS) + 7) / 8;
-            const dim3 grid(8u * (unsigned)std::min<int64_t>(NC_Q, per), (unsigned)T.n);
-            if (phase) hipLaunchKernelGGL(k_norm_col<true>, grid, dim3(NC_THREADS), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
-                                          c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per, c->d_dirty.as<NormDirty>(),
-                                          c->d_dcount.as<unsigned long long>(), dirty_cap, &sc->dirty_over);
-            else hipLaunchKernelGGL(k_norm_col<false>, grid, dim3(NC_THREADS), 0, st, A, D, c->d_cq.as<uint8_t>(), &sc->qhigh,
-                                    c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, per, c->d_dirty.as<NormDirty>(),
-                                    c->d_dcount.as<unsigned long long>(), dirty_cap, &sc->dirty_over);
-            hipLaunchKernelGGL(k_norm_dirty, dim3(8, NORM_DIRTY_REGIONS), dim3(256), 0, st, A, c->d_dirty.as<NormDirty>(),
-                               c->d_dcount.as<unsigned long long>(), dirty_cap);
-        }
-        // (behind k_norm_col it runs only for a contig with a base quality of 128 or more, which that kernel leaves alone)
-        hipLaunchKernelGGL(k_norm_tile, grid, dim3(256), 0, st, A, D, c->d_callable.as<uint32_t>(), c->d_winlo.as<int32_t>(),
-                           c->d_winhi.as<int32_t>(), nblk, per, sweep_col ? &sc->qhigh : (const int*)nullptr);
-    } else if (c->n > 0 && T.n > 0) {
-        for (int64_t p_lo = 0; p_lo < (int64_t)maxend; p_lo += NORM_PASS) {
-            const int64_t p_hi = std::min<int64_t>(p_lo + NORM_PASS, maxend);
-            bool any = false;
-            for (size_t k = 0; k < c->cstart.size() && !any; k++) any = c->cstart[k] < p_hi && c->cend[k] > p_lo;
-            if (!any) continue;
-            // ones at the chunk positions of the pass, rank, per-block windows and slot offsets
-            HCHECK(hipMemsetAsync(c->d_posbits_c.p, 0, (size_t)(nwords + 2) * 4, st));
-            hipLaunchKernelGGL(k_fill_bits, dim3(blocks_for((p_hi - p_lo + 31) / 32 + 1, 256)), dim3(256), 0, st, C, p_lo, p_hi,
-                               c->d_posbits_c.as<uint32_t>(), nwords);
-            hipLaunchKernelGGL(k_word_popc, dim3(blocks_for(nwords + 1, 256)), dim3(256), 0, st, c->d_posbits_c.as<uint32_t>(),
-                               nwords + 1, c->d_poppc.as<uint32_t>());
-            HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan2, c->d_poppc.as<uint32_t>(), c->d_posrank.as<uint32_t>(), 0u,
-                                           (size_t)(nwords + 1), rocprim::plus<uint32_t>(), st));
-            HCHECK(hipMemsetAsync(&sc->reserved0, 0, 8, st));
-            hipLaunchKernelGGL(k_block_slots, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
-                               c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), nblk, c->d_blkslots.as<uint32_t>(),
-                               &sc->reserved0);
-            HCHECK(rocprim::exclusive_scan(c->d_tmp2.p, scan3, c->d_blkslots.as<uint32_t>(), c->d_blkoff.as<uint32_t>(), 0u,
-                                           (size_t)nblk, rocprim::plus<uint32_t>(), st));
-            hipLaunchKernelGGL(k_block_table, dim3(blocks_for(nblk, 256)), dim3(256), 0, st, c->d_posrank.as<uint32_t>(), nwords,
-                               c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(), c->d_blkoff.as<uint32_t>(), nblk,
-                               c->d_blktab.as<BlockTab>(), (int*)nullptr);
-            uint32_t last_off = 0, last_n = 0;
-            unsigned long long hs_total = 0;
-            HCHECK(hipMemcpyAsync(&last_off, c->d_blkoff.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
-            HCHECK(hipMemcpyAsync(&last_n, c->d_blkslots.as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
-            HCHECK(hipMemcpyAsync(&hs_total, &sc->reserved0, 8, hipMemcpyDeviceToHost, st));
-            HCHECK(hipStreamSynchronize(st));
-            const size_t nslots = (size_t)last_off + last_n;
-            const int64_t rb = std::upper_bound(c->h_prefmax.begin(), c->h_prefmax.end(), (int32_t)p_lo) - c->h_prefmax.begin();
-            const int64_t re = std::lower_bound(c->h_tstart.begin(), c->h_tstart.end(), (int32_t)p_hi) - c->h_tstart.begin();
-            if (hs_total != (unsigned long long)nslots)
-                return fail(c, HIMUT_ERR_ARG, "normcounts: pile too deep for one pass (more than 2^32 column slots)");
-            slots_total += (int64_t)nslots;
-            c->d_colstore.reserve(nslots * 2 + 256);
-            if (nslots) HCHECK(hipMemsetD16Async(c->d_colstore.p, (unsigned short)CELL_EMPTY, nslots, st));
-            PosIndex X;
-            X.bits = c->d_posbits_c.as<uint32_t>(); X.rank = c->d_posrank.as<uint32_t>(); X.nwords = nwords;
-            X.bt = c->d_blktab.as<BlockTab>(); X.nblk = nblk;
-            CaptureArgs G;
-            G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)nslots;
-            G.r_begin = rb; G.r_end = std::max(rb, re); G.callable = c->d_callable.as<uint32_t>(); G.bqsum = nullptr; G.err = &sc->err; G.mask = nullptr; G.tilecnt = nullptr; G.ccs_flag = nullptr;
-            G.C = C; G.H = H; G.P = c->params;
-            if (re > rb)
-                hipLaunchKernelGGL(k_stream_capture<true>, dim3(blocks_for(re - rb, 4)), dim3(256), 0, st, G);
-            A.X = X; A.colstore = c->d_colstore.as<uint16_t>(); A.p_lo = p_lo; A.p_hi = p_hi;
-            hipLaunchKernelGGL(k_norm_eval, dim3(ex, (unsigned)T.n), dim3(256), 0, st, A);
+        if (sweep_quad) {
+            // the plan: which pieces of which reads lie over each tile of 256 positions (k_norm_plan), then the sweep
+            const int64_t tpc = (int64_t)blocks_for(maxspan, NQ_COLS);                  // tiles per chunk (the plan's stride)
+            c->d_plan.reserve((size_t)T.n * (size_t)tpc * NQ_ITEMS * sizeof(NqItem) + 256);
+            c->d_plancnt.reserve((size_t)T.n * (size_t)tpc * 4 + 256);
+            const dim3 pgrid((unsigned)blocks_for(tpc, 4), (unsigned)T.n);
+            if (phase) hipLaunchKernelGGL(k_norm_plan<true>, pgrid, dim3(256), 0, st, A, D, c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(),
+                                          nblk, tpc, c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), c->d_redo.as<NormRedo>(),
+                                          &sc->nredo, redo_cap);
+            else hipLaunchKernelGGL(k_norm_plan<false>, pgrid, dim3(256), 0, st, A, D, c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(),
+                                    nblk, tpc, c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), c->d_redo.as<NormRedo>(),
+                                    &sc->nredo, redo_cap);
+            const dim3 grid(q_gx, (unsigned)T.n);
+            const unsigned pool_limit = c->dbg_norm_pool > 0 ? (unsigned)std::min(c->dbg_norm_pool, NQ_SLOTS) : (unsigned)NQ_SLOTS;
+            if (phase) hipLaunchKernelGGL(k_norm_quad<true>, grid, dim3(NQ_WAVES * 64), 0, st, A, c->d_callable.as<uint32_t>(), (int64_t)c->bq_bytes,
+                                          c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), tpc, q_per, c->d_dirty.as<NormDirty>(),
+                                          c->d_dcount.as<uint32_t>(), dirty_cap, &sc->dirty_over, c->d_redo.as<NormRedo>(),
+                                          &sc->nredo, redo_cap, pool_limit);
+            else hipLaunchKernelGGL(k_norm_quad<false>, grid, dim3(NQ_WAVES * 64), 0, st, A, c->d_callable.as<uint32_t>(), (int64_t)c->bq_bytes,
+                                    c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), tpc, q_per, c->d_dirty.as<NormDirty>(),
+                                    c->d_dcount.as<uint32_t>(), dirty_cap, &sc->dirty_over, c->d_redo.as<NormRedo>(),
+                                    &sc->nredo, redo_cap, pool_limit);
+            hipLaunchKernelGGL(k_norm_dirty, dim3((unsigned)std::min<int64_t>(blocks_for(q_regions, 4), 16384)), dim3(256), 0, st, A,
+                               c->d_dirty.as<NormDirty>(), c->d_dcount.as<uint32_t>(), dirty_cap, q_regions);
+            // (returns at once unless a tile was listed)
+            hipLaunchKernelGGL(k_norm_tile, dim3(1024), dim3(256), 0, st, A, D, c->d_callable.as<uint32_t>(), c->d_winlo.as<int32_t>(),
+                               c->d_winhi.as<int32_t>(), nblk, (int64_t)0, c->d_redo.as<NormRedo>(), &sc->nredo, redo_cap);
+        } else {
+            const int64_t per = ((int64_t)blocks_for(maxspan, 256) + 7) / 8;
+            const dim3 grid(8u * (unsigned)std::min<int64_t>(NT_Q, per), (unsigned)T.n);
+            hipLaunchKernelGGL(k_norm_tile, grid, dim3(256), 0, st, A, D, c->d_callable.as<uint32_t>(), c->d_winlo.as<int32_t>(),
+                               c->d_winhi.as<int32_t>(), nblk, per, (const NormRedo*)nullptr, (const unsigned int*)nullptr, 0u);
         }
     }
     if (c->n > 0 && T.n > 0)
@@ -1460,7 +1414,9 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     HCHECK(hipMemcpyAsync(c->h_tri.data(), c->d_tri.p, (2 * ntri + 16) * 8, hipMemcpyDeviceToHost, st));
     HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
     HCHECK(hipStreamSynchronize(st));
-    if (hs.dirty_over && !force_tile) return do_normcounts(c, alt_order, non_human, true);   // (the list of left-over positions was too short)
+    // one of the two lists was too short: the whole contig again with k_norm_tile
+    if ((hs.dirty_over || hs.nredo > redo_cap) && !force_tile) return do_normcounts(c, alt_order, non_human, true);
+    c->stats.reran = force_tile ? 1 : 0;
     if (hs.err) return check_device_err(c, hs.err);
     c->h_tri[2 * ntri + 0] = hs.nccs;
     float f = 0;
@@ -1475,7 +1431,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     (void)hipEventElapsedTime(&f, c->ev[EV_EMIT], c->ev[EV_FINAL]);
     c->stats.ms_eval = (double)f;           // the position sweep
     c->stats.n_reads = c->n; c->stats.read_bases = c->read_bases; c->stats.positions = T.positions;
-    c->stats.column_slots = slots_total;
+    c->stats.column_slots = hs.nredo;        // (normcounts: tiles k_norm_quad left to k_norm_tile)
     c->have_norm = true;
     return HIMUT_OK;
 }
@@ -1588,6 +1544,12 @@ int himut_sbs96_counts(himut_ctx* c, const int32_t* pos0, const uint8_t* ref, co
 int himut_run_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human_sample) {
     if (!c || !alt_order) return HIMUT_ERR_ARG;
     return guarded(c, [&]() -> int { return do_normcounts(c, alt_order, non_human_sample); });
+}
+
+int himut_debug_normcounts(himut_ctx* c, int sweep, int64_t dirty_cap, int pool_slots) {
+    if (!c || sweep < 0 || sweep > 1 || dirty_cap < 0 || pool_slots < 0) return HIMUT_ERR_ARG;
+    c->dbg_norm_sweep = sweep; c->dbg_norm_dirty_cap = dirty_cap; c->dbg_norm_pool = pool_slots;
+    return HIMUT_OK;
 }
 
 int himut_get_normcounts(himut_ctx* c, int64_t* ccs_tri, int64_t* ref_tri, int64_t log[14]) {

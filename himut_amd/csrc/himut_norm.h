@@ -6,26 +6,22 @@
 // more bit: "this base counts as callable for its read" (update_tri2count, normcounts.py:66-110).
 //
 //   k_read_live    sixteen lanes per read: the read filters but the mean quality (normcounts.py:302-309), cs-vs-SEQ check
-//   k_callable     wave per read: one bit per query base (the mismatch-window / trim / BQ rules), and a byte per base,
-//                  quality | bit << 7; the mean-quality filter (it reads every quality anyway), num_ccs
-//   k_norm_col     the sweep in use: a wave per 64 positions, a lane per column, no cells in memory; classifies the
-//                  columns that hold nothing but the reference allele, lists the others
+//   k_callable     wave per read: one bit per query base (the mismatch-window / trim / BQ rules); the mean-quality filter
+//                  (it reads every quality anyway), num_ccs
+//   k_norm_plan, k_norm_quad (himut_normq.h)
+//                  the sweep in use: per 256 positions the list of the reads' gapless pieces over them, then a wave per 256
+//                  positions, four columns per lane, no cells in memory; classifies the columns that hold nothing but the
+//                  reference allele, lists the others
 //   k_norm_dirty   lane per listed position: the general classification (ten PLs twice, PoN / common look-ups)
-//   k_norm_tile    round 2's first sweep (HIMUT_NORM_SWEEP=tile, and behind k_norm_col for a contig with a quality of 128
-//                  or more): workgroup per 256-position tile of a chunk, the cells of the reads over the tile built in
-//                  LDS, 48 rows at a time, every thread down its column
-//   k_fill_bits, k_stream_capture<true>, k_norm_eval
-//                  the earliest sweep (HIMUT_NORM_SWEEP=store): the position bitmap is all ones inside the chunks,
-//                  the capture kernel transposes every (read, position) cell into the read-major column store in
-//                  HBM, in passes of NORM_PASS positions, and k_norm_eval (thread per (chunk, position)) reads it
-//                  back.  Kept for comparison; all of them evaluate a position with the same text (NORM_* macros).
+//   k_norm_tile    round 2's first sweep: workgroup per 256-position tile of a chunk, the cells of the reads over the tile
+//                  built in LDS, 48 rows at a time, every thread down its column.  It takes the tiles k_norm_quad leaves
+//                  alone (from a list) and the whole contig when a list was too short; all of them evaluate a position with
+//                  the same text (NORM_* macros).
 #pragma once
 
 #include "himut_kernels.h"
 
 namespace himut {
-
-constexpr int64_t NORM_PASS = (int64_t)8 << 20;   // reference positions per pass (multiple of 256)
 
 // ---------------------------------------------------------------------------------------
 // phased runs: a read counts in a chunk only if it carries haplotype 0 or 1 there (normcounts.py:293-298)
@@ -338,23 +334,6 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
 }
 
 // ---------------------------------------------------------------------------------------
-// ones at the positions of [p_lo, p_hi) that lie in some chunk [start, end)
-__global__ void __launch_bounds__(256) k_fill_bits(Chunks C, int64_t p_lo, int64_t p_hi, uint32_t* bits, int64_t nwords) {
-    const int64_t w = (p_lo >> 5) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwords || w * 32 >= p_hi) return;
-    const int64_t a = max(w * 32, p_lo), b = min(w * 32 + 32, p_hi);
-    uint32_t m = 0;
-    // chunks with start < b, newest first, while the running maximum of end can still reach a
-    int64_t lo = 0, hi = C.n;
-    while (lo < hi) { const int64_t k = (lo + hi) >> 1; if (C.rec[k].start < b) lo = k + 1; else hi = k; }
-    for (int64_t j = lo - 1; j >= 0 && C.rec[j].pmaxend > a; j--) {
-        const int64_t s = max((int64_t)C.rec[j].start, a), e = min((int64_t)C.rec[j].end, b);
-        if (s < e) m |= (uint32_t)(((1ULL << (e - s)) - 1ULL) << (s - w * 32));
-    }
-    bits[w] = m;
-}
-
-// ---------------------------------------------------------------------------------------
 struct NormArgs {
     Params P;
     SiteSets S;
@@ -378,9 +357,8 @@ struct NormArgs {
     int* err;
 };
 
-// The per-position state, the per-cell update and the classification of a position are shared by the two sweeps
-// (k_norm_eval over the column store, k_norm_tile over cells built in LDS) as text, so that both compile to the same
-// register-resident code (normcounts.py:243-402; comments in k_norm_eval's history: gtlib.py:72-174 for the sums).
+// The per-position state and the classification of a position are shared by k_norm_tile and k_norm_dirty as text, so that
+// both compile to the same register-resident code (normcounts.py:243-402; gtlib.py:72-174 for the sums).
 #define NORM_POS_STATE() \
         uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}; \
         double S[3][4]; \
@@ -390,82 +368,6 @@ _Pragma("unroll") \
         uint32_t nref = 0; \
         uint32_t tri_sum = 0, h0 = 0, h1 = 0; \
         bool bq0 = false;
-
-#define NORM_CELL(V, HP) \
-            { \
-                const uint32_t q_ = (V) >> 8; \
-                NORM_CELL_L(V, HP, s_lut[q_], s_lut[256 + q_], s_lut[512 + q_]) \
-            }
-
-#define NORM_CELL_L(V, HP, VH, VT, VE) \
-            { \
-                const uint32_t cell = (V) & 7u; \
-                if ((V) & CELL_INS) cnt[4]++; \
-                if (cell < 4) { \
-                    const uint32_t q = (V) >> 8; \
-                    if (q == 0) bq0 = true; \
-                    const double vh = (VH), vt = (VT), ve = (VE); \
-                    if ((int)cell == ref) { \
-                        nref++; \
-                        R0 = R0 + vh; R1 = R1 + vt; R2 = R2 + ve; \
-                    } else { \
-_Pragma("unroll") \
-                        for (int b = 0; b < 4; b++) { \
-                            if ((int)cell == b) { \
-                                cnt[b]++; \
-                                S[0][b] = S[0][b] + vh; \
-                                S[1][b] = S[1][b] + vt; \
-                                S[2][b] = S[2][b] + ve; \
-                            } \
-                        } \
-                    } \
-                    uint32_t counts_here = ((V) >> 4) & 1u; \
-                    if (phase) { \
-                        const uint32_t hp = (HP); \
-                        if (hp == HAP_0) h0++; else if (hp == HAP_1) h1++; else counts_here = 0; \
-                    } \
-                    tri_sum += counts_here; \
-                } else if (cell == CELL_DEL) cnt[5]++; \
-                else if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE; \
-            }
-
-// The same update without a branch on the common path (the tile sweep's inner loop): a cell that is skipped or is
-// not the reference allele adds +0.0 to the reference allele's sums, which leaves them bit for bit as they were (they
-// start at +0.0 and only negative terms are added, so they are never -0.0); the other alleles, rare, keep the branch.
-#define NORM_CELL_BF(V, USE, HP, VH, VT, VE) \
-            { \
-                const uint32_t cell = (V) & 7u; \
-                const bool use_ = (USE); \
-                const bool base_ = use_ && cell < 4; \
-                const bool isref_ = base_ && (int)cell == ref; \
-                cnt[4] += (use_ && ((V) & CELL_INS)) ? 1u : 0u; \
-                cnt[5] += (use_ && cell == CELL_DEL) ? 1u : 0u; \
-                const uint32_t q = (V) >> 8; \
-                bq0 = bq0 || (base_ && q == 0); \
-                nref += isref_ ? 1u : 0u; \
-                const double vh = (VH), vt = (VT), ve = (VE); \
-                R0 = R0 + (isref_ ? vh : 0.0); R1 = R1 + (isref_ ? vt : 0.0); R2 = R2 + (isref_ ? ve : 0.0); \
-                if (use_ && !isref_ && cell <= CELL_OTHER) {        /* rare: another allele, or a base outside ATGC */ \
-                    if (cell == CELL_OTHER) bad |= 1 << HIMUT_ERR_BASE; \
-_Pragma("unroll") \
-                    for (int b = 0; b < 4; b++) { \
-                        if ((int)cell == b) { \
-                            cnt[b]++; \
-                            S[0][b] = S[0][b] + vh; \
-                            S[1][b] = S[1][b] + vt; \
-                            S[2][b] = S[2][b] + ve; \
-                        } \
-                    } \
-                } \
-                uint32_t counts_here = base_ ? (((V) >> 4) & 1u) : 0u; \
-                if (phase) { \
-                    const uint32_t hp = (HP); \
-                    h0 += (base_ && hp == HAP_0) ? 1u : 0u; \
-                    h1 += (base_ && hp == HAP_1) ? 1u : 0u; \
-                    if (hp != HAP_0 && hp != HAP_1) counts_here = 0; \
-                } \
-                tri_sum += counts_here; \
-            }
 
 // The tile sweep's form of the update.  (TH, TT, TE) are the table values of the cell's quality if the cell is the
 // reference allele and +0.0 otherwise (the caller reads entry 256, a zero row, for those), so the reference allele's
@@ -639,63 +541,6 @@ _Pragma("unroll") \
                 atomicAdd(&A.ref_tri[k], 1ULL); \
             }
 
-constexpr int NE_TILES = 16;     // 256-position tiles per workgroup
-
-__global__ void __launch_bounds__(256) k_norm_eval(NormArgs A) {
-    __shared__ double s_lut[3 * 256];
-    __shared__ double s_prior[4];
-    __shared__ unsigned int s_log[16];
-    __shared__ unsigned int s_ccs[32], s_ref[32];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = A.lut->t[i >> 8][i & 255];
-    if (tid < 4) s_prior[tid] = A.lut->prior[tid];
-    if (tid < 16) s_log[tid] = 0;
-    if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
-    __syncthreads();
-    const int chunk = blockIdx.y;
-    const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
-    int bad = 0;
-    for (int t = 0; t < NE_TILES; t++) {
-        const int64_t rpos = (int64_t)cs_ + ((int64_t)blockIdx.x * NE_TILES + t) * 256 + tid;
-        if (rpos >= ce_ || rpos < A.p_lo || rpos >= A.p_hi) continue;
-        if (rpos < 0 || rpos >= A.reflen) { bad |= 1 << HIMUT_ERR_ARG; continue; }   // IndexError in the reference
-        const int refc = A.refseq[rpos];
-        const int ref = char2allele(refc);
-        const uint32_t u = pos_rank(A.X, (int32_t)rpos);
-        const BlockTab bt = A.X.bt[rpos >> 8];
-        const uint32_t n = bt.ncnt & BT_N_MASK, stride = bt.ncnt >> 22;
-        const int32_t lo = bt.lo;
-        const uint16_t* col = A.colstore + ((int64_t)bt.boff + (int64_t)(u - bt.ufirst));
-        const bool edge = rpos <= cs_;
-        NORM_POS_STATE()
-        const bool phase = A.P.p.phase != 0;
-        const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
-        // eight slots of the column are in flight at a time (their addresses do not depend on each other)
-        for (uint32_t i0 = 0; i0 < n; i0 += 8) {
-            uint32_t vv[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) vv[k] = (i0 + k < n) ? (uint32_t)col[(int64_t)(i0 + k) * stride] : (uint32_t)CELL_EMPTY;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t v = vv[k];
-                if ((v & 15u) == CELL_EMPTY) continue;
-                if (edge && !(A.R.tend[lo + (int32_t)(i0 + k)] > cs_)) continue;   // not fetched by this chunk (normcounts.py:289)
-                NORM_CELL(v, A.H.hap[pairbase + lo + (int32_t)(i0 + k)])
-            }
-        }
-        NORM_CLASSIFY()
-    }
-    __syncthreads();
-    if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
-    if (tid < 32 && (s_ccs[tid] || s_ref[tid])) {
-        const int cl[4] = {A.cA, A.cC, A.cG, A.cT};
-        const int64_t k = ((int64_t)cl[tid >> 3] * A.K + ((tid & 4) ? A.cT : A.cC)) * A.K + cl[tid & 3];
-        atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
-        atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
-    }
-    if (bad) atomicOr(A.err, bad);
-}
-
 // ---------------------------------------------------------------------------------------
 // k_norm_tile: the same sweep without a column store.  A workgroup takes tiles of 256 positions of one chunk; the
 // reads that can cover a tile (the window index of its one or two 256-position blocks) are its rows.  Rows are
@@ -716,8 +561,11 @@ constexpr int NT_Q = HIMUT_NT_Q;         // workgroups per XCD class and chunk (
 constexpr int NT_ROWS = 48;
 constexpr int NT_RPW = NT_ROWS / 4;    // rows per wave and batch
 
+struct NormRedo { int32_t chunk, base; };          // 256 positions from `base` of chunk `chunk`, left to k_norm_tile by k_norm_quad
+
 __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, Derived D, const uint32_t* callable, const int32_t* winlo,
-                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class, const int* only_if) {
+                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class, const NormRedo* redo,
+                                                   const unsigned int* nredo, unsigned int redo_cap) {
     __shared__ double s_lut[3 * 257];         // three tables of 256 qualities + a zero entry each (index 256)
     __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
@@ -725,7 +573,10 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
     __shared__ __align__(16) uint16_t s_cells[NT_ROWS][256];
     __shared__ int32_t s_tend[NT_ROWS];
     __shared__ uint32_t s_hap[NT_ROWS];
-    if (only_if && !*only_if) return;        // (launched behind k_norm_col: for the contig that kernel left alone)
+    // with a list (launched behind k_norm_quad): the tiles that kernel left alone, any workgroup any tile; a list that did
+    // not hold them all is the host's business (it repeats the contig without the list)
+    const int64_t nlist = redo ? (int64_t)min(*nredo, redo_cap) : 0;
+    if (redo && nlist == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     for (int i = tid; i < 3 * 256; i += 256) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 255];
     if (tid < 3) s_lut[tid * 257 + 256] = 0.0;
@@ -733,10 +584,7 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
     if (tid < 16) s_log[tid] = 0;
     if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
     __syncthreads();
-    const int chunk = blockIdx.y;
-    const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
     const bool phase = A.P.p.phase != 0;
-    const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
     const Reads& R = A.R;
     int bad = 0;
     // Which tile: workgroups are dealt round-robin over the eight XCDs (each with an L2 of its own), so the workgroups
@@ -747,10 +595,15 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
     // A workgroup goes through several such tiles (its counters go to memory once): XCD class r = blockIdx.x & 7 owns the
     // tiles [r * per, (r + 1) * per) of the chunk and its NT_Q workgroups take NT_Q neighbouring ones per step.
     const int64_t per = tiles_per_class;
-    for (int64_t t = blockIdx.x >> 3; t < per; t += (int64_t)(gridDim.x >> 3)) {
+    const int64_t wg = redo ? (int64_t)blockIdx.x + (int64_t)blockIdx.y * gridDim.x : (int64_t)(blockIdx.x >> 3);
+    const int64_t wgs = redo ? (int64_t)gridDim.x * gridDim.y : (int64_t)(gridDim.x >> 3);
+    for (int64_t t = wg; t < (redo ? nlist : per); t += wgs) {
+        const int chunk = redo ? redo[t].chunk : (int)blockIdx.y;
+        const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
+        const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
         const int64_t tile = (int64_t)(blockIdx.x & 7) * per + t;
-        const int64_t base = (int64_t)cs_ + tile * 256;
-        if (base >= ce_) break;                                   // the same for every thread
+        const int64_t base = redo ? (int64_t)redo[t].base : (int64_t)cs_ + tile * 256;
+        if (base >= ce_) { if (redo) continue; break; }           // the same for every thread
         const int64_t rpos = base + tid;
         bool valid = rpos < ce_;
         if (valid && (rpos < 0 || rpos >= A.reflen)) { bad |= 1 << HIMUT_ERR_ARG; valid = false; }   // IndexError in the reference
@@ -941,9 +794,8 @@ struct NormDirty {
     double S[9];              // [table * 3 + slot]: the other alleles', allele c in slot c - (c > ref)
 };
 
-constexpr int NORM_DIRTY_REGIONS = 256;   // the list in as many parts, each with a counter of its own (16 words apart) and room for `cap` entries
 
-__global__ void __launch_bounds__(256) k_norm_dirty(NormArgs A, const NormDirty* recs, const unsigned long long* dcount, int64_t cap) {
+__global__ void __launch_bounds__(256) k_norm_dirty(NormArgs A, const NormDirty* recs, const uint32_t* dcount, int64_t cap, int64_t nregions) {
     __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
     __shared__ unsigned int s_ccs[32], s_ref[32];
@@ -953,10 +805,14 @@ __global__ void __launch_bounds__(256) k_norm_dirty(NormArgs A, const NormDirty*
     if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
     __syncthreads();
     const bool phase = A.P.p.phase != 0;
-    const int64_t n = min((int64_t)dcount[blockIdx.y * 16], cap);       // region blockIdx.y
     int bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
-        const NormDirty d = recs[(int64_t)blockIdx.y * cap + i];
+    // the list is in `nregions` parts of `cap` entries (one part per wave of the sweep, filled from its start, a third full or
+    // less): a wave per part
+    const int lane = tid & 63;
+    for (int64_t region = ((int64_t)blockIdx.x * 256 + tid) >> 6; region < nregions; region += (int64_t)gridDim.x * 4)
+    for (int64_t i = lane; i < (int64_t)min((int64_t)dcount[region], cap); i += 64) {
+        const int64_t t = region * cap + i;
+        const NormDirty d = recs[t];
         const int64_t rpos = d.rpos;
         const int refc = (int)A.refseq[rpos];
         const int ref = char2allele(refc);
@@ -983,347 +839,6 @@ __global__ void __launch_bounds__(256) k_norm_dirty(NormArgs A, const NormDirty*
         atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
         atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
     }
-    if (bad) atomicOr(A.err, bad);
-}
-
-// ---------------------------------------------------------------------------------------
-// k_norm_col: the sweep with no cells in LDS.  A wave owns 64 consecutive positions -- a lane is a column from the first
-// row to the last -- and the eight waves of a workgroup take the eight parts of a 512-position tile (k_norm_tile's
-// mapping of tiles to workgroups: neighbours share an XCD's L2).  The rows of a wave's 64 positions are prepared 64 at a
-// time with a LANE per ROW (read header, the segment that reaches the positions by binary search, whether that one gapless
-// segment spans all 64 -- 97 rows in 100 -- and then where the row's first base lies, as a 32-bit distance from the
-// batch's first read); the wave goes through the live rows in read order (the set bits of a ballot: a read of the window
-// index that does not reach these positions costs nothing).  A spanning row is 64 consecutive query bases from K on: one
-// byte load at a scalar base brings quality | callable << 7 (`cq`, written by k_callable: the callable bit travels with
-// the quality), one 16-bit load the packed bases -- no address arithmetic in a lane, no LDS round trip, no barrier; the
-// reference allele's three sums and two counters are a dozen vector instructions per row.  While HIMUT_NC_NB spanning
-// rows follow each other they are taken together, their loads issued before the first is used.  Everything else -- a
-// row with an indel or a read end inside the 64 positions, another allele -- takes the general update lane by lane, in
-// its place in the read order.  The sums of the other three alleles, touched by one row in twenty, live in LDS (a column's
-// nine doubles), not in registers.  What is the same for a whole row sits in a lane of a row vector and comes back with
-// one v_readlane; the counts that do not depend on the order (insertions in front of a spanning segment, haplotype votes
-// of spanning rows) are taken per 64 rows with a popcount.  At the end of a column: nothing but the reference allele in
-// it (29 columns in 30) makes the ten genotype sums four numbers, and the kernel classifies the position itself; the
-// others go into a list for k_norm_dirty.  Qualities of 128 and more do not fit beside the callable bit: k_callable
-// raises a flag and k_norm_tile does the contig (each of the two kernels looks at the flag first).  Same counts as
-// k_norm_tile (HIMUT_NORM_SWEEP=tile takes that one).
-#ifndef HIMUT_NC_WAVES
-#define HIMUT_NC_WAVES 6
-#endif
-#ifndef HIMUT_NC_NB
-#define HIMUT_NC_NB 4
-#endif
-#ifndef HIMUT_NC_THREADS
-#define HIMUT_NC_THREADS 512
-#endif
-#ifndef HIMUT_NC_Q
-#define HIMUT_NC_Q 8
-#endif
-// A workgroup's positions per tile (64 per wave).  The other alleles' sums and counts take 88 bytes of LDS a column, so 512
-// columns with the tables are 51 KB: three workgroups of eight waves on a CU are six waves per SIMD, where five workgroups of four
-// waves were five (3.92 -> 3.55 ms); NC_Q workgroups per XCD class and chunk take neighbouring tiles (2 to 8 measure the same).
-constexpr int NC_THREADS = HIMUT_NC_THREADS;
-constexpr int NC_Q = HIMUT_NC_Q;
-
-typedef const __attribute__((address_space(1))) uint8_t* nc_gptr8;
-
-// one base of another allele than the reference's (cell 0..3): its three sums and its count in LDS.  A column has three
-// such alleles: allele c sits in slot c - (c > ref).  (Where the reference base is not one of ATGC the position is never
-// classified and the slots may mix.)
-#define NC_ALT(CELL, Q) \
-            { \
-                const uint32_t c_ = (CELL), qa_ = (Q); \
-                const uint32_t a_ = min(c_ - ((int)c_ > ref ? 1u : 0u), 2u); \
-                s_S[a_][tid] = s_S[a_][tid] + s_lut[qa_]; \
-                s_S[3 + a_][tid] = s_S[3 + a_][tid] + s_lut[257 + qa_]; \
-                s_S[6 + a_][tid] = s_S[6 + a_][tid] + s_lut[514 + qa_]; \
-                s_cnt[c_][tid] = s_cnt[c_][tid] + 1u; \
-            }
-
-// the loads of spanning row L (a scalar) into slot k: the row's first base is base K = Kb + d, d from the row vector
-#define NC_ROW_LOADS(L, k) \
-            { \
-                const uint32_t d_ = (uint32_t)lane_val(dqv, (L)); \
-                const uint32_t e_ = d_ + kb_par; \
-                kpar[k] = e_ & 1u; \
-                if (PHASE) hnone[k] = (m_hnone >> (L)) & 1; \
-                qv[k] = reinterpret_cast<nc_gptr8>(pqb + d_)[o1]; \
-                sv[k] = *reinterpret_cast<const __attribute__((address_space(1), aligned(1))) uint16_t*>(reinterpret_cast<nc_gptr8>(psb + (e_ >> 1)) + o2); \
-            }
-
-// the update of slot k: every lane holds a base of the row (a base outside ATGC ends the run with an error, a zero
-// quality ends it at the classification: what they add meanwhile does not matter)
-#define NC_ROW_UPDATE(k) \
-            { \
-                const uint32_t nib_ = (sv[k] >> (kpar[k] ? sh_odd : sh_even)) & 15u; \
-                const uint32_t cq_ = qv[k]; \
-                qmin = min(qmin, cq_ & 127u); \
-                uint32_t cb_ = cq_ >> 7; \
-                if (PHASE && hnone[k]) cb_ = 0;                          /* the read carries no haplotype in this chunk */ \
-                tri_sum += cb_; \
-                if (nib_ == refnib) { \
-                    nref++; \
-                    R0 = R0 + s_lut[cq_]; R1 = R1 + s_lut[257 + cq_]; R2 = R2 + s_lut[514 + cq_]; \
-                } else if (valid) {                                      /* rare: another allele, or a base outside ATGC */ \
-                    const uint32_t cell_ = (uint32_t)nib2allele((int)nib_); \
-                    if (cell_ > 3) s_bad = 1 << HIMUT_ERR_BASE; \
-                    else if ((cq_ & 127u) != 0) NC_ALT(cell_, cq_) \
-                } \
-            }
-
-template <bool PHASE>
-__global__ void __launch_bounds__(NC_THREADS, HIMUT_NC_WAVES) k_norm_col(NormArgs A, Derived D, const uint8_t* __restrict__ cq,
-                                                                   const int* __restrict__ qhigh, const int32_t* winlo,
-                                                                   const int32_t* winhi, int64_t nblk, int64_t tiles_per_class,
-                                                                   NormDirty* dirty, unsigned long long* dcount, int64_t dirty_cap,
-                                                                   int* dirty_over) {
-    __shared__ double s_lut[3 * 257];         // three tables indexed by quality | callable << 7 (the upper half repeats the lower) + a zero entry each
-    __shared__ double s_prior[4];
-    __shared__ unsigned int s_log[16];
-    __shared__ unsigned int s_ccs[32], s_ref[32];
-    __shared__ double s_S[9][NC_THREADS];     // [table * 3 + slot][column]: the sums of the three alleles that are not the reference's
-    __shared__ uint32_t s_cnt[4][NC_THREADS]; // [allele][column]: their counts
-    __shared__ int s_bad;                     // a base outside ATGC was seen (the reference raises KeyError)
-    if (*qhigh) return;                       // a quality of 128 or more somewhere: k_norm_tile does this contig
-    const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
-    for (int i = tid; i < 3 * 256; i += NC_THREADS) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 127];
-    if (tid < 3) s_lut[tid * 257 + 256] = 0.0;
-    if (tid < 4) s_prior[tid] = A.lut->prior[tid];
-    if (tid < 16) s_log[tid] = 0;
-    if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
-    if (tid == 0) s_bad = 0;
-    __syncthreads();
-    const int chunk = blockIdx.y;
-    const int64_t dregion = (int64_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NORM_DIRTY_REGIONS - 1));   // this workgroup's part of the list
-    const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
-    constexpr bool phase = PHASE;
-    const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
-    const Reads& R = A.R;
-    int bad = 0;
-    // base K + lane of a spanning row: the 16-bit load at byte (K >> 1) + (lane >> 1) holds it at one of two shifts
-    const uint32_t hoff = (uint32_t)lane >> 1;
-    const uint32_t sh_even = (lane & 1) ? 0u : 4u, sh_odd = (lane & 1) ? 12u : 0u;       // K even / K odd
-    constexpr int NB = HIMUT_NC_NB;
-    const int64_t per = tiles_per_class;
-    for (int64_t t = blockIdx.x >> 3; t < per; t += (int64_t)(gridDim.x >> 3)) {         // the tile mapping of k_norm_tile
-        const int64_t tile = (int64_t)(blockIdx.x & 7) * per + t;
-        const int64_t base = (int64_t)cs_ + tile * NC_THREADS + 64 * wv;                  // this wave's 64 positions
-        if (base >= ce_) break;                                   // (the later tiles of this workgroup lie further on)
-        const int64_t rpos = base + lane;
-        bool valid = rpos < ce_;
-        if (valid && (rpos < 0 || rpos >= A.reflen)) { bad |= 1 << HIMUT_ERR_ARG; valid = false; }   // IndexError in the reference
-        // the reference's letter and its two neighbours (the trinucleotide at the end needs them) in one unaligned load
-        uint32_t ref3 = 0x4e4e4eu;                                // "NNN"
-        if (valid) {
-            if (rpos >= 1 && rpos + 2 <= A.reflen) __builtin_memcpy(&ref3, A.refseq + rpos - 1, 4);   // (the array has slack behind it)
-            else ref3 = 0x4e004eu | ((uint32_t)A.refseq[rpos] << 8);
-        }
-        const int refc = (int)((ref3 >> 8) & 255u);
-        const int ref = char2allele(refc);
-        const uint32_t refnib = ref == 0 ? 1u : ref == 3 ? 2u : ref == 2 ? 4u : ref == 1 ? 8u : 0xffu;   // the BAM code of the reference base
-        uint32_t n_ins = 0, n_del = 0;
-        double R0 = 0.0, R1 = 0.0, R2 = 0.0;
-        uint32_t nref = 0, tri_sum = 0, h0 = 0, h1 = 0, qmin = 255;
-#pragma unroll
-        for (int k = 0; k < 9; k++) s_S[k][tid] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) s_cnt[k][tid] = 0;
-        const int64_t b0 = min(max(base, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min((base + 63) >> WIN_SHIFT, nblk - 1);
-        const int32_t lo = uni(winlo[b0]), hi = uni(winhi[b1]);
-        const int32_t P = (int32_t)base + lane;
-        for (int32_t r0 = lo; r0 < hi; r0 += 64) {
-            // ---- a lane per row: header, the last segment that starts at or before the quarter, the spanning test
-            const int nb = min(64, hi - r0);
-            ReadMeta M;
-            M.tstart = 0; M.tend = 0; M.nseg = 0; M.flags = RF_SECONDARY; M.segbase = 0; M.qoff = 0;
-            if (lane < nb) M = D.meta[r0 + lane];
-            const bool live_row = lane < nb && !(M.flags & RF_SECONDARY) && M.nseg > 0 && M.tstart < base + 64 && M.tend >= base;
-            int j0 = 0;
-            int4 sg0 = make_int4(0x7fffffff, 0, 0, 0);
-            if (live_row) {
-                // the starts of the read's first eight segments in one round trip (a read has about as many); the binary search,
-                // a round trip a step, only where the segment lies further on
-                constexpr int NP = 8;
-                int32_t tp[NP];
-#pragma unroll
-                for (int k = 0; k < NP; k++) tp[k] = D.segs[M.segbase + min(k, M.nseg - 1)].t0;
-                int a = 0;
-#pragma unroll
-                for (int k = 0; k < NP; k++) a += (k < M.nseg && tp[k] <= (int32_t)base) ? 1 : 0;       // (starts ascend: the first `a` of them)
-                if (a == NP && M.nseg > NP) {
-                    int e = M.nseg;
-                    while (a < e) { const int m = (a + e) >> 1; if (D.segs[M.segbase + m].t0 <= (int32_t)base) a = m + 1; else e = m; }
-                }
-                j0 = max(a - 1, 0);
-                sg0 = *reinterpret_cast<const int4*>(D.segs + M.segbase + j0);
-            }
-            // the bases of a batch's reads lie side by side in the arrays: a row's first base as a distance from the first
-            // read's first base (a row further away than 2^31, which does not happen, takes the general path)
-            const int64_t Kb = ((int64_t)lane_val((int)(M.qoff >> 32), 0) << 32) | (uint32_t)lane_val((int)M.qoff, 0);
-            const int64_t K0 = M.qoff + sg0.y + ((int32_t)base - sg0.x);
-            const int64_t dK = K0 - Kb;
-            const bool whole = live_row && !((uint32_t)sg0.w & SEG_DEL) && sg0.x <= (int32_t)base && (int64_t)sg0.x + sg0.z >= base + 64 &&
-                               dK >= 0 && dK < ((int64_t)1 << 31);
-            const int dqv = whole ? (int)dK : 0;
-            const uint64_t pqb = (uint64_t)cq + (uint64_t)Kb, psb = (uint64_t)R.seq + (uint64_t)(Kb >> 1);
-            const uint32_t kb_par = (uint32_t)Kb & 1u;
-            uint32_t hp = HAP_NONE;
-            if (phase && live_row && M.tstart < ce_ && M.tend > cs_) hp = A.H.hap[pairbase + r0 + lane];   // fetched by the chunk
-            const uint64_t m_live = __ballot(live_row), m_whole = __ballot(whole);
-            const uint64_t m_slow = m_live & ~m_whole;
-            const uint64_t m_hnone = phase ? __ballot(hp != HAP_0 && hp != HAP_1) : 0;
-            // counts that do not depend on the order: an insertion in front of a spanning segment that starts with the
-            // quarter is counted at its first position; every lane of a spanning row is a base of its haplotype
-            const uint64_t m_ins0 = __ballot(whole && sg0.x == (int32_t)base && ((uint32_t)sg0.w & SEG_INS));
-            if (lane == 0) n_ins += (uint32_t)__builtin_popcountll(m_ins0);
-            if (phase) {
-                h0 += (uint32_t)__builtin_popcountll(__ballot(whole && hp == HAP_0));
-                h1 += (uint32_t)__builtin_popcountll(__ballot(whole && hp == HAP_1));
-            }
-            // ---- the live rows in read order
-            uint64_t m = m_live;
-            while (m) {
-                uint32_t qv[NB], sv[NB], kpar[NB];
-                bool hnone[NB];
-                // do NB spanning rows follow each other?  (live rows in front of the next row of the other kind)
-                const uint64_t ms = m & m_slow;
-                const uint64_t front = ms ? (m & ((ms & (0 - ms)) - 1)) : m;
-                uint32_t o1 = (uint32_t)lane, o2 = hoff;          // (redefined here so that the loads below take a scalar base + this offset)
-                asm volatile("" : "+v"(o1), "+v"(o2));
-                if (__builtin_popcountll(front) >= NB) {
-#pragma unroll
-                    for (int k = 0; k < NB; k++) {
-                        const int l = (int)__builtin_ctzll(m);
-                        m &= m - 1;
-                        NC_ROW_LOADS(l, k)
-                    }
-#pragma unroll
-                    for (int k = 0; k < NB; k++) NC_ROW_UPDATE(k)
-                    continue;
-                }
-                const int l0 = (int)__builtin_ctzll(m);
-                m &= m - 1;
-                if ((m_whole >> l0) & 1) {                               // a spanning row by itself
-                    NC_ROW_LOADS(l0, 0)
-                    NC_ROW_UPDATE(0)
-                    continue;
-                }
-                // ---- the general row: every lane finds its position in the segments from the cursor on
-                {
-                    const int ns = lane_val(M.nseg, l0), jf = lane_val(j0, l0);
-                    const int64_t segbase = ((int64_t)lane_val((int)(M.segbase >> 32), l0) << 32) | (uint32_t)lane_val((int)M.segbase, l0);
-                    const int64_t qoff = ((int64_t)lane_val((int)(M.qoff >> 32), l0) << 32) | (uint32_t)lane_val((int)M.qoff, l0);
-                    const int32_t tend_r = lane_val(M.tend, l0);
-                    uint32_t hps = HAP_NONE;
-                    if (phase) hps = (uint32_t)lane_val((int)hp, l0);
-                    uint32_t v = CELL_EMPTY;
-                    for (int j = jf; j < ns; j++) {
-                        int32_t t0, q0, len;
-                        uint32_t fl;
-                        if (j == jf) {                                   // (the row vector holds it)
-                            t0 = lane_val(sg0.x, l0); q0 = lane_val(sg0.y, l0); len = lane_val(sg0.z, l0); fl = (uint32_t)lane_val(sg0.w, l0);
-                        } else {
-                            const Seg g = D.segs[segbase + j];
-                            t0 = uni(g.t0); q0 = uni(g.q0); len = uni(g.len); fl = uni(g.flags);
-                        }
-                        if (t0 >= base + 64) break;
-                        const int32_t span = len > 0 ? len : ((fl & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
-                        if (P >= t0 && P < t0 + span) {
-                            const uint32_t insb = (P == t0 && (fl & SEG_INS)) ? (uint32_t)CELL_INS : 0u;
-                            if (fl & SEG_DEL) v = CELL_DEL | insb;
-                            else if (len == 0) v = CELL_EMPTY | CELL_INS;
-                            else {
-                                const int64_t K = qoff + q0 + (P - t0);
-                                v = (uint32_t)nib2allele(nib_at(R.seq, K)) | ((uint32_t)cq[K] << 8) | insb;    // bits 8..14 quality, bit 15 callable
-                            }
-                        }
-                    }
-                    // an EMPTY cell, or a read this chunk did not fetch (normcounts.py:289), adds nothing
-                    if (valid && (v & 15u) != CELL_EMPTY && !(rpos <= cs_ && !(tend_r > cs_))) {
-                        const uint32_t c = v & 7u, q7 = v >> 8;
-                        if (v & CELL_INS) n_ins++;
-                        if (c < 4) {
-                            qmin = min(qmin, q7 & 127u);
-                            if ((int)c == ref) { nref++; R0 = R0 + s_lut[q7]; R1 = R1 + s_lut[257 + q7]; R2 = R2 + s_lut[514 + q7]; }
-                            else NC_ALT(c, q7)
-                            uint32_t counts_here = q7 >> 7;
-                            if (phase) {
-                                h0 += hps == HAP_0 ? 1u : 0u; h1 += hps == HAP_1 ? 1u : 0u;
-                                if (hps != HAP_0 && hps != HAP_1) counts_here = 0;
-                            }
-                            tri_sum += counts_here;
-                        } else if (c == CELL_DEL) n_del++;
-                        else if (c == CELL_OTHER) s_bad = 1 << HIMUT_ERR_BASE;
-                    }
-                }
-            }
-        }
-        // ---- the position's class (normcounts.py:317-402), in the order of the general text (NORM_CLASSIFY).  No lane leaves
-        //      early: the three counters nearly every position adds to are summed over the wave first -- 64 lanes adding
-        //      to one LDS word take their turns one by one, and that was two fifths of this kernel's time
-        const bool cls = valid && ref >= 0 && tri_sum != 0;
-        const bool hapfail = phase && cls && !((int64_t)h0 >= A.P.p.min_hap_count && (int64_t)h1 >= A.P.p.min_hap_count);
-        const bool q0 = cls && !hapfail && qmin == 0;
-        if (q0) bad |= 1 << HIMUT_ERR_BQ0;
-        const bool open = cls && !hapfail && !q0;
-        const uint32_t ca0 = s_cnt[0][tid], ca1 = s_cnt[1][tid], ca2 = s_cnt[2][tid], ca3 = s_cnt[3][tid];
-        // Nothing but the reference allele in the column (29 in 30): the ten genotype sums are four numbers -- an allele
-        // that was not seen adds +0.0 to a sum, which leaves it bit for bit what it was -- hom-ref's, the three
-        // genotypes' with one reference allele, the three of two different other alleles and the three of one other
-        // allele twice.  When hom-ref is the smallest by itself it is the genotype and the quality is the gap to the
-        // smallest of the rest; any other outcome, and any column with another allele, goes to k_norm_dirty.
-        const double pa = -10.0 * (R0 + s_prior[0]), pb = -10.0 * (R1 + s_prior[1]);
-        const double pc = -10.0 * (R2 + s_prior[2]), pd = -10.0 * (R2 + s_prior[3]);
-        const double nxt = fmin(pb, fmin(pc, pd));
-        const bool mine = open && (ca0 | ca1 | ca2 | ca3) == 0 && pa < nxt;
-        const double gqf = nxt - pa;
-        const int gq = (gqf < 99.0) ? (int)gqf : 99;
-        int slot = 13;
-        if (n_del != 0 || n_ins != 0) slot = 7;
-        else if ((int64_t)nref > A.P.p.md_threshold) slot = 8;
-        else if (gq < A.P.p.min_gq) slot = 10;
-        else if ((int64_t)nref < A.P.p.min_ref_count) slot = 9;
-        {
-            const uint32_t w1 = (uint32_t)lane_val(wave_incl_add((int)((mine || hapfail) ? tri_sum : 0u), lane), 63);
-            const uint32_t w6 = (uint32_t)lane_val(wave_incl_add((int)(mine ? tri_sum : 0u), lane), 63);
-            const uint32_t w13 = (uint32_t)lane_val(wave_incl_add((int)((mine && slot == 13) ? tri_sum : 0u), lane), 63);
-            uint32_t w2 = 0;
-            if (phase) w2 = (uint32_t)lane_val(wave_incl_add((int)(hapfail ? tri_sum : 0u), lane), 63);
-            if (lane == 0) {
-                if (w1) atomicAdd(&s_log[1], w1);
-                if (w2) atomicAdd(&s_log[2], w2);
-                if (w6) atomicAdd(&s_log[6], w6);
-                if (w13) atomicAdd(&s_log[13], w13);
-            }
-        }
-        if (mine && slot != 13) atomicAdd(&s_log[slot], tri_sum);
-        if (mine && slot == 13) {
-            NORM_TRIBINS((int)(ref3 & 255u), (int)((ref3 >> 16) & 255u))
-        }
-        if (open && !mine) {
-            // a place in the workgroup's region of the list: one atomic per wave, on one of NORM_DIRTY_REGIONS counters (a single
-            // counter takes about 300 additions a microsecond, and every other wave of this kernel has a position to leave)
-            const int64_t at = (int64_t)wave_reserve(dcount + dregion * 16);
-            if (at < dirty_cap) {
-                NormDirty d;
-                d.rpos = rpos; d.nref = nref; d.tri_sum = tri_sum; d.n_ins = n_ins; d.n_del = n_del; d.h0 = h0; d.h1 = h1;
-                d.cnt[0] = ca0; d.cnt[1] = ca1; d.cnt[2] = ca2; d.cnt[3] = ca3;
-                d.R[0] = R0; d.R[1] = R1; d.R[2] = R2;
-#pragma unroll
-                for (int k = 0; k < 9; k++) d.S[k] = s_S[k][tid];
-                dirty[dregion * dirty_cap + at] = d;
-            } else *dirty_over = 1;              // more of them than there is room for: the host repeats the contig with k_norm_tile
-        }
-    }
-    __syncthreads();
-    if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
-    if (tid < 32 && (s_ccs[tid] || s_ref[tid])) {
-        const int cl[4] = {A.cA, A.cC, A.cG, A.cT};
-        const int64_t k = ((int64_t)cl[tid >> 3] * A.K + ((tid & 4) ? A.cT : A.cC)) * A.K + cl[tid & 3];
-        atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
-        atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
-    }
-    if (tid == 0 && s_bad) bad |= s_bad;
     if (bad) atomicOr(A.err, bad);
 }
 

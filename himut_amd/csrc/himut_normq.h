@@ -1,20 +1,24 @@
-// k_norm_quad: the position sweep of normcounts.get_callable_tricounts (src/himut/normcounts.py:113-140,315-402) with FOUR
-// consecutive reference positions per lane.
+// The position sweep of normcounts.get_callable_tricounts (src/himut/normcounts.py:113-140,315-402) in two kernels.
 //
-// A wave owns 256 consecutive positions of a chunk (a lane the columns P0 .. P0 + 3, P0 = base + 4 * lane), a workgroup of
-// four waves 1024.  The reads of the window index under the 256 positions are the wave's rows, prepared 64 at a time with
-// a LANE per ROW (header, the segment that reaches the positions, whether that one gapless segment spans all 256) and
-// then taken in read order.  A spanning row is 256 consecutive query bases from K on, so a row is three loads at a scalar
-// base plus a fixed per-lane offset: a dword of four qualities (a 256-byte transaction per wave), a dword that holds the
-// four packed bases, sixteen bits of the callable bit array.  The reference allele's three ordered fp64 sums of the lane's
-// four columns are four independent chains; a cell of another allele -- one in a thousand -- sends the row's lanes that
-// hold one down a side path that adds to a small POOL of accumulators in LDS (thirty-two columns of a wave's 256 may own
-// one; nine doubles and four counts each), so the kernel's LDS is the tables plus 11 KB and the registers decide the
-// occupancy.  A row with an indel or a read end inside the 256 positions is taken segment by segment with the same update
-// under a per-lane mask of cells.  At the end of a column: nothing but the reference allele in it makes the ten genotype
-// sums four numbers and the kernel classifies the position itself; the others go to k_norm_dirty's list (himut_norm.h).
-// A wave whose pool runs out (more than thirty-two columns with another allele among 256) leaves its 256 positions to
-// k_norm_tile through a list of tiles.  Same counts as k_norm_tile, bit for bit.
+//   k_norm_plan   a wave per 256 positions of a chunk, a LANE per read of the window index under them: which gapless pieces
+//                 of which reads lie over the 256 positions, written as a list of ITEMS in read order (where a piece's
+//                 bases sit in the arrays, its first position and length, whether it is a deletion, whether an insertion
+//                 precedes it, the read's haplotype).  Everything here is a chain of dependent look-ups -- window index,
+//                 read header, segment starts, segment -- and every chain is short and independent of every other, so the
+//                 chip hides them behind each other.
+//   k_norm_quad   a wave per 256 positions again, FOUR consecutive positions per lane (columns P0 .. P0 + 3, P0 = base +
+//                 4 * lane).  It reads its items with one load and goes through them in order.  An item that spans all
+//                 256 positions -- nine in ten -- is three loads at a scalar base plus a fixed per-lane offset: a dword of
+//                 four qualities (a 256-byte row per wave), a dword that holds the four packed bases, sixteen bits of the
+//                 callable bit array.  The reference allele's three ordered fp64 sums of the lane's four columns are four
+//                 independent chains (nq_pair: scheduled by hand); a cell of another allele -- one in a thousand -- sends
+//                 the lanes that hold one down a side path that adds to a small POOL of accumulators in LDS (thirty-two of
+//                 a wave's 256 columns may own one: nine doubles and four counts each).  An item that covers a part of the
+//                 positions takes the same update under a per-lane mask of cells.  At the end of a column: nothing but the
+//                 reference allele in it makes the ten genotype sums four numbers and the kernel classifies the position
+//                 itself; the others go to k_norm_dirty's list (himut_norm.h).  A wave whose pool runs out, or whose
+//                 positions have more items than the plan holds, leaves them to k_norm_tile through a list of tiles.
+// Same counts as k_norm_tile, bit for bit.
 #pragma once
 
 #include "himut_norm.h"
@@ -22,10 +26,10 @@
 namespace himut {
 
 #ifndef HIMUT_NQ_NB
-#define HIMUT_NQ_NB 4            // spanning rows whose loads are issued together
+#define HIMUT_NQ_NB 4            // spanning items whose loads are issued together
 #endif
 #ifndef HIMUT_NQ_OCC
-#define HIMUT_NQ_OCC 6           // waves per SIMD asked of the register allocator
+#define HIMUT_NQ_OCC 4           // waves per SIMD asked of the register allocator
 #endif
 #ifndef HIMUT_NQ_Q
 #define HIMUT_NQ_Q 8             // workgroups per XCD class and chunk (neighbouring tiles: the mapping of k_norm_tile)
@@ -35,8 +39,6 @@ constexpr int NQ_COLS = 256;                       // positions per wave
 constexpr int NQ_WG_COLS = NQ_WAVES * NQ_COLS;     // positions per workgroup and step
 constexpr int NQ_SLOTS = 32;                       // pool of other-allele accumulators per wave
 constexpr int NQ_Q = HIMUT_NQ_Q;
-
-struct NormRedo { int32_t chunk, base; };          // 256 positions from `base` of chunk `chunk`, left to k_norm_tile
 
 typedef const __attribute__((address_space(1))) uint8_t* nq_g8;
 // loads at a 64-bit base (wave-uniform where the caller keeps it so) plus a 32-bit per-lane offset; no alignment assumed
@@ -64,84 +66,252 @@ struct NqPool {
     uint32_t pad;
 };
 
+// The update of two neighbouring columns (J, J + 1) with one read's cells, scheduled by hand: the compiler, short of
+// registers, waited for each of the twelve table values of an item by itself.  xi: a nibble of zeros (bits 12 - 4j ..) = the
+// cell is the reference allele's; qv: the qualities (byte j); lut: LDS address of the three tables (257 doubles each, entry
+// 256 = +0.0: what a cell adds that is not the reference allele's -- the sums stay bit for bit what they were).  The six
+// values are asked for together and added as they arrive.
+template <int J>
+__device__ __forceinline__ void nq_pair(double& r0a, double& r1a, double& r2a, uint32_t& na, double& r0b, double& r1b,
+                                        double& r2b, uint32_t& nb, uint32_t qv, uint32_t xi, uint32_t lut) {
+    uint32_t a0, a1, t0;
+    double d0, d1, d2, d3, d4, d5;
+    asm volatile(
+        "v_and_b32 %[t0], %[ma], %[xi]\n\t"
+        "v_bfe_u32 %[a0], %[qv], %[sa], 8\n\t"
+        "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
+        "v_cndmask_b32 %[a0], %[c256], %[a0], vcc\n\t"
+        "v_addc_co_u32 %[na], vcc, 0, %[na], vcc\n\t"
+        "v_lshl_add_u32 %[a0], %[a0], 3, %[lut]\n\t"
+        "ds_read_b64 %[d0], %[a0]\n\t"
+        "ds_read_b64 %[d1], %[a0] offset:2056\n\t"
+        "ds_read_b64 %[d2], %[a0] offset:4112\n\t"
+        "v_and_b32 %[t0], %[mb], %[xi]\n\t"
+        "v_bfe_u32 %[a1], %[qv], %[sb], 8\n\t"
+        "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
+        "v_cndmask_b32 %[a1], %[c256], %[a1], vcc\n\t"
+        "v_addc_co_u32 %[nb], vcc, 0, %[nb], vcc\n\t"
+        "v_lshl_add_u32 %[a1], %[a1], 3, %[lut]\n\t"
+        "ds_read_b64 %[d3], %[a1]\n\t"
+        "ds_read_b64 %[d4], %[a1] offset:2056\n\t"
+        "ds_read_b64 %[d5], %[a1] offset:4112\n\t"
+        "s_waitcnt lgkmcnt(5)\n\t"
+        "v_add_f64 %[r0a], %[r0a], %[d0]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_add_f64 %[r1a], %[r1a], %[d1]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_add_f64 %[r2a], %[r2a], %[d2]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_add_f64 %[r0b], %[r0b], %[d3]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_add_f64 %[r1b], %[r1b], %[d4]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_f64 %[r2b], %[r2b], %[d5]"
+        : [r0a] "+v"(r0a), [r1a] "+v"(r1a), [r2a] "+v"(r2a), [na] "+v"(na), [r0b] "+v"(r0b), [r1b] "+v"(r1b), [r2b] "+v"(r2b),
+          [nb] "+v"(nb), [a0] "=&v"(a0), [a1] "=&v"(a1), [t0] "=&v"(t0), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2),
+          [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5)
+        : [qv] "v"(qv), [xi] "v"(xi), [lut] "s"(lut), [c256] "v"(256u), [ma] "n"(0xf000 >> (4 * J)), [mb] "n"(0x0f00 >> (4 * J)), [sa] "n"(8 * J),
+          [sb] "n"(8 * J + 8)
+        : "vcc");
+}
+
+// one gapless piece of one read over a tile's positions
+struct NqItem {
+    int64_t kq;        // the cell at position P is query base kq + P of the arrays (MATCH)
+    int32_t tlo;       // first position of the piece inside the tile
+    uint16_t len;      // positions
+    uint16_t flags;    // NQI_*
+};
+constexpr uint32_t NQI_TYPE = 3, NQI_MATCH = 0, NQI_DEL = 1, NQI_INSONLY = 2;   // bases / deleted positions / only the mark of an insertion
+constexpr uint32_t NQI_INS = 4;                        // an insertion precedes the piece's first position
+constexpr uint32_t NQI_HAP_SHIFT = 3;                  // two bits: HAP_0, HAP_1, HAP_NONE
+constexpr int NQ_ITEMS = 128;                          // items per tile the plan has room for
+constexpr uint32_t NQ_PLAN_OVER = 0xffffffffu;         // count of a tile that has more
+
+// ---------------------------------------------------------------------------------------
+// k_norm_plan: tile k of chunk blockIdx.y is positions [cs + 256 k, cs + 256 k + 256) below the chunk's end; its items go
+// to items[(chunk * tpc + k) * NQ_ITEMS ..], their number to counts[chunk * tpc + k].
+template <bool PHASE>
+__global__ void __launch_bounds__(256) k_norm_plan(NormArgs A, Derived D, const int32_t* winlo, const int32_t* winhi, int64_t nblk,
+                                                   int64_t tpc, NqItem* items, uint32_t* counts, NormRedo* redo,
+                                                   unsigned int* nredo, unsigned int redo_cap) {
+    const int lane = threadIdx.x & 63, wv = uni((int)(threadIdx.x >> 6));
+    const int chunk = blockIdx.y;
+    const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
+    const int64_t k = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t base64 = (int64_t)cs_ + k * NQ_COLS;
+    if (base64 >= ce_) return;
+    const int32_t base = (int32_t)base64;
+    const int32_t tile_end = (int32_t)min((int64_t)base + NQ_COLS, (int64_t)ce_);
+    constexpr bool phase = PHASE;
+    const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
+    NqItem* out = items + (chunk * tpc + k) * NQ_ITEMS;
+    const int64_t b0 = min(max(base64, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min((base64 + NQ_COLS - 1) >> WIN_SHIFT, nblk - 1);
+    const int32_t lo = uni(winlo[b0]), hi = uni(winhi[b1]);
+    uint32_t total = 0;
+    for (int32_t r0 = lo; r0 < hi; r0 += 64) {
+        const int nb = min(64, hi - r0);
+        bool live = false;
+        ReadMeta M;
+        M.tstart = 0; M.tend = 0; M.nseg = 0; M.flags = RF_SECONDARY; M.segbase = 0; M.qoff = 0;
+        int j0 = 0;
+        uint32_t hp = HAP_NONE;
+        if (lane < nb) {
+            M = D.meta[r0 + lane];
+            live = !(M.flags & RF_SECONDARY) && M.nseg > 0 && M.tstart < tile_end && M.tend >= base;
+            if (live) {
+                // the last segment that starts at or before the tile: the starts of the read's first eight segments in one
+                // round trip, the binary search only where the segment lies further on
+                constexpr int NP = 8;
+                int32_t tp[NP];
+#pragma unroll
+                for (int q = 0; q < NP; q++) tp[q] = D.segs[M.segbase + min(q, M.nseg - 1)].t0;
+                int a = 0;
+#pragma unroll
+                for (int q = 0; q < NP; q++) a += (q < M.nseg && tp[q] <= base) ? 1 : 0;
+                if (a == NP && M.nseg > NP) {
+                    int e = M.nseg;
+                    while (a < e) { const int mm = (a + e) >> 1; if (D.segs[M.segbase + mm].t0 <= base) a = mm + 1; else e = mm; }
+                }
+                j0 = max(a - 1, 0);
+                if (phase && M.tstart < ce_ && M.tend > cs_) hp = A.H.hap[pairbase + r0 + lane];   // fetched by the chunk
+            }
+        }
+        // the pieces of this lane's read inside the tile; pass 0 counts them, pass 1 writes them behind the rows in front
+        uint32_t mine = 0, at = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            uint32_t n = 0;
+            if (live) {
+                for (int j = j0; j < M.nseg; j++) {
+                    const Seg g = D.segs[M.segbase + j];
+                    if (g.t0 >= tile_end) break;
+                    const int32_t span = g.len > 0 ? g.len : ((g.flags & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
+                    int32_t tlo = max(g.t0, base);
+                    const int32_t thi = (int32_t)min((int64_t)g.t0 + span, (int64_t)tile_end);
+                    // a read this chunk did not fetch (normcounts.py:289) adds nothing: only its trailing insertion can reach in
+                    if (!(M.tend > cs_)) tlo = max(tlo, cs_ + 1);
+                    if (tlo >= thi) continue;
+                    if (pass == 1 && total + at + n < (uint32_t)NQ_ITEMS) {
+                        NqItem it;
+                        it.kq = M.qoff + g.q0 - (int64_t)g.t0;
+                        it.tlo = tlo;
+                        it.len = (uint16_t)(thi - tlo);
+                        uint32_t f = (g.flags & SEG_DEL) ? NQI_DEL : g.len == 0 ? NQI_INSONLY : NQI_MATCH;
+                        if ((g.flags & SEG_INS) && tlo == g.t0) f |= NQI_INS;
+                        f |= hp << NQI_HAP_SHIFT;
+                        it.flags = (uint16_t)f;
+                        out[total + at + n] = it;
+                    }
+                    n++;
+                }
+            }
+            if (pass == 0) {
+                mine = n;
+                const uint32_t incl = (uint32_t)wave_incl_add((int)n, lane);
+                at = incl - n;
+                const uint32_t batch = (uint32_t)lane_val((int)incl, 63);
+                if (total + batch > (uint32_t)NQ_ITEMS) {           // more than the plan holds: the tile goes to k_norm_tile
+                    if (lane == 0) {
+                        counts[chunk * tpc + k] = NQ_PLAN_OVER;
+                        const unsigned int w = atomicAdd(nredo, 1u);
+                        if (w < redo_cap) { NormRedo z; z.chunk = chunk; z.base = base; redo[w] = z; }
+                    }
+                    return;
+                }
+            }
+        }
+        total += (uint32_t)lane_val(wave_incl_add((int)mine, lane), 63);
+    }
+    if (lane == 0) counts[chunk * tpc + k] = total;
+}
+
+// packed per-lane column flags
+constexpr uint32_t NQF_CLS = 0, NQF_RAL = 4, NQF_ZERO = 12, NQF_INDEL = 16, NQF_OVER = 20;
+
 template <bool PHASE>
 __global__ void __launch_bounds__(NQ_WAVES * 64, HIMUT_NQ_OCC)
-k_norm_quad(NormArgs A, Derived D, const uint32_t* __restrict__ callable, const int32_t* winlo, const int32_t* winhi, int64_t nblk,
-            int64_t tiles_per_class, NormDirty* dirty, unsigned long long* dcount, int64_t dirty_cap, int* dirty_over,
-            NormRedo* redo, unsigned int* nredo, unsigned int redo_cap) {
+k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, const NqItem* __restrict__ items,
+            const uint32_t* __restrict__ counts, int64_t tpc, int64_t tiles_per_class, NormDirty* dirty, uint32_t* dcount,
+            int64_t dirty_cap, int* dirty_over, NormRedo* redo, unsigned int* nredo, unsigned int redo_cap, unsigned int pool_limit) {
     __shared__ double s_lut[3 * 257];         // three tables of 256 qualities + a zero entry each (index 256)
     __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
     __shared__ unsigned int s_ccs[32], s_ref[32];
     __shared__ NqPool s_pool[NQ_WAVES];
     __shared__ int s_bad;                     // a base outside ATGC was seen (the reference raises KeyError)
+    __shared__ unsigned int s_ndirty;         // positions this workgroup has left to k_norm_dirty
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     for (int i = tid; i < 3 * 256; i += NQ_WAVES * 64) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 255];
     if (tid < 3) s_lut[tid * 257 + 256] = 0.0;
     if (tid < 4) s_prior[tid] = A.lut->prior[tid];
     if (tid < 16) s_log[tid] = 0;
     if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
-    if (tid == 0) s_bad = 0;
+    if (tid == 0) { s_bad = 0; s_ndirty = 0; }
     __syncthreads();
+    const uint32_t lut = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)s_lut);
     NqPool& pool = s_pool[wv];
     const int chunk = blockIdx.y;
-    const int64_t dregion = (int64_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NORM_DIRTY_REGIONS - 1));   // this workgroup's part of the list
+    // this workgroup's part of the list of positions left to k_norm_dirty: filled from its start, the counter in LDS until the end
+    const int64_t dregion = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
     constexpr bool phase = PHASE;
-    const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
     const Reads& R = A.R;
     int bad = 0;
-    // per-lane load offsets of a spanning row (kept in vector registers: the loads then take a scalar base + this offset)
-    uint32_t o_q = 4u * (uint32_t)lane, o_s = 2u * (uint32_t)lane, o_b = (uint32_t)lane >> 1;
-    const uint32_t bsh_lane = 4u * ((uint32_t)lane & 1u);
+    const uint32_t o_q = 4u * (uint32_t)lane;                   // this lane's offset into a spanning piece's 256 qualities
     constexpr int NB = HIMUT_NQ_NB;
     const int64_t per = tiles_per_class;
     for (int64_t t = blockIdx.x >> 3; t < per; t += (int64_t)(gridDim.x >> 3)) {         // the tile mapping of k_norm_tile
-        const int64_t tile = (int64_t)(blockIdx.x & 7) * per + t;
-        const int64_t base = (int64_t)cs_ + tile * NQ_WG_COLS + NQ_COLS * wv;             // this wave's 256 positions
-        if (base >= ce_) { if ((int64_t)cs_ + tile * NQ_WG_COLS >= ce_) break; continue; }   // (this wave's part lies behind the chunk)
-        const int64_t P0l = base + 4 * lane;
-        const int32_t P0 = (int32_t)P0l;
-        // ---- the columns: which of the four exist, their reference letters and the two beside them
+        const int64_t tile = ((int64_t)(blockIdx.x & 7) * per + t) * NQ_WAVES + wv;       // this wave's 256 positions
+        const int64_t base64 = (int64_t)cs_ + tile * NQ_COLS;
+        if (base64 >= ce_) { if (base64 - NQ_COLS * wv >= ce_) break; continue; }          // (this wave's part lies behind the chunk)
+        const uint32_t n_items = uni(counts[chunk * tpc + tile]);
+        if (n_items == NQ_PLAN_OVER) continue;                                            // (k_norm_plan listed it for k_norm_tile)
+        if (n_items > (uint32_t)NQ_ITEMS) { bad |= 1 << HIMUT_ERR_ARG; continue; }
+        const NqItem* plan = items + (chunk * tpc + tile) * NQ_ITEMS;
+        const int32_t base = (int32_t)base64;
+        const int32_t P0 = base + 4 * lane;
+        // ---- the columns: which of the four exist, their reference letters
         uint32_t valid4 = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int64_t rp = P0l + j;
+            const int64_t rp = (int64_t)P0 + j;
             if (rp < ce_) {
                 if (rp < 0 || rp >= A.reflen) bad |= 1 << HIMUT_ERR_ARG;                   // IndexError in the reference
                 else valid4 |= 1u << j;
             }
         }
-        uint32_t rl_lo = 0x4e4e4e4eu, rl_hi = 0x4e4e4e4eu;       // the letters at P0 - 1 .. P0 + 2 and P0 + 3 .. P0 + 6 ("N" outside)
+        // the letters at P0 - 1 .. P0 + 6 (0 outside the string): the columns' own and, for the trinucleotides, their neighbours'
+        uint64_t six = 0;
         if (valid4) {
-            if (P0l >= 1 && P0l + 7 <= A.reflen) {                // (the array has slack behind it, but its end is the contig's)
-                rl_lo = nq_ld32((uint64_t)A.refseq, (uint32_t)(P0l - 1));
-                rl_hi = nq_ld32((uint64_t)A.refseq, (uint32_t)(P0l + 3));
+            uint32_t lo = 0, hi = 0;
+            if (P0 >= 1 && (int64_t)P0 + 7 <= A.reflen) {
+                lo = nq_ld32((uint64_t)A.refseq, (uint32_t)(P0 - 1));
+                hi = nq_ld32((uint64_t)A.refseq, (uint32_t)(P0 + 3));
             } else {
-                uint32_t lo = 0, hi = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const int64_t p = P0l - 1 + k;
-                    const uint32_t c = (p >= 0 && p < A.reflen) ? (uint32_t)A.refseq[p] : 0u;   // 0: outside the string
+                    const int64_t p = (int64_t)P0 - 1 + k;
+                    const uint32_t c = (p >= 0 && p < A.reflen) ? (uint32_t)A.refseq[p] : 0u;
                     if (k < 4) lo |= c << (8 * k); else hi |= c << (8 * (k - 4));
                 }
-                rl_lo = lo; rl_hi = hi;
             }
+            six = (uint64_t)lo | ((uint64_t)hi << 32);
         }
-        const uint32_t letters = (rl_lo >> 8) | (rl_hi << 24);   // the four columns' own letters
-        int ref[4];
-        uint32_t ref4 = 0, force4 = 0, cls4 = 0;                 // packed BAM codes (column j in bits 12 - 4j ..), never-equal marks, classifiable columns
+        // packed per column j: ref4 the BAM code to match (bits 12 - 4j ..) and, sixteen bits up, a never-equal mark; fl the
+        // flags: "an upper-case ATGC letter: the position is classified", the allele (two bits), a zero quality seen, an
+        // insertion or deletion seen, and bit NQF_OVER: the pool ran out
+        uint32_t ref4 = 0, fl = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int c = (int)((letters >> (8 * j)) & 255u);
-            ref[j] = ((valid4 >> j) & 1u) ? char2allele(c) : -1;
+            const int c = (int)((six >> (8 * (j + 1))) & 255u);
+            const int al = ((valid4 >> j) & 1u) ? char2allele(c) : -1;
             // a column whose letter is not one of ATGC is never classified; its cells are matched against the upper-case
             // letter so that they stay on the common path (a base outside ATGC is still found: it equals no letter)
             const int cu = c & 0xdf;
             const uint32_t nib = cu == 'A' ? 1u : cu == 'C' ? 2u : cu == 'G' ? 4u : cu == 'T' ? 8u : 0u;
             ref4 |= nib << (12 - 4 * j);
-            if (nib == 0) force4 |= 1u << (12 - 4 * j);
-            if (ref[j] >= 0) cls4 |= 1u << j;
+            if (nib == 0) ref4 |= 0x10000u << (12 - 4 * j);
+            if (al >= 0) fl |= (1u << (NQF_CLS + j)) | ((uint32_t)al << (NQF_RAL + 2 * j));
         }
         // ---- per-column state
         double R0[4], R1[4], R2[4];
@@ -149,220 +319,173 @@ k_norm_quad(NormArgs A, Derived D, const uint32_t* __restrict__ callable, const 
 #pragma unroll
         for (int j = 0; j < 4; j++) { R0[j] = 0.0; R1[j] = 0.0; R2[j] = 0.0; nref[j] = 0; tri[j] = 0; }
         uint32_t tri4b = 0;                    // callable bases of the running batch, a byte per column
-        uint32_t indel4 = 0, zero4 = 0;        // columns with an insertion or a deletion; with a zero quality
         uint32_t slotmap = 0xffffffffu;        // pool slot per column (255: none)
-        uint32_t h0g[4], h1g[4];               // (phase) haplotype votes of the rows that do not span
+        uint32_t h0g[4], h1g[4];               // (phase) the reads of either haplotype with a base in the column
         uint32_t h0b = 0, h1b = 0;
-        uint32_t h0_span = 0, h1_span = 0;     // (phase) spanning rows per haplotype: the same for every column
         if (phase) {
 #pragma unroll
             for (int j = 0; j < 4; j++) { h0g[j] = 0; h1g[j] = 0; }
         }
-        bool over = false;                     // the pool ran out: the tile goes to k_norm_tile
         if (lane == 0) pool.n = 0;
         __builtin_amdgcn_wave_barrier();
 
-        // one cell of another allele than the reference's (or a base outside ATGC), column J, BAM code NIB, quality Q
-        auto alt_cell = [&](int J, uint32_t nibv, uint32_t q) {
-            const uint32_t cell = (uint32_t)nib2allele((int)nibv);
-            if (cell > 3) { s_bad = 1 << HIMUT_ERR_BASE; return; }
-            if (!((cls4 >> J) & 1u) || q == 0) return;                      // (never classified / ends at the classification)
-            uint32_t slot = (slotmap >> (8 * J)) & 255u;
-            if (slot == 255u) {
-                slot = atomicAdd(&pool.n, 1u);
-                if (slot >= (uint32_t)NQ_SLOTS) { over = true; return; }
-#pragma unroll
-                for (int k = 0; k < 9; k++) pool.S[k][slot] = 0.0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) pool.cnt[k][slot] = 0;
-                slotmap = (slotmap & ~(255u << (8 * J))) | (slot << (8 * J));
-            }
-            const uint32_t a_ = min(cell - ((int)cell > ref[J] ? 1u : 0u), 2u);
-            pool.S[a_][slot] = pool.S[a_][slot] + s_lut[q];
-            pool.S[3 + a_][slot] = pool.S[3 + a_][slot] + s_lut[257 + q];
-            pool.S[6 + a_][slot] = pool.S[6 + a_][slot] + s_lut[514 + q];
-            pool.cnt[cell][slot] = pool.cnt[cell][slot] + 1u;
-        };
-        // The update of four cells of one read: qualities qv (byte j = column j), BAM codes n4 (column j in bits 12 - 4j ..),
-        // callable bits cb (bit j), cm = which of the four are cells of this read at all (15 for a spanning row)
-        auto update4 = [&](uint32_t qv, uint32_t n4, uint32_t cb, uint32_t cm, bool full) {
-            uint32_t x = (n4 ^ ref4) | force4;                               // a nibble of zeros: the reference allele
-            if (!full) {
-                const uint32_t keep = (cm & 1u ? 0xf000u : 0u) | (cm & 2u ? 0x0f00u : 0u) | (cm & 4u ? 0x00f0u : 0u) | (cm & 8u ? 0x000fu : 0u);
-                x &= keep;
-                cb &= cm;
-            }
-            tri4b += nq_spread4(cb);
-#pragma unroll
+        // rare: the cells of one item again, one by one -- a cell of another allele goes to the pool, a base outside ATGC and a
+        // zero quality are noted.  qk / nk: the item's qualities and BAM codes, ck: which of the four cells are there
+        auto rare_item = [&](uint32_t qk, uint32_t nk, uint32_t ck) {
+            const uint32_t x = (nk ^ ref4) | (ref4 >> 16);
+#pragma unroll 1
             for (int j = 0; j < 4; j++) {
-                const bool isref = ((x >> (12 - 4 * j)) & 15u) == 0u && (full || ((cm >> j) & 1u));
-                const uint32_t q = (qv >> (8 * j)) & 255u;
-                const uint32_t e = isref ? q : 256u;                        // the zero row for everything but the reference allele
-                nref[j] += isref ? 1u : 0u;
-                R0[j] = R0[j] + s_lut[e]; R1[j] = R1[j] + s_lut[257 + e]; R2[j] = R2[j] + s_lut[514 + e];
-            }
-            uint32_t zq = nq_zero_bytes(qv);
-            if (!full && zq) {                                               // (only the zero bytes of cells that are there)
-                zq = 0;
+                if (!((ck >> j) & 1u)) continue;
+                const uint32_t q = (qk >> (8 * j)) & 255u;
+                if (q == 0u) fl |= 1u << (NQF_ZERO + j);
+                if (!((x >> (12 - 4 * j)) & 15u)) continue;
+                const uint32_t cell = (uint32_t)nib2allele((int)((nk >> (12 - 4 * j)) & 15u));
+                if (cell > 3) { s_bad = 1 << HIMUT_ERR_BASE; continue; }
+                if (!((fl >> (NQF_CLS + j)) & 1u) || q == 0u) continue;       // (never classified / ends at the classification)
+                uint32_t slot = (slotmap >> (8 * j)) & 255u;
+                if (slot == 255u) {
+                    slot = atomicAdd(&pool.n, 1u);
+                    if (slot >= pool_limit) { fl |= 1u << NQF_OVER; continue; }
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (((cm >> j) & 1u) && ((qv >> (8 * j)) & 255u) == 0u) zq |= 1u;
-            }
-            if (__builtin_expect((x | zq) != 0u, 0)) {                       // rare: another allele, a base outside ATGC, a zero quality
+                    for (int z = 0; z < 9; z++) pool.S[z][slot] = 0.0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (!full && !((cm >> j) & 1u)) continue;
-                    const uint32_t q = (qv >> (8 * j)) & 255u;
-                    if (q == 0u) zero4 |= 1u << j;
-                    if ((x >> (12 - 4 * j)) & 15u) alt_cell(j, (n4 >> (12 - 4 * j)) & 15u, q);
+                    for (int z = 0; z < 4; z++) pool.cnt[z][slot] = 0;
+                    slotmap = (slotmap & ~(255u << (8 * j))) | (slot << (8 * j));
                 }
+                const uint32_t rj = (fl >> (NQF_RAL + 2 * j)) & 3u;
+                const uint32_t a_ = min(cell - (cell > rj ? 1u : 0u), 2u);   // allele c sits in slot c - (c > ref)
+                pool.S[a_][slot] = pool.S[a_][slot] + s_lut[q];
+                pool.S[3 + a_][slot] = pool.S[3 + a_][slot] + s_lut[257 + q];
+                pool.S[6 + a_][slot] = pool.S[6 + a_][slot] + s_lut[514 + q];
+                pool.cnt[cell][slot] = pool.cnt[cell][slot] + 1u;
             }
         };
 
-        const int64_t b0 = min(max(base, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min((base + NQ_COLS - 1) >> WIN_SHIFT, nblk - 1);
-        const int32_t lo = uni(winlo[b0]), hi = uni(winhi[b1]);
-        for (int32_t r0 = lo; r0 < hi; r0 += 64) {
-            // ---- a lane per row: header, the last segment that starts at or before the positions, the spanning test
-            const int nb = min(64, hi - r0);
-            ReadMeta M;
-            M.tstart = 0; M.tend = 0; M.nseg = 0; M.flags = RF_SECONDARY; M.segbase = 0; M.qoff = 0;
-            if (lane < nb) M = D.meta[r0 + lane];
-            const bool live_row = lane < nb && !(M.flags & RF_SECONDARY) && M.nseg > 0 && M.tstart < base + NQ_COLS && M.tend >= base;
-            int j0 = 0;
-            int4 sg0 = make_int4(0x7fffffff, 0, 0, 0);
-            if (live_row) {
-                // the starts of the read's first eight segments in one round trip; the binary search, a round trip a step, only
-                // where the segment lies further on
-                constexpr int NP = 8;
-                int32_t tp[NP];
-#pragma unroll
-                for (int k = 0; k < NP; k++) tp[k] = D.segs[M.segbase + min(k, M.nseg - 1)].t0;
-                int a = 0;
-#pragma unroll
-                for (int k = 0; k < NP; k++) a += (k < M.nseg && tp[k] <= (int32_t)base) ? 1 : 0;       // (starts ascend: the first `a` of them)
-                if (a == NP && M.nseg > NP) {
-                    int e = M.nseg;
-                    while (a < e) { const int m = (a + e) >> 1; if (D.segs[M.segbase + m].t0 <= (int32_t)base) a = m + 1; else e = m; }
-                }
-                j0 = max(a - 1, 0);
-                sg0 = *reinterpret_cast<const int4*>(D.segs + M.segbase + j0);
+        for (uint32_t i0 = 0; i0 < n_items; i0 += 64) {
+            // ---- a lane per item
+            const int nb = (int)min(64u, n_items - i0);
+            int64_t kq = 0;
+            int32_t tlo = 0;
+            uint32_t lf = 0;                                  // len | flags << 16
+            if (lane < nb) {
+                const int4 raw = *reinterpret_cast<const int4*>(plan + i0 + lane);
+                kq = ((int64_t)raw.y << 32) | (uint32_t)raw.x; tlo = raw.z; lf = (uint32_t)raw.w;
             }
-            // the bases of a batch's reads lie side by side in the arrays: a row's first base as a distance from the first
-            // read's first base (a row further away than 2^31, which does not happen, takes the general path)
-            const int64_t Kb = (int64_t)nq_lane64(M.qoff, 0);
-            const int64_t K0 = M.qoff + sg0.y + ((int32_t)base - sg0.x);
-            const int64_t dK = K0 - Kb;
-            const bool whole = live_row && !((uint32_t)sg0.w & SEG_DEL) && sg0.x <= (int32_t)base &&
-                               (int64_t)sg0.x + sg0.z >= base + NQ_COLS && dK >= 0 && dK < ((int64_t)1 << 31);
-            const int dqv = whole ? (int)dK : 0;
-            uint32_t hp = HAP_NONE;
-            if (phase && live_row && M.tstart < ce_ && M.tend > cs_) hp = A.H.hap[pairbase + r0 + lane];   // fetched by the chunk
-            const uint64_t m_live = __ballot(live_row), m_whole = __ballot(whole);
-            const uint64_t m_slow = m_live & ~m_whole;
-            const uint64_t m_hnone = phase ? __ballot(hp != HAP_0 && hp != HAP_1) : 0;
-            // counts that do not depend on the order: an insertion in front of a spanning segment that starts with the
-            // positions is counted at the first of them; every cell of a spanning row is a base of its haplotype
-            const uint64_t m_ins0 = __ballot(whole && sg0.x == (int32_t)base && ((uint32_t)sg0.w & SEG_INS));
-            if (lane == 0 && m_ins0) indel4 |= 1u;
-            if (phase) {
-                h0_span += (uint32_t)__builtin_popcountll(__ballot(whole && hp == HAP_0));
-                h1_span += (uint32_t)__builtin_popcountll(__ballot(whole && hp == HAP_1));
+            bool is_item = lane < nb;
+            // (a piece whose bases lie outside the arrays, or outside the tile, cannot come out of k_norm_plan; acting on one
+            //  would be a memory fault, so it is looked for)
+            if (is_item && (tlo < base || (int64_t)tlo + (lf & 0xffffu) > (int64_t)base + NQ_COLS || (lf & 0xffffu) == 0 ||
+                            (((lf >> 16) & NQI_TYPE) == NQI_MATCH && (kq + tlo < 0 || kq + tlo + (int64_t)(lf & 0xffffu) > nbases)))) {
+                bad |= 1 << HIMUT_ERR_ARG;
+                is_item = false;
             }
-            // ---- the live rows in read order
-            uint64_t m = m_live;
+            const uint32_t ifl = lf >> 16;
+            const bool full = is_item && (ifl & NQI_TYPE) == NQI_MATCH && tlo == base && (lf & 0xffffu) == (uint32_t)NQ_COLS;
+            const uint64_t m_full = __ballot(full);
+            // ---- the items in read order.  What an item adds comes as four cells per lane: qualities qv (byte j = column j),
+            //      BAM codes n4 (column j in bits 12 - 4j ..), callable bits cb.  The nine items in ten that span the tile go
+            //      NB at a time, their loads issued together: a scalar base plus a fixed offset per lane
+            uint64_t m = __ballot(is_item);
             while (m) {
-                // do NB spanning rows follow each other?  (live rows in front of the next row of the other kind)
-                const uint64_t ms = m & m_slow;
+                const uint64_t ms = m & ~m_full;
                 const uint64_t front = ms ? (m & ((ms & (0 - ms)) - 1)) : m;
-                asm volatile("" : "+v"(o_q), "+v"(o_s), "+v"(o_b));
-                if (__builtin_popcountll(front) >= NB) {
-                    uint32_t qv[NB], sv[NB], bv[NB], sh_s[NB], sh_b[NB];
-                    bool hn[NB];
+                if (front) {
+                    // up to NB of them: cnt items sit in the LAST cnt of the NB places, and both the loads and the updates are
+                    // entered at the place of the first (a switch that falls through): every update stands in the text once
+                    // and runs unconditionally from its entry on
+                    const int cnt = min(NB, (int)__builtin_popcountll(front));
+                    uint32_t qv[NB], n4[NB], cb[NB], shs[NB], shb[NB], ifk[NB];
+#define NQ_LOAD(k) { \
+                        const int l = (int)__builtin_ctzll(m); \
+                        m &= m - 1; \
+                        const uint64_t Kr = nq_lane64(kq, l) + (uint64_t)(int64_t)base; \
+                        ifk[k] = (uint32_t)lane_val((int)ifl, l); \
+                        shs[k] = (Kr & 1u) ? 12u : 16u; \
+                        shb[k] = (uint32_t)(Kr & 7u); \
+                        qv[k] = nq_ld32((uint64_t)R.bq + Kr, o_q); \
+                        n4[k] = nq_ld32((uint64_t)R.seq + (Kr >> 1), o_q >> 1); \
+                        cb[k] = nq_ld16((uint64_t)callable + (Kr >> 3), o_q >> 3); }
 #pragma unroll
-                    for (int k = 0; k < NB; k++) {
-                        const int l = (int)__builtin_ctzll(m);
-                        m &= m - 1;
-                        const uint64_t Kr = (uint64_t)Kb + (uint32_t)lane_val(dqv, l);
-                        sh_s[k] = (Kr & 1u) ? 12u : 16u;
-                        sh_b[k] = (uint32_t)(Kr & 7u);
-                        hn[k] = phase && ((m_hnone >> l) & 1);
-                        qv[k] = nq_ld32((uint64_t)R.bq + Kr, o_q);
-                        sv[k] = nq_ld32((uint64_t)R.seq + (Kr >> 1), o_s);
-                        bv[k] = nq_ld16((uint64_t)callable + (Kr >> 3), o_b);
+                    for (int k = 0; k < NB; k++) { qv[k] = 0x01010101u; n4[k] = 0; cb[k] = 0; shs[k] = 16; shb[k] = 0; ifk[k] = 0; }
+                    static_assert(NB == 4, "the switches below are written for four places");
+                    switch (cnt) {
+                        case 4: NQ_LOAD(0) [[fallthrough]];
+                        case 3: NQ_LOAD(1) [[fallthrough]];
+                        case 2: NQ_LOAD(2) [[fallthrough]];
+                        default: NQ_LOAD(3)
                     }
+#undef NQ_LOAD
+                    uint32_t rare = 0;
+#define NQ_UPDATE(k) { \
+                        n4[k] = (__builtin_bswap32(n4[k]) >> shs[k]) & 0xffffu; \
+                        uint32_t cbk = (cb[k] >> (shb[k] + (o_q & 4u))) & 15u; \
+                        if (ifk[k] & NQI_INS) fl |= (lane == 0 ? 1u : 0u) << NQF_INDEL;     /* an insertion in front of the piece: counted at its first position */ \
+                        if (phase) { \
+                            const uint32_t hap = (ifk[k] >> NQI_HAP_SHIFT) & 3u; \
+                            if (hap == HAP_0) h0b += 0x01010101u; \
+                            else if (hap == HAP_1) h1b += 0x01010101u; \
+                            else cbk = 0;                                        /* the read carries no haplotype in this chunk: no bit of it counts */ \
+                        } \
+                        const uint32_t x = (n4[k] ^ ref4) | (ref4 >> 16);           /* a nibble of zeros: the reference allele */ \
+                        tri4b += nq_spread4(cbk); \
+                        nq_pair<0>(R0[0], R1[0], R2[0], nref[0], R0[1], R1[1], R2[1], nref[1], qv[k], x, lut); \
+                        nq_pair<2>(R0[2], R1[2], R2[2], nref[2], R0[3], R1[3], R2[3], nref[3], qv[k], x, lut); \
+                        if ((x & 0xffffu) | nq_zero_bytes(qv[k])) rare |= 1u << k; }
+                    switch (cnt) {
+                        case 4: NQ_UPDATE(0) [[fallthrough]];
+                        case 3: NQ_UPDATE(1) [[fallthrough]];
+                        case 2: NQ_UPDATE(2) [[fallthrough]];
+                        default: NQ_UPDATE(3)
+                    }
+#undef NQ_UPDATE
+                    if (__builtin_expect(__ballot(rare != 0) != 0, 0)) {
+#pragma unroll 1
+                        for (int k = NB - cnt; k < NB; k++) {
+                            uint32_t qk = qv[0], nk = n4[0];
 #pragma unroll
-                    for (int k = 0; k < NB; k++) {
-                        const uint32_t n4 = (__builtin_bswap32(sv[k]) >> sh_s[k]) & 0xffffu;
-                        uint32_t cb = (bv[k] >> (sh_b[k] + bsh_lane)) & 15u;
-                        if (phase && hn[k]) cb = 0;                          // the read carries no haplotype in this chunk
-                        update4(qv[k], n4, cb, 15u, true);
+                            for (int kk = 1; kk < NB; kk++) if (k == kk) { qk = qv[kk]; nk = n4[kk]; }
+                            if ((rare >> k) & 1u) rare_item(qk, nk, 15u);
+                        }
                     }
                     continue;
                 }
-                const int l0 = (int)__builtin_ctzll(m);
+                // ---- an item that covers a part of the positions (an indel or a read end inside them, the chunk's last tile): the
+                //      same update under a mask of cells
+                const int gl = (int)__builtin_ctzll(m);
                 m &= m - 1;
-                if ((m_whole >> l0) & 1) {                               // a spanning row by itself
-                    const uint64_t Kr = (uint64_t)Kb + (uint32_t)lane_val(dqv, l0);
-                    const uint32_t q1 = nq_ld32((uint64_t)R.bq + Kr, o_q);
-                    const uint32_t s1 = nq_ld32((uint64_t)R.seq + (Kr >> 1), o_s);
-                    const uint32_t b1_ = nq_ld16((uint64_t)callable + (Kr >> 3), o_b);
-                    const uint32_t n4 = (__builtin_bswap32(s1) >> ((Kr & 1u) ? 12u : 16u)) & 0xffffu;
-                    uint32_t cb = (b1_ >> ((uint32_t)(Kr & 7u) + bsh_lane)) & 15u;
-                    if (phase && ((m_hnone >> l0) & 1)) cb = 0;
-                    update4(q1, n4, cb, 15u, true);
-                    continue;
-                }
-                // ---- the general row: segment by segment from the cursor on, the same update under a mask of cells
-                {
-                    const int ns = lane_val(M.nseg, l0), jf = lane_val(j0, l0);
-                    const uint64_t segbase = nq_lane64(M.segbase, l0), qoff = nq_lane64(M.qoff, l0);
-                    const int32_t tend_r = lane_val(M.tend, l0);
-                    uint32_t hps = HAP_NONE;
-                    if (phase) hps = (uint32_t)lane_val((int)hp, l0);
-                    const bool hap_ok = !phase || hps == HAP_0 || hps == HAP_1;
-                    for (int j = jf; j < ns; j++) {
-                        int32_t t0, q0, len;
-                        uint32_t fl;
-                        if (j == jf) {                                   // (the row vector holds it)
-                            t0 = lane_val(sg0.x, l0); q0 = lane_val(sg0.y, l0); len = lane_val(sg0.z, l0); fl = (uint32_t)lane_val(sg0.w, l0);
-                        } else {
-                            const Seg g = D.segs[segbase + j];
-                            t0 = uni(g.t0); q0 = uni(g.q0); len = uni(g.len); fl = uni(g.flags);
-                        }
-                        if (t0 >= base + NQ_COLS) break;
-                        const int32_t span = len > 0 ? len : ((fl & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
-                        // this lane's cells of the segment: columns jlo .. jhi - 1
-                        const int32_t jlo = min(max(t0 - P0, 0), 4), jhi = min(max(t0 + span - P0, 0), 4);
-                        uint32_t cm = jhi > jlo ? (((1u << (jhi - jlo)) - 1u) << jlo) : 0u;
-                        // a read this chunk did not fetch (normcounts.py:289) adds nothing: only its trailing insertion can reach in
-                        if (!(tend_r > cs_)) {
-#pragma unroll
-                            for (int jj = 0; jj < 4; jj++) if (P0 + jj <= cs_) cm &= ~(1u << jj);
-                        }
-                        cm &= valid4;
-                        // an insertion in front of the segment is counted at its first position
-                        if ((fl & SEG_INS) && P0 <= t0 && t0 < P0 + 4 && ((cm >> (t0 - P0)) & 1u)) indel4 |= 1u << (t0 - P0);
-                        if (fl & SEG_DEL) { indel4 |= cm; continue; }
-                        if (len == 0 || !__ballot(cm != 0)) continue;
-                        if (cm) {
-                            // the first of the lane's cells is query base off (from the read's first): loads from there on, brought
-                            // to the columns' places (nothing in front of the segment is touched: the first read has nothing there)
-                            const uint32_t off = (uint32_t)(q0 + (P0 + jlo - t0));
-                            const uint32_t qraw = nq_ld32((uint64_t)R.bq + qoff, off);
-                            const uint64_t ks = qoff + off;                  // absolute base index
-                            const uint32_t sraw = nq_ld32((uint64_t)R.seq, (uint32_t)(ks >> 1));
-                            const uint32_t braw = nq_ld16((uint64_t)callable, (uint32_t)(ks >> 3));
-                            const uint32_t qv = qraw << (8 * jlo);
-                            const uint32_t n4 = ((__builtin_bswap32(sraw) >> ((ks & 1u) ? 12u : 16u)) & 0xffffu) >> (4 * jlo);
-                            uint32_t cb = ((braw >> (uint32_t)(ks & 7u)) & 15u) << jlo;
-                            if (!hap_ok) cb = 0;
-                            update4(qv, n4, cb, cm, false);
-                            if (phase) {
-                                if (hps == HAP_0) h0b += nq_spread4(cm);
-                                else if (hps == HAP_1) h1b += nq_spread4(cm);
-                            }
-                        }
+                const int32_t g_tlo = lane_val(tlo, gl);
+                const uint32_t g_lf = (uint32_t)lane_val((int)lf, gl);
+                const uint32_t g_fl = g_lf >> 16, g_len = g_lf & 0xffffu, g_hap = (g_fl >> NQI_HAP_SHIFT) & 3u;
+                // this lane's cells of the piece: columns jlo .. jhi - 1
+                const int32_t jlo = min(max(g_tlo - P0, 0), 4), jhi = (int32_t)min(max((int64_t)g_tlo + g_len - P0, (int64_t)0), (int64_t)4);
+                const uint32_t c4 = (jhi > jlo ? (((1u << (jhi - jlo)) - 1u) << jlo) : 0u) & valid4;
+                // an insertion in front of the piece is counted at its first position
+                if ((g_fl & NQI_INS) && P0 <= g_tlo && g_tlo < P0 + 4 && ((c4 >> (g_tlo - P0)) & 1u)) fl |= 1u << (NQF_INDEL + (g_tlo - P0));
+                if ((g_fl & NQI_TYPE) == NQI_DEL) { fl |= c4 << NQF_INDEL; continue; }
+                if ((g_fl & NQI_TYPE) != NQI_MATCH || !__ballot(c4 != 0)) continue;
+                uint32_t qv1 = 0x01010101u, n41 = 0, cb1 = 0;
+                if (c4) {
+                    // the first of the lane's cells is query base ks of the arrays: loads from there on, brought to the columns'
+                    // places (nothing in front of the piece is touched: the first read has nothing there)
+                    const uint64_t ks = nq_lane64(kq, gl) + (uint64_t)(int64_t)(P0 + jlo);
+                    const uint32_t qraw = nq_ld32((uint64_t)R.bq + ks, 0u);
+                    const uint32_t sraw = nq_ld32((uint64_t)R.seq + (ks >> 1), 0u);
+                    const uint32_t braw = nq_ld16((uint64_t)callable + (ks >> 3), 0u);
+                    qv1 = (qraw << (8 * jlo)) | ~(0xffffffffu << (8 * jlo));      // (bytes in front: not zero)
+                    n41 = ((__builtin_bswap32(sraw) >> ((ks & 1u) ? 12u : 16u)) & 0xffffu) >> (4 * jlo);
+                    cb1 = (((braw >> (uint32_t)(ks & 7u)) & 15u) << jlo) & c4;
+                    if (phase) {
+                        if (g_hap == HAP_0) h0b += nq_spread4(c4);
+                        else if (g_hap == HAP_1) h1b += nq_spread4(c4);
+                        else cb1 = 0;
                     }
                 }
+                const uint32_t keep = (c4 & 1u ? 0xf000u : 0u) | (c4 & 2u ? 0x0f00u : 0u) | (c4 & 4u ? 0x00f0u : 0u) | (c4 & 8u ? 0x000fu : 0u);
+                const uint32_t x = (n41 ^ ref4) | (ref4 >> 16);
+                tri4b += nq_spread4(cb1);
+                nq_pair<0>(R0[0], R1[0], R2[0], nref[0], R0[1], R1[1], R2[1], nref[1], qv1, x | ~keep, lut);
+                nq_pair<2>(R0[2], R1[2], R2[2], nref[2], R0[3], R1[3], R2[3], nref[3], qv1, x | ~keep, lut);
+                if (__builtin_expect(__ballot(((x & keep) | nq_zero_bytes(qv1)) != 0) != 0, 0)) rare_item(qv1, n41, c4);
             }
             // ---- the batch's byte counters into the columns' words
 #pragma unroll
@@ -375,68 +498,87 @@ k_norm_quad(NormArgs A, Derived D, const uint32_t* __restrict__ callable, const 
             }
         }
         // ---- the pool ran out somewhere in the wave: the 256 positions go to k_norm_tile as they are
-        if (__ballot(over)) {
+        if (__ballot((fl >> NQF_OVER) & 1u)) {
             if (lane == 0) {
                 const unsigned int at = atomicAdd(nredo, 1u);
-                if (at < redo_cap) { NormRedo z; z.chunk = chunk; z.base = (int32_t)base; redo[at] = z; }
+                if (at < redo_cap) { NormRedo z; z.chunk = chunk; z.base = base; redo[at] = z; }
             }
             continue;
         }
-        // ---- the positions' classes (normcounts.py:317-402), in the order of the general text (NORM_CLASSIFY).  The counters
-        //      nearly every position adds to are summed over the lane's columns and the wave first
+        // ---- the positions' classes (normcounts.py:317-402), in the order of the general text (NORM_CLASSIFY), the lane's four
+        //      columns one after the other through one text (the state is rotated).  The counters nearly every position adds
+        //      to are summed over the lane's columns and the wave first
         uint32_t w1 = 0, w2 = 0, w6 = 0, w13 = 0;
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j < 4; j++) {
-            const int64_t rpos = P0l + j;
-            const uint32_t tri_sum = tri[j];
-            const bool cls = ((cls4 >> j) & 1u) && tri_sum != 0;
+            const int64_t rpos = (int64_t)P0 + j;
+            const uint32_t tri_sum = tri[0];
+            const bool cls = ((fl >> NQF_CLS) & 1u) && tri_sum != 0;
             uint32_t h0 = 0, h1 = 0;
-            if (phase) { h0 = h0_span + h0g[j]; h1 = h1_span + h1g[j]; }
+            if (phase) { h0 = h0g[0]; h1 = h1g[0]; }
             const bool hapfail = phase && cls && !((int64_t)h0 >= A.P.p.min_hap_count && (int64_t)h1 >= A.P.p.min_hap_count);
-            const bool q0 = cls && !hapfail && ((zero4 >> j) & 1u);
+            const bool q0 = cls && !hapfail && ((fl >> NQF_ZERO) & 1u);
             if (q0) bad |= 1 << HIMUT_ERR_BQ0;
             const bool open = cls && !hapfail && !q0;
-            const uint32_t slot = (slotmap >> (8 * j)) & 255u;
+            const uint32_t slot = slotmap & 255u;
             // Nothing but the reference allele in the column: the ten genotype sums are four numbers (an allele that was not
             // seen adds +0.0 to a sum, which leaves it bit for bit what it was).  When hom-ref is the smallest by itself it
             // is the genotype and the quality is the gap to the smallest of the rest; any other outcome, and any column
             // with another allele, goes to k_norm_dirty.
-            const double pa = -10.0 * (R0[j] + s_prior[0]), pb = -10.0 * (R1[j] + s_prior[1]);
-            const double pc = -10.0 * (R2[j] + s_prior[2]), pd = -10.0 * (R2[j] + s_prior[3]);
+            const double pa = -10.0 * (R0[0] + s_prior[0]), pb = -10.0 * (R1[0] + s_prior[1]);
+            const double pc = -10.0 * (R2[0] + s_prior[2]), pd = -10.0 * (R2[0] + s_prior[3]);
             const double nxt = fmin(pb, fmin(pc, pd));
             const bool mine = open && slot == 255u && pa < nxt;
             const double gqf = nxt - pa;
             const int gq = (gqf < 99.0) ? (int)gqf : 99;
-            const bool indel = (indel4 >> j) & 1u;
+            const bool indel = (fl >> NQF_INDEL) & 1u;
             int slotn = 13;
             if (indel) slotn = 7;
-            else if ((int64_t)nref[j] > A.P.p.md_threshold) slotn = 8;
+            else if ((int64_t)nref[0] > A.P.p.md_threshold) slotn = 8;
             else if (gq < A.P.p.min_gq) slotn = 10;
-            else if ((int64_t)nref[j] < A.P.p.min_ref_count) slotn = 9;
+            else if ((int64_t)nref[0] < A.P.p.min_ref_count) slotn = 9;
             w1 += (mine || hapfail) ? tri_sum : 0u;
             w2 += hapfail ? tri_sum : 0u;
             w6 += mine ? tri_sum : 0u;
             w13 += (mine && slotn == 13) ? tri_sum : 0u;
             if (mine && slotn != 13) atomicAdd(&s_log[slotn], tri_sum);
             if (mine && slotn == 13) {
-                const int refc = (int)((letters >> (8 * j)) & 255u);
-                const uint64_t six = (uint64_t)rl_lo | ((uint64_t)rl_hi << 32);
-                NORM_TRIBINS((int)((six >> (8 * j)) & 255u), (int)((six >> (8 * (j + 2))) & 255u))
+                const int refc = (int)((six >> 8) & 255u);
+                NORM_TRIBINS((int)(six & 255u), (int)((six >> 16) & 255u))
             }
-            if (open && !mine) {
-                // a place in the workgroup's region of the list: one atomic per wave and column index
-                const int64_t at = (int64_t)wave_reserve(dcount + dregion * 16);
-                if (at < dirty_cap) {
-                    NormDirty d;
-                    d.rpos = rpos; d.nref = nref[j]; d.tri_sum = tri_sum; d.n_ins = indel ? 1u : 0u; d.n_del = 0; d.h0 = h0; d.h1 = h1;
+            // a position left to k_norm_dirty: the next places in this workgroup's part of the list (one LDS atomic per wave)
+            const bool left = open && !mine;
+            const uint64_t lm = __ballot(left);
+            if (lm) {
+                uint32_t at0 = 0;
+                if (lane == 0) at0 = atomicAdd(&s_ndirty, (unsigned int)__builtin_popcountll(lm));
+                const uint32_t at = uni(at0) + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                if (left) {
+                    if ((int64_t)at < dirty_cap) {
+                        NormDirty* d = dirty + (dregion * dirty_cap + at);
+                        d->rpos = rpos; d->nref = nref[0]; d->tri_sum = tri_sum; d->n_ins = indel ? 1u : 0u; d->n_del = 0; d->h0 = h0; d->h1 = h1;
+                        d->R[0] = R0[0]; d->R[1] = R1[0]; d->R[2] = R2[0];
+                        if (slot != 255u) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) d.cnt[k] = slot != 255u ? pool.cnt[k][slot] : 0u;
-                    d.R[0] = R0[j]; d.R[1] = R1[j]; d.R[2] = R2[j];
+                            for (int k = 0; k < 4; k++) d->cnt[k] = pool.cnt[k][slot];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) d.S[k] = slot != 255u ? pool.S[k][slot] : 0.0;
-                    dirty[dregion * dirty_cap + at] = d;
-                } else *dirty_over = 1;              // more of them than there is room for: the host repeats the contig with k_norm_tile
+                            for (int k = 0; k < 9; k++) d->S[k] = pool.S[k][slot];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) d->cnt[k] = 0;
+#pragma unroll
+                            for (int k = 0; k < 9; k++) d->S[k] = 0.0;
+                        }
+                    } else *dirty_over = 1;          // more of them than there is room for: the host repeats the contig with k_norm_tile
+                }
             }
+            // the next column into place
+            R0[0] = R0[1]; R0[1] = R0[2]; R0[2] = R0[3]; R1[0] = R1[1]; R1[1] = R1[2]; R1[2] = R1[3];
+            R2[0] = R2[1]; R2[1] = R2[2]; R2[2] = R2[3];
+            nref[0] = nref[1]; nref[1] = nref[2]; nref[2] = nref[3]; tri[0] = tri[1]; tri[1] = tri[2]; tri[2] = tri[3];
+            if (phase) { h0g[0] = h0g[1]; h0g[1] = h0g[2]; h0g[2] = h0g[3]; h1g[0] = h1g[1]; h1g[1] = h1g[2]; h1g[2] = h1g[3]; }
+            fl = (fl >> 1) & 0x77007u;                       // (the one-bit fields move down; the alleles are not looked at here)
+            slotmap >>= 8; six >>= 8;
         }
         {
             const uint32_t s1 = (uint32_t)lane_val(wave_incl_add((int)w1, lane), 63);
@@ -454,6 +596,7 @@ k_norm_quad(NormArgs A, Derived D, const uint32_t* __restrict__ callable, const 
         __builtin_amdgcn_wave_barrier();           // (the pool is handed out anew by the next tile)
     }
     __syncthreads();
+    if (tid == 0) dcount[dregion] = min(s_ndirty, (unsigned int)min(dirty_cap, (int64_t)0x7fffffff));
     if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
     if (tid < 32 && (s_ccs[tid] || s_ref[tid])) {
         const int cl[4] = {A.cA, A.cC, A.cG, A.cT};

@@ -256,6 +256,11 @@ int himut_download_reads(himut_ctx* ctx, himut_read_batch* batch, uint8_t* tp);
 int himut_set_reference(himut_ctx* ctx, const uint8_t* seq, int64_t len, const uint8_t cls[256], int n_classes);
 int himut_run_normcounts(himut_ctx* ctx, const uint8_t alt_order[12], int non_human_sample);
 int himut_get_normcounts(himut_ctx* ctx, int64_t* ccs_tri, int64_t* ref_tri, int64_t log[14]);
+/* Test hook, no counterpart in the reference: which sweep himut_run_normcounts takes (0: k_norm_quad with its two lists,
+ * the default; 1: k_norm_tile for the whole contig), the capacity of one part of the list of positions left to k_norm_dirty
+ * (0: sized from the contig) and how many of a wave's pool slots may be handed out (0: all) -- the last two make the
+ * fall-back paths run on small inputs.  Results never depend on any of them. */
+int himut_debug_normcounts(himut_ctx* ctx, int sweep, int64_t dirty_list_cap, int pool_slots);
 /* reflib.get_chrom_tricount (reflib.py:11-33) of the string given to himut_set_reference: out[first * 16 + centre * 4 +
  * last], letters A0 C1 G2 T3, purine centres already turned to the other strand (so 32 of the 64 bins fill). */
 int himut_ref_tricounts(himut_ctx* ctx, int64_t out[64]);

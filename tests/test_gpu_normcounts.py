@@ -51,21 +51,6 @@ def test_normcounts_alt_order_variants(worker):
         assert {k: c for k, c in rf.items() if c} == {k: int(c) for k, c in v["ref_tri2count"].items() if c}
 
 
-@pytest.mark.parametrize("case", ["norm_dense", "norm_phase"])
-def test_normcounts_golden_column_store_sweep(worker, case, monkeypatch):
-    """The earlier sweep (cells through a column store in HBM, HIMUT_NORM_SWEEP=store) is kept for comparison with
-    the tiled one: the same golden vectors."""
-    from himut_amd import normcounts
-    monkeypatch.setenv("HIMUT_NORM_SWEEP", "store")
-    batch, exp, p, refseq, pon, com = load_norm_case(case)
-    _configure(worker, p, util.phase_of(exp) is not None)
-    ccs, rf, log = normcounts.norm_contig(worker, batch, util.chunks_of(exp), refseq, pon, com,
-                                          exp["non_human_sample"], exp["alt_order"], phase_sets=util.phase_of(exp))
-    assert log == exp["log"]
-    assert ccs == {k: int(v) for k, v in exp["ccs_tri2count"].items()}
-    assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
-
-
 @pytest.mark.parametrize("seed,length,chunks", [
     (31, 300_000, None),                                     # reference chunking, two chunks
     (32, 120_000, [(500, 40_000), (40_000, 41_000), (90_000, 119_000)]),   # gaps and a tiny chunk
@@ -93,44 +78,55 @@ def test_normcounts_oracle_parity(worker, seed, length, chunks):
     assert log[13] > 0 and log[11] + log[12] > 0
 
 
-@pytest.mark.parametrize("case", ["norm_dense", "norm_phase", "norm_nsub"])
-def test_normcounts_golden_tile_sweep(worker, case, monkeypatch):
-    """k_norm_tile (cells built in LDS by the workgroup, HIMUT_NORM_SWEEP=tile) stays in the library: it does the
-    contigs k_norm_col leaves alone.  The same golden vectors."""
+def _golden_with(worker, case, **dbg):
     from himut_amd import normcounts
-    monkeypatch.setenv("HIMUT_NORM_SWEEP", "tile")
     batch, exp, p, refseq, pon, com = load_norm_case(case)
     _configure(worker, p, util.phase_of(exp) is not None)
-    ccs, rf, log = normcounts.norm_contig(worker, batch, util.chunks_of(exp), refseq, pon, com,
-                                          exp["non_human_sample"], exp["alt_order"], phase_sets=util.phase_of(exp))
+    worker.ctx.debug_normcounts(**dbg)
+    try:
+        ccs, rf, log = normcounts.norm_contig(worker, batch, util.chunks_of(exp), refseq, pon, com,
+                                              exp["non_human_sample"], exp["alt_order"], phase_sets=util.phase_of(exp))
+        reran = worker.ctx.stats()["reran"]
+        redo = worker.ctx.stats()["column_slots"]
+    finally:
+        worker.ctx.debug_normcounts()
     assert log == exp["log"]
     assert ccs == {k: int(v) for k, v in exp["ccs_tri2count"].items()}
     assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
+    return reran, redo
+
+
+@pytest.mark.parametrize("case", ["norm_dense", "norm_phase", "norm_nsub"])
+def test_normcounts_golden_tile_sweep(worker, case):
+    """k_norm_tile (cells built in LDS by the workgroup) stays in the library: it does the tiles k_norm_quad leaves alone,
+    and the whole contig when a list was too short.  The whole contig through it (himut_debug_normcounts), the same
+    golden vectors."""
+    _golden_with(worker, case, sweep=1)
 
 
 @pytest.mark.parametrize("case", ["norm_dense", "norm_sets", "norm_phase"])
-def test_normcounts_left_over_positions_do_not_fit(worker, case, monkeypatch):
-    """k_norm_col hands the positions it does not classify itself (a column with another allele) to k_norm_dirty through
+def test_normcounts_left_over_positions_do_not_fit(worker, case):
+    """k_norm_quad hands the positions it does not classify itself (a column with another allele) to k_norm_dirty through
     a list sized for one position in eight; when the list is too short the contig is repeated with k_norm_tile.  A list
     with one entry per part, the same golden vectors."""
-    from himut_amd import normcounts
-    monkeypatch.setenv("HIMUT_NORM_DIRTY_CAP", "1")
-    batch, exp, p, refseq, pon, com = load_norm_case(case)
-    _configure(worker, p, util.phase_of(exp) is not None)
-    ccs, rf, log = normcounts.norm_contig(worker, batch, util.chunks_of(exp), refseq, pon, com,
-                                          exp["non_human_sample"], exp["alt_order"], phase_sets=util.phase_of(exp))
-    assert log == exp["log"]
-    assert ccs == {k: int(v) for k, v in exp["ccs_tri2count"].items()}
-    assert rf == {k: int(v) for k, v in exp["ref_tri2count"].items()}
+    reran, _ = _golden_with(worker, case, dirty_cap=1)
+    assert reran == 1
 
 
-def test_normcounts_every_piled_base_has_its_cq_byte(worker, monkeypatch):
-    """k_callable writes quality | callable << 7 for every base the sweep can reach (also of reads that fail the filters,
-    and of bases behind a soft clip's first 2 KB); with the array cleared first (HIMUT_DEBUG_FILL_CQ) a byte it left out
-    would read as a zero quality and end the run with the BQ 0 error."""
+@pytest.mark.parametrize("case,slots", [("norm_dense", 1), ("norm_sets", 2), ("norm_phase", 1), ("norm_nsub", 1), ("norm_dense", 4)])
+def test_normcounts_pool_runs_out(worker, case, slots):
+    """A wave of k_norm_quad keeps the sums of the alleles that are not the reference's in a pool of 32 accumulators for its
+    256 columns; a wave that needs more leaves its tile to k_norm_tile through a list.  With one to four slots nearly every
+    tile of the goldens goes that way: the same vectors, no repeat of the contig."""
+    reran, redo = _golden_with(worker, case, pool_slots=slots)
+    assert reran == 0 and redo > 0
+
+
+def test_normcounts_soft_clips_and_failing_reads(worker):
+    """Long soft clips (the sweep's loads start behind them), a fifth of the reads failing the quality filter, a fifth the
+    mapping-quality filter (piled, not counted), against the oracle."""
     from oracle import oracle as O
     from himut_amd import normcounts, synth, util as hutil
-    monkeypatch.setenv("HIMUT_DEBUG_FILL_CQ", "1")
     s = synth.generate(synth.SynthConfig(seed=44, contig_len=80_000, depth=35.0, frac_softclip=0.6, softclip_max=5000,
                                          frac_lowbq=0.2, frac_lowmapq=0.2, name="chrF"), want_ref=True)
     refseq = bytes(s.ref)
@@ -146,10 +142,9 @@ def test_normcounts_every_piled_base_has_its_cq_byte(worker, monkeypatch):
 
 
 def test_normcounts_qualities_of_128_and_more(worker):
-    """k_norm_col reads quality | callable << 7 from one byte; a contig with a quality that does not leave the bit free
-    is done by k_norm_tile (k_callable raises a flag, each kernel looks at it first).  Qualities up to 255 in passing
-    and in failing reads, against the oracle (its tables have 256 entries like the reference's); then the same context
-    takes an ordinary contig again."""
+    """Qualities up to 255 in passing and in failing reads, against the oracle (its tables have 256 entries like the
+    reference's; round 2's sweep kept the callable bit in bit 7 of the quality byte and sent such a contig down a slower
+    path); then the same context takes an ordinary contig again."""
     from oracle import oracle as O
     from himut_amd import normcounts, synth, util as hutil
     from himut_amd.readbatch import ReadBatch
@@ -182,8 +177,8 @@ def test_normcounts_qualities_of_128_and_more(worker):
                     read_len_max=6000)),                      # short reads, piles several hundred deep
 ])
 def test_normcounts_deep_and_ragged_piles_oracle_parity(worker, seed, depth, extra):
-    """k_norm_col's row batches (64 reads of the window index at a time) and its general rows (an indel or a read end
-    inside a 64-position quarter) against the oracle where they are the rule, not the exception."""
+    """k_norm_quad's row batches (64 reads of the window index at a time) and its general rows (an indel or a read end
+    inside a wave's 256 positions) against the oracle where they are the rule, not the exception."""
     from oracle import oracle as O
     from himut_amd import normcounts, synth, util as hutil
     s = synth.generate(synth.SynthConfig(seed=seed, contig_len=60_000, depth=depth, name="chrD", **extra), want_ref=True)
@@ -212,7 +207,7 @@ _SWEEP = [
 def test_normcounts_parameter_sweep_oracle_parity(worker, k):
     """The filters' parameters away from their defaults (quality thresholds on both sides of 128, mismatch windows from 0
     to 100 with up to 8 mismatches allowed, trimming, genotype-quality and depth thresholds), qualities up to 255 in every
-    other case (those contigs are k_norm_tile's), against the oracle."""
+    other case, against the oracle."""
     from oracle import oracle as O
     from himut_amd import normcounts, synth, util as hutil
     from himut_amd.readbatch import ReadBatch
