@@ -1346,7 +1346,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
                            c->d_live.as<uint8_t>(), c->d_ccs.as<uint8_t>(), &sc->err);
         // (k_callable takes the reads with a low mean quality out of `live`: before the phased runs' count of the reads)
         hipLaunchKernelGGL(k_callable, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, c->d_live.as<uint8_t>(),
-                           c->d_callable.as<uint32_t>(), (uint8_t*)nullptr, &sc->qhigh, c->d_ccs.as<uint8_t>());
+                           c->d_callable.as<uint32_t>(), c->d_ccs.as<uint8_t>());
         if (phase && T.npairs > 0) {
             hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
             hipLaunchKernelGGL(k_pair_ccs, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, C, H, R, c->d_live.as<uint8_t>(),

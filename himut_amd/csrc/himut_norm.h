@@ -75,57 +75,54 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
 }
 
 // ---------------------------------------------------------------------------------------
-// k_callable: one wave per passing read; lane = 32 query bases = one output word.
+// k_callable: one wave per read; a word of the bit array = 32 query bases.
 // A match base counts when its quality is at least min_bq, it is not trimmed, and the
 // number of mismatch-list entries in its window is at most max_mismatch_count; the window
 // is the one get_mismatch_range gives for the START of the base's cs match operation,
 // shifted along (normcounts.py:84-90), in 0-based coordinates against the 1-based list.
 // A substitution always counts (its three tests are evaluated and ignored, :97-109).
-constexpr int CAL_NM = 256;   // mismatch entries kept in LDS per wave
+//
+// Away from every mismatch entry the window test cannot fail and a base's bit is its quality test and its trim test, so
+// the kernel runs in two passes.  Pass A streams the read's qualities once (their sum decides the read filter's mean
+// quality, normcounts.py:302, bamlib.py:34-36: it is the kernel that reads every quality anyway), 32 bases a lane, and
+// writes quality-and-trim words for the whole read.  Pass B takes the words that lie within two windows of a mismatch entry --
+// marked beforehand in a bitmap, from the segment boundaries (indels) and the substitutions, a twentieth of the words -- 64
+// at a time, a lane each, with the exact rule.  A read that fails a filter gets zeros: it is piled, not counted; a read that
+// stays is counted (num_ccs: ccs_flag, unless the run is phased -- k_pair_ccs then).
+constexpr int CAL_NM = 256;     // mismatch entries kept in LDS per wave
+constexpr int CAL_BM = 64;      // dwords of the bitmap of words to redo: reads of up to 65,536 bases (a longer one: every word exact)
+constexpr int CAL_LIST = 128;   // words gathered before a round of pass B
 
-// With `cq` the kernel also writes, for every base of every read, quality | callable << 7 -- what k_norm_col reads
-// instead of the quality array and the bit array (the bases of a read that fails the filters keep their qualities: they
-// are piled, not counted) -- and raises *qhigh when a quality does not leave that bit free.
-// The read filter's mean quality (normcounts.py:302, bamlib.py:34-36) is decided here as well: the kernel sums the
-// qualities it reads anyway, and a read whose mean is too low gets its bits cleared and its plain qualities back, its
-// `live` flag taken away; a read that stays is counted (num_ccs: ccs_flag, unless the run is phased -- k_pair_ccs then).
-__global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, uint8_t* live, uint32_t* cbits,
-                                                  uint8_t* cq, int* qhigh, uint8_t* ccs_flag) {
+__global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, uint8_t* live, uint32_t* cbits, uint8_t* ccs_flag) {
     __shared__ int32_t s_mis[4][CAL_NM];
     __shared__ uint32_t s_mq[4][CAL_NM];
     __shared__ __align__(16) int4 s_seg[4][64];
+    __shared__ uint32_t s_bm[4][CAL_BM];
+    __shared__ uint16_t s_list[4][CAL_LIST];
     const int lane = threadIdx.x & 63, wv = uni((int)(threadIdx.x >> 6));
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= R.n) return;
+    const int64_t qo = uni(R.qoff[r]);
+    const int32_t qlen = uni(R.qlen[r]);
     if (!uni((int)live[r])) {                                  // no base of it counts (every read's words are written: the array is not cleared first)
-        const int64_t qo = uni(R.qoff[r]);
-        const int32_t qlen = uni(R.qlen[r]);
-        uint32_t hb = 0;
-        for (int32_t o = lane * 32; o < qlen; o += 2048) {
-            cbits[(qo + o) >> 5] = 0;
-            if (cq) {                                             // qualities as they are (a read's bases start at a multiple of 32)
-                const uint4 x0 = *reinterpret_cast<const uint4*>(R.bq + qo + o), x1 = *reinterpret_cast<const uint4*>(R.bq + qo + o + 16);
-                *reinterpret_cast<uint4*>(cq + qo + o) = x0;
-                *reinterpret_cast<uint4*>(cq + qo + o + 16) = x1;
-                hb |= x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w;
-            }
-        }
-        if (hb & 0x80808080u) atomicOr(qhigh, 1);
+        for (int32_t o = lane * 32; o < qlen; o += 2048) cbits[(qo + o) >> 5] = 0;
         return;
     }
     const ReadMeta Mv = D.meta[r];
     const int ns = uni(Mv.nseg);
-    const int64_t segbase = uni(Mv.segbase), qo = uni(Mv.qoff);
+    const int64_t segbase = uni(Mv.segbase);
     const int nm = uni(D.nmis[r]);
-    const int32_t qlen = uni(R.qlen[r]);
     const Seg* gsegs = D.segs + segbase;
     const int32_t* gmis = D.mis + segbase;
     const uint32_t* gmq = D.mq + segbase;
     int32_t* lmis = s_mis[wv];
     uint32_t* lmq = s_mq[wv];
     int4* lseg = s_seg[wv];
+    uint32_t* bm = s_bm[wv];
+    uint16_t* list = s_list[wv];
     for (int k = lane; k < min(nm, CAL_NM); k += 64) { lmis[k] = gmis[k]; lmq[k] = gmq[k]; }
     if (lane < min(ns, 64)) lseg[lane] = *reinterpret_cast<const int4*>(gsegs + lane);
+    bm[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     // substitutions with an N reference base (rare): not in the mismatch list, their bases always count, and each one
     // starts a new match operation behind it (normcounts.py:75-110 walks the cs operations).  Query offsets, ascending.
@@ -144,192 +141,245 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
     const int min_bq_c = min(max(min_bq, 1), 127);
     const int32_t trim_lo = (int32_t)trim_start, trim_hi = (int32_t)trim_end;
     const int maxmm = P.p.max_mismatch_count;
-    const int32_t q_first = uni(lseg[0].y);
-    // the qualities of the next window are asked for before this one is worked on (addresses clamped into the read)
-    const int32_t q_last = (max(qlen, 1) - 1) & ~31;
-    uint4 p0, p1;
-    {
-        const int32_t qn = min(lane * 32, q_last);
-        p0 = *reinterpret_cast<const uint4*>(R.bq + qo + qn);
-        p1 = *reinterpret_cast<const uint4*>(R.bq + qo + qn + 16);
-    }
-    (void)q_first;
-    uint32_t qsum = 0;   // this lane's share of the sum of the read's qualities (from offset 0: the mean is over the whole query)
-    int jc = 0;      // the first segment that reaches into the window (segments are in query order: the cursor only moves on)
-    for (int32_t c0 = 0; c0 < qlen; c0 += 2048) {
-        const int32_t qa = c0 + lane * 32;
-        uint32_t word = 0;
-        while (jc < ns) {
-            const int4 sg = SEG(jc);
-            const int32_t qspan = (((uint32_t)uni(sg.w) & SEG_DEL) || uni(sg.z) <= 0) ? 0 : uni(sg.z);
-            if (uni(sg.y) + qspan > c0) break;
-            jc++;
+    const int32_t nwords = (qlen + 31) >> 5;
+    const bool big = nwords > CAL_BM * 32;                      // a read the bitmap does not hold: every word the exact way
+
+    // the quality and trim tests of the 32 bases from qa on, given their qualities (bytes behind the read are masked by the trim)
+    auto quality_trim = [&](const uint32_t (&bw)[8], int32_t qa) -> uint32_t {
+        uint32_t okq = 0;    // four bytes at a time: the low seven bits compared, bit 7 by itself
+        const uint32_t hb = (bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) & 0x80808080u;   // a quality of 128 or more among them
+        if (min_bq <= 127 && !hb) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) okq |= cs_pack4(cs_ge_bytes(bw[k], (uint32_t)min_bq_c)) << (4 * k);
+        } else if (min_bq <= 127) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                okq |= cs_pack4(cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)min_bq_c) | (bw[k] & 0x80808080u)) << (4 * k);
+        } else if (min_bq <= 255) {                           // (a threshold above 127: only a quality of 128 or more can pass)
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                okq |= cs_pack4((min_bq > 128 ? cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)(min_bq - 128)) : 0x80808080u) &
+                                (bw[k] & 0x80808080u)) << (4 * k);
         }
-        const uint4 b0 = p0, b1 = p1;
+        if (min_bq <= 0) okq = ~0u;
+        // not trimmed: trim_lo <= q <= trim_hi (the two bounds are whole numbers), and q < qlen
+        const int32_t lo_q = max(trim_lo, 0), hi_q = min(trim_hi, qlen - 1);
+        const int32_t a0 = max(lo_q - qa, 0), a1 = min(hi_q - qa, 31);
+        return okq & ((a0 <= a1) ? ((a1 - a0 >= 31 ? ~0u : ((1u << (a1 - a0 + 1)) - 1u)) << a0) : 0u);
+    };
+
+    // ---- which words lie within two windows of a mismatch entry: around every segment boundary (an indel: from the last
+    //      base in front of it to the first base behind it) and every substitution, in query coordinates.  (A base and an
+    //      entry that are D reference positions apart with no indel between them are D query bases apart; with indels
+    //      between them the nearest of those is an entry itself and no further from the base.)
+    if (!big) {
+        // (2 w + 2 either way: a base's window reaches w reference positions to each side, up to 2 w to one side where its match
+        //  operation starts near an end of the read, one more for the 0-based positions against the 1-based list)
+        auto reach = [&](int32_t) -> int32_t { return 2 * w + 2; };
+        auto mark = [&](int32_t qlo, int32_t qhi) {
+            qlo = max(qlo, 0); qhi = min(qhi, qlen - 1);
+            for (int32_t wd = qlo >> 5; wd <= (qhi >> 5); wd++) atomicOr(&bm[wd >> 5], 1u << (wd & 31));
+        };
+        for (int j = lane - 1; j + 1 < ns; j += 64) {             // boundary between segment j and j + 1 (j = -1: in front of the first)
+            const int4 sb = SEG(j + 1);
+            if (j < 0) { if ((uint32_t)sb.w & SEG_INS) { const int32_t q0 = uni(R.qstart[r]); mark(q0 - reach(q0), sb.y + reach(sb.y)); } continue; }
+            const int4 sa = SEG(j);
+            const int32_t qa_end = sa.y + ((((uint32_t)sa.w & SEG_DEL) || sa.z <= 0) ? 0 : sa.z);
+            mark(qa_end - 1 - reach(qa_end), sb.y + reach(sb.y));
+        }
+        for (int k = lane; k < nm; k += 64) { const uint32_t v = MQ(k); if (v & 16u) { const int32_t q = (int32_t)(v >> 5); mark(q - reach(q), q + reach(q)); } }
+        for (int k = lane; k < nN; k += 64) { const int32_t q = NQ(k); mark(q - reach(q), q + reach(q)); }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass A: the qualities once; quality-and-trim words everywhere
+    uint32_t qsum = 0;   // this lane's share of the sum of the read's qualities (from offset 0: the mean is over the whole query)
+    {
+        const int32_t q_last = (max(qlen, 1) - 1) & ~31;       // (addresses clamped into the read)
+        uint4 p0, p1;
         {
-            const int32_t qn = min(c0 + 2048 + lane * 32, q_last);
+            const int32_t qn = min(lane * 32, q_last);
             p0 = *reinterpret_cast<const uint4*>(R.bq + qo + qn);
             p1 = *reinterpret_cast<const uint4*>(R.bq + qo + qn + 16);
         }
-        if (qa < qlen) {
-            // qualities of the lane's 32 bases
-            const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            if (qa + 32 <= qlen) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) qsum = __builtin_amdgcn_sad_u8(bw[k], 0u, qsum);
-            } else {                                              // the read's last bases: the bytes behind them are padding
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int rb = qlen - (qa + 4 * k);           // bytes of the word inside the read
-                    const uint32_t x = rb >= 4 ? bw[k] : rb <= 0 ? 0u : (bw[k] & (0xffffffffu >> (8 * (4 - rb))));
-                    qsum = __builtin_amdgcn_sad_u8(x, 0u, qsum);
-                }
+        for (int32_t c0 = 0; c0 < qlen; c0 += 2048) {
+            const int32_t qa = c0 + lane * 32;
+            const uint4 b0 = p0, b1 = p1;
+            {                                                   // the next window's qualities are asked for before this one is worked on
+                const int32_t qn = min(c0 + 2048 + lane * 32, q_last);
+                p0 = *reinterpret_cast<const uint4*>(R.bq + qo + qn);
+                p1 = *reinterpret_cast<const uint4*>(R.bq + qo + qn + 16);
             }
-            uint32_t okq = 0;    // quality and trim tests per base, four bytes at a time: the low seven bits compared, bit 7 by itself
-            const uint32_t hb = (bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) & 0x80808080u;   // a quality of 128 or more among them
-            if (min_bq <= 127 && !hb) {
+            if (qa < qlen) {
+                const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                if (qa + 32 <= qlen) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) okq |= cs_pack4(cs_ge_bytes(bw[k], (uint32_t)min_bq_c)) << (4 * k);
-            } else if (min_bq <= 127) {
+                    for (int k = 0; k < 8; k++) qsum = __builtin_amdgcn_sad_u8(bw[k], 0u, qsum);
+                } else {                                          // the read's last bases: the bytes behind them are padding
 #pragma unroll
-                for (int k = 0; k < 8; k++)
-                    okq |= cs_pack4(cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)min_bq_c) | (bw[k] & 0x80808080u)) << (4 * k);
-            } else if (min_bq <= 255) {                           // (a threshold above 127: only a quality of 128 or more can pass)
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    okq |= cs_pack4((min_bq > 128 ? cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)(min_bq - 128)) : 0x80808080u) &
-                                    (bw[k] & 0x80808080u)) << (4 * k);
-            }
-            if (min_bq <= 0) okq = ~0u;
-            {
-                // not trimmed: trim_lo <= q <= trim_hi (the two bounds are whole numbers), and q < qlen
-                const int32_t lo_q = max(trim_lo, 0), hi_q = min(trim_hi, qlen - 1);
-                const int32_t a0 = max(lo_q - qa, 0), a1 = min(hi_q - qa, 31);
-                okq &= (a0 <= a1) ? ((a1 - a0 >= 31 ? ~0u : ((1u << (a1 - a0 + 1)) - 1u)) << a0) : 0u;
-            }
-            // segments under [qa, qa + 32)
-            for (int j = jc; j < ns; j++) {
-                const int4 sg = SEG(j);
-                if (sg.y >= qa + 32) break;
-                if (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) continue;
-                const int32_t a = max(sg.y, qa), b = min(sg.y + sg.z, qa + 32);     // query overlap
-                if (a >= b) continue;
-                const int32_t tlo = sg.x + (a - sg.y), thi = sg.x + (b - 1 - sg.y);  // 0-based reference positions
-                uint32_t nsub_bits = 0;      // N-reference substitutions among these bases; the last one in front of them
-                int32_t nsub_prev = -1;
-                for (int k = 0; k < nN; k++) {
-                    const int32_t q = NQ(k);
-                    if (q >= a && q < b) nsub_bits |= 1u << (q - qa);
-                    else if (q >= sg.y && q < a) nsub_prev = q;
-                }
-                // any list entry that could fall into a window of these bases?
-                const int k0 = lower(tlo - 2 * w - 1);
-                if (k0 >= nm || MIS(k0) > thi + 2 * w + 1) {
-                    word |= (okq & (((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa))) | nsub_bits;
-                    continue;
-                }
-                // the few entries near these bases, in registers (value, query offset | substitution flag)
-                // (four: the slots are filled and counted for all of them whatever a lane holds, and a lane with more nearby
-                //  -- 0.1 are expected -- takes the exact loop over its bases below; 8: 1.62 ms, 4: 1.39, 3: 1.38, 2: 1.54)
-                constexpr int NE = 4;
-                int32_t ev[NE];
-                uint32_t eq[NE];
-                int ne = 0;
-#pragma unroll
-                for (int i = 0; i < NE; i++) {
-                    ev[i] = 0x7fffffff; eq[i] = 0;
-                    if (k0 + i < nm) { const int32_t m = MIS(k0 + i); if (m <= thi + 2 * w + 1) { ev[i] = m; eq[i] = MQ(k0 + i); ne = i + 1; } }
-                }
-                const bool overflow = k0 + NE < nm && MIS(k0 + NE) <= thi + 2 * w + 1;   // more than NE entries nearby
-                // start of the match operation the first base belongs to: behind the previous substitution of this
-                // segment, else the segment start
-                int32_t osq = sg.y;
-                {
-                    const int kp = lower(tlo + 1) - 1;
-                    if (kp >= 0) {
-                        const uint32_t pv = MQ(kp);
-                        const int32_t pq = (int32_t)(pv >> 5);
-                        if ((pv & 16u) && pq >= sg.y && pq < a) osq = pq + 1;
+                    for (int k = 0; k < 8; k++) {
+                        const int rb = qlen - (qa + 4 * k);       // bytes of the word inside the read
+                        const uint32_t x = rb >= 4 ? bw[k] : rb <= 0 ? 0u : (bw[k] & (0xffffffffu >> (8 * (4 - rb))));
+                        qsum = __builtin_amdgcn_sad_u8(x, 0u, qsum);
                     }
-                    if (nsub_prev >= 0) osq = max(osq, nsub_prev + 1);
                 }
-                // Away from the read's ends every match operation has the window (w, w), so "how many entries see
-                // this base" is a sum of bit ranges: bit-sliced counters instead of a loop over the bases.
-                if (!overflow && osq >= w && (int64_t)qa + 32 + w <= (int64_t)qlen) {
-                    const int32_t shift = sg.y - sg.x - qa;           // bit of reference position t = t + shift
-                    const uint32_t span = ((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa);
-                    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, sub = 0;
-#pragma unroll
-                    for (int i = 0; i < NE; i++) {
-                        if (i >= ne) continue;
-                        const int lo = max(ev[i] - w + shift, 0), hi = min(ev[i] + w + shift, 31);
-                        uint32_t rr = 0;
-                        if (lo <= hi) rr = ((hi - lo) >= 31 ? ~0u : ((1u << (hi - lo + 1)) - 1u)) << lo;
-                        const uint32_t k0_ = c0 & rr; c0 ^= rr;
-                        const uint32_t k1_ = c1 & k0_; c1 ^= k0_;
-                        const uint32_t k2_ = c2 & k1_; c2 ^= k1_;
-                        c3 ^= k2_;
-                        const int32_t sq = (int32_t)(eq[i] >> 5);
-                        if ((eq[i] & 16u) && sq >= a && sq < b && ev[i] == sg.x + (sq - sg.y) + 1) sub |= 1u << (sq - qa);
-                    }
-                    uint32_t gt = 0;                                   // bases seen by more than maxmm entries
-                    if (maxmm < 8) {
-                        uint32_t same = ~0u;
-                        const uint32_t planes[4] = {c0, c1, c2, c3};
-#pragma unroll
-                        for (int pbit = 3; pbit >= 0; pbit--) {
-                            const uint32_t kb = ((maxmm >> pbit) & 1) ? ~0u : 0u;
-                            gt |= same & planes[pbit] & ~kb;
-                            same &= ~(planes[pbit] ^ kb);
-                        }
-                    }
-                    word |= (span & ((okq & ~gt) | sub)) | nsub_bits;
-                    continue;
-                }
-                for (int32_t q = a; q < b; q++) {
-                    const int32_t t = sg.x + (q - sg.y);
-                    const int bit = q - qa;
-                    bool is_sub = false;
-#pragma unroll
-                    for (int i = 0; i < NE; i++) if (ev[i] == t + 1 && (eq[i] & 16u) && (int32_t)(eq[i] >> 5) == q) is_sub = true;
-                    if (overflow && !is_sub)
-                        for (int kk = lower(t + 1); kk < nm && MIS(kk) == t + 1; kk++) { const uint32_t v = MQ(kk); if ((v & 16u) && (int32_t)(v >> 5) == q) is_sub = true; }
-                    if (is_sub || ((nsub_bits >> bit) & 1u)) { word |= 1u << bit; osq = q + 1; continue; }
-                    int64_t qs = (int64_t)osq - w, qe = (int64_t)osq + w, ur, dr;      // bamlib.py:245-258
-                    if (qs < 0) { ur = w + qs; dr = w - qs; }
-                    else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - osq; }
-                    else { ur = w; dr = w; }
-                    int cnt = 0;
-                    if (!overflow) {
-#pragma unroll
-                        for (int i = 0; i < NE; i++) cnt += (ev[i] >= t - ur && ev[i] <= t + dr) ? 1 : 0;
-                    } else cnt = upper((int32_t)(t + dr)) - lower((int32_t)(t - ur));
-                    if (cnt <= maxmm && ((okq >> bit) & 1u)) word |= 1u << bit;
-                }
-            }
-            cbits[((qo + qa) >> 5)] = word;
-            if (cq) {
-                uint32_t ow[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++)                   // bit j of a nibble of the word to bit 7 of byte j
-                    ow[k] = bw[k] | (((((word >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u) << 7);
-                *reinterpret_cast<uint4*>(cq + qo + qa) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                *reinterpret_cast<uint4*>(cq + qo + qa + 16) = make_uint4(ow[4], ow[5], ow[6], ow[7]);
-                if (hb) atomicOr(qhigh, 1);
+                cbits[(qo + qa) >> 5] = quality_trim(bw, qa);
             }
         }
+    }
+
+    // ---- pass B: a word with a mismatch entry nearby, the exact way (qa: its first base)
+    auto exact_word = [&](int32_t qa) {
+        uint32_t bw[8];
+        {
+            const uint4 b0 = *reinterpret_cast<const uint4*>(R.bq + qo + qa), b1 = *reinterpret_cast<const uint4*>(R.bq + qo + qa + 16);
+            bw[0] = b0.x; bw[1] = b0.y; bw[2] = b0.z; bw[3] = b0.w; bw[4] = b1.x; bw[5] = b1.y; bw[6] = b1.z; bw[7] = b1.w;
+        }
+        const uint32_t okq = quality_trim(bw, qa);
+        uint32_t word = 0;
+        // the first segment that reaches behind qa (segments are in query order)
+        int jc = 0;
+        {
+            int lo = 0, hi = ns;
+            while (lo < hi) {
+                const int m = (lo + hi) >> 1;
+                const int4 sg = SEG(m);
+                const int32_t qspan = (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) ? 0 : sg.z;
+                if (sg.y + qspan <= qa) lo = m + 1; else hi = m;
+            }
+            jc = lo;
+        }
+        for (int j = jc; j < ns; j++) {
+            const int4 sg = SEG(j);
+            if (sg.y >= qa + 32) break;
+            if (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) continue;
+            const int32_t a = max(sg.y, qa), b = min(sg.y + sg.z, qa + 32);     // query overlap
+            if (a >= b) continue;
+            const int32_t tlo = sg.x + (a - sg.y), thi = sg.x + (b - 1 - sg.y);  // 0-based reference positions
+            uint32_t nsub_bits = 0;      // N-reference substitutions among these bases; the last one in front of them
+            int32_t nsub_prev = -1;
+            for (int k = 0; k < nN; k++) {
+                const int32_t q = NQ(k);
+                if (q >= a && q < b) nsub_bits |= 1u << (q - qa);
+                else if (q >= sg.y && q < a) nsub_prev = q;
+            }
+            // any list entry that could fall into a window of these bases?
+            const int k0 = lower(tlo - 2 * w - 1);
+            if (k0 >= nm || MIS(k0) > thi + 2 * w + 1) {
+                word |= (okq & (((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa))) | nsub_bits;
+                continue;
+            }
+            // the few entries near these bases, in registers (value, query offset | substitution flag); a lane with more
+            // than NE nearby takes the exact loop over its bases below
+            constexpr int NE = 4;
+            int32_t ev[NE];
+            uint32_t eq[NE];
+            int ne = 0;
+#pragma unroll
+            for (int i = 0; i < NE; i++) {
+                ev[i] = 0x7fffffff; eq[i] = 0;
+                if (k0 + i < nm) { const int32_t m = MIS(k0 + i); if (m <= thi + 2 * w + 1) { ev[i] = m; eq[i] = MQ(k0 + i); ne = i + 1; } }
+            }
+            const bool overflow = k0 + NE < nm && MIS(k0 + NE) <= thi + 2 * w + 1;   // more than NE entries nearby
+            // start of the match operation the first base belongs to: behind the previous substitution of this
+            // segment, else the segment start
+            int32_t osq = sg.y;
+            {
+                const int kp = lower(tlo + 1) - 1;
+                if (kp >= 0) {
+                    const uint32_t pv = MQ(kp);
+                    const int32_t pq = (int32_t)(pv >> 5);
+                    if ((pv & 16u) && pq >= sg.y && pq < a) osq = pq + 1;
+                }
+                if (nsub_prev >= 0) osq = max(osq, nsub_prev + 1);
+            }
+            // Away from the read's ends every match operation has the window (w, w), so "how many entries see
+            // this base" is a sum of bit ranges: bit-sliced counters instead of a loop over the bases.
+            if (!overflow && osq >= w && (int64_t)qa + 32 + w <= (int64_t)qlen) {
+                const int32_t shift = sg.y - sg.x - qa;           // bit of reference position t = t + shift
+                const uint32_t span = ((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa);
+                uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, sub = 0;
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    if (i >= ne) continue;
+                    const int lo = max(ev[i] - w + shift, 0), hi = min(ev[i] + w + shift, 31);
+                    uint32_t rr = 0;
+                    if (lo <= hi) rr = ((hi - lo) >= 31 ? ~0u : ((1u << (hi - lo + 1)) - 1u)) << lo;
+                    const uint32_t k0_ = c0 & rr; c0 ^= rr;
+                    const uint32_t k1_ = c1 & k0_; c1 ^= k0_;
+                    const uint32_t k2_ = c2 & k1_; c2 ^= k1_;
+                    c3 ^= k2_;
+                    const int32_t sq = (int32_t)(eq[i] >> 5);
+                    if ((eq[i] & 16u) && sq >= a && sq < b && ev[i] == sg.x + (sq - sg.y) + 1) sub |= 1u << (sq - qa);
+                }
+                uint32_t gt = 0;                                   // bases seen by more than maxmm entries
+                if (maxmm < 8) {
+                    uint32_t same = ~0u;
+                    const uint32_t planes[4] = {c0, c1, c2, c3};
+#pragma unroll
+                    for (int pbit = 3; pbit >= 0; pbit--) {
+                        const uint32_t kb = ((maxmm >> pbit) & 1) ? ~0u : 0u;
+                        gt |= same & planes[pbit] & ~kb;
+                        same &= ~(planes[pbit] ^ kb);
+                    }
+                }
+                word |= (span & ((okq & ~gt) | sub)) | nsub_bits;
+                continue;
+            }
+            for (int32_t q = a; q < b; q++) {
+                const int32_t t = sg.x + (q - sg.y);
+                const int bit = q - qa;
+                bool is_sub = false;
+#pragma unroll
+                for (int i = 0; i < NE; i++) if (ev[i] == t + 1 && (eq[i] & 16u) && (int32_t)(eq[i] >> 5) == q) is_sub = true;
+                if (overflow && !is_sub)
+                    for (int kk = lower(t + 1); kk < nm && MIS(kk) == t + 1; kk++) { const uint32_t v = MQ(kk); if ((v & 16u) && (int32_t)(v >> 5) == q) is_sub = true; }
+                if (is_sub || ((nsub_bits >> bit) & 1u)) { word |= 1u << bit; osq = q + 1; continue; }
+                int64_t qs = (int64_t)osq - w, qe = (int64_t)osq + w, ur, dr;      // bamlib.py:245-258
+                if (qs < 0) { ur = w + qs; dr = w - qs; }
+                else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - osq; }
+                else { ur = w; dr = w; }
+                int cnt = 0;
+                if (!overflow) {
+#pragma unroll
+                    for (int i = 0; i < NE; i++) cnt += (ev[i] >= t - ur && ev[i] <= t + dr) ? 1 : 0;
+                } else cnt = upper((int32_t)(t + dr)) - lower((int32_t)(t - ur));
+                if (cnt <= maxmm && ((okq >> bit) & 1u)) word |= 1u << bit;
+            }
+        }
+        cbits[(qo + qa) >> 5] = word;
+    };
+    if (big) {
+        for (int32_t w0 = 0; w0 < nwords; w0 += 64) if (w0 + lane < nwords) exact_word((w0 + lane) * 32);
+    } else {
+        // the marked words, gathered into a list and worked off 64 at a time
+        int nl = 0;
+        const int ndw = (nwords + 31) >> 5;
+        for (int d0 = 0; d0 < ndw; d0 += 2) {
+            const uint64_t bits2 = (uint64_t)uni(bm[d0]) | ((uint64_t)(d0 + 1 < ndw ? uni(bm[d0 + 1]) : 0u) << 32);
+            if (!bits2) continue;
+            const int here = __builtin_popcountll(bits2);
+            if (nl + here > CAL_LIST) {
+                __builtin_amdgcn_wave_barrier();
+                for (int i0 = 0; i0 < nl; i0 += 64) if (i0 + lane < nl) exact_word((int32_t)list[i0 + lane] * 32);
+                __builtin_amdgcn_wave_barrier();
+                nl = 0;
+            }
+            if ((bits2 >> lane) & 1ull) {
+                const int rank = __builtin_popcountll(bits2 & ((1ull << lane) - 1ull));
+                const int32_t wd = d0 * 32 + lane;
+                if (wd < nwords) list[nl + rank] = (uint16_t)wd; else list[nl + rank] = (uint16_t)(nwords - 1);
+            }
+            nl += here;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < nl; i0 += 64) if (i0 + lane < nl) exact_word((int32_t)list[i0 + lane] * 32);
     }
     // ---- the mean quality (np.mean of the whole query against min_qv, as in k_read_live's other tests)
     const uint32_t qtot = (uint32_t)lane_val(wave_incl_add((int)qsum, lane), 63);
     if ((double)qtot / (double)qlen < (double)P.p.min_qv) {
         if (lane == 0) live[r] = 0;
-        for (int32_t o = lane * 32; o < qlen; o += 2048) {            // no base of it counts: bits cleared, plain qualities
-            cbits[(qo + o) >> 5] = 0;
-            if (cq) {
-                *reinterpret_cast<uint4*>(cq + qo + o) = *reinterpret_cast<const uint4*>(R.bq + qo + o);
-                *reinterpret_cast<uint4*>(cq + qo + o + 16) = *reinterpret_cast<const uint4*>(R.bq + qo + o + 16);
-            }
-        }
+        for (int32_t o = lane * 32; o < qlen; o += 2048) cbits[(qo + o) >> 5] = 0;     // no base of it counts
     } else if (!P.p.phase && lane == 0) ccs_flag[R.qid[r]] = 1;
 }
 
