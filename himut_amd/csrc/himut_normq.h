@@ -249,6 +249,7 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
     if (tid == 0) { s_bad = 0; s_ndirty = 0; }
     __syncthreads();
     const uint32_t lut = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)s_lut);
+    const double pr0 = A.lut->prior[0], pr1 = A.lut->prior[1], pr2 = A.lut->prior[2], pr3 = A.lut->prior[3];   // (uniform: scalar registers)
     NqPool& pool = s_pool[wv];
     const int chunk = blockIdx.y;
     // this workgroup's part of the list of positions left to k_norm_dirty: filled from its start, the counter in LDS until the end
@@ -386,6 +387,26 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
             //      BAM codes n4 (column j in bits 12 - 4j ..), callable bits cb.  The nine items in ten that span the tile go
             //      NB at a time, their loads issued together: a scalar base plus a fixed offset per lane
             uint64_t m = __ballot(is_item);
+            // the loads of the NEXT item that covers a part of the positions are kept in flight while the spanning items in front
+            // of it are worked on (a memory round trip of its own for each was a seventh of the kernel): pl = its lane of the
+            // item vector, or -1
+            const uint64_t m_pm = __ballot(is_item && !full && (ifl & NQI_TYPE) == NQI_MATCH);
+            uint32_t pq = 0, pn = 0, pc = 0;
+            int pl = -1;
+            auto part_issue = [&](uint64_t from) {
+                const uint64_t c = m_pm & from;
+                pl = c ? (int)__builtin_ctzll(c) : -1;
+                if (pl < 0) return;
+                const int32_t t_ = lane_val(tlo, pl);
+                const int32_t last = t_ + (int32_t)((uint32_t)lane_val((int)lf, pl) & 0xffffu) - 1;
+                if (P0 + 3 >= t_ && P0 <= last) {                  // (a lane the piece reaches: nothing else is touched)
+                    const uint64_t ks = nq_lane64(kq, pl) + (uint64_t)(int64_t)max(P0, t_);
+                    pq = nq_ld32((uint64_t)R.bq + ks, 0u);
+                    pn = nq_ld32((uint64_t)R.seq + (ks >> 1), 0u);
+                    pc = nq_ld16((uint64_t)callable + (ks >> 3), 0u);
+                }
+            };
+            part_issue(m);
             while (m) {
                 const uint64_t ms = m & ~m_full;
                 const uint64_t front = ms ? (m & ((ms & (0 - ms)) - 1)) : m;
@@ -453,6 +474,9 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 //      same update under a mask of cells
                 const int gl = (int)__builtin_ctzll(m);
                 m &= m - 1;
+                // (its words were asked for when the partial item in front of it was done; now the next one's are)
+                const uint32_t qraw = pq, sraw = pn, braw = pc;
+                if (gl == pl) part_issue(m);
                 const int32_t g_tlo = lane_val(tlo, gl);
                 const uint32_t g_lf = (uint32_t)lane_val((int)lf, gl);
                 const uint32_t g_fl = g_lf >> 16, g_len = g_lf & 0xffffu, g_hap = (g_fl >> NQI_HAP_SHIFT) & 3u;
@@ -465,15 +489,12 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 if ((g_fl & NQI_TYPE) != NQI_MATCH || !__ballot(c4 != 0)) continue;
                 uint32_t qv1 = 0x01010101u, n41 = 0, cb1 = 0;
                 if (c4) {
-                    // the first of the lane's cells is query base ks of the arrays: loads from there on, brought to the columns'
-                    // places (nothing in front of the piece is touched: the first read has nothing there)
-                    const uint64_t ks = nq_lane64(kq, gl) + (uint64_t)(int64_t)(P0 + jlo);
-                    const uint32_t qraw = nq_ld32((uint64_t)R.bq + ks, 0u);
-                    const uint32_t sraw = nq_ld32((uint64_t)R.seq + (ks >> 1), 0u);
-                    const uint32_t braw = nq_ld16((uint64_t)callable + (ks >> 3), 0u);
-                    qv1 = (qraw << (8 * jlo)) | ~(0xffffffffu << (8 * jlo));      // (bytes in front: not zero)
-                    n41 = ((__builtin_bswap32(sraw) >> ((ks & 1u) ? 12u : 16u)) & 0xffffu) >> (4 * jlo);
-                    cb1 = (((braw >> (uint32_t)(ks & 7u)) & 15u) << jlo) & c4;
+                    // the loaded words begin at the lane's first cell, query base ks of the arrays: brought to the columns' places
+                    const uint32_t ks_lo = (uint32_t)lane_val((int)kq, gl) + (uint32_t)(P0 + jlo);
+                    const uint32_t js = (uint32_t)(jlo & 3);
+                    qv1 = (qraw << (8 * js)) | ~(0xffffffffu << (8 * js));      // (bytes in front: not zero)
+                    n41 = ((__builtin_bswap32(sraw) >> ((ks_lo & 1u) ? 12u : 16u)) & 0xffffu) >> (4 * js);
+                    cb1 = (((braw >> (ks_lo & 7u)) & 15u) << js) & c4;
                     if (phase) {
                         if (g_hap == HAP_0) h0b += nq_spread4(c4);
                         else if (g_hap == HAP_1) h1b += nq_spread4(c4);
@@ -525,8 +546,8 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
             // seen adds +0.0 to a sum, which leaves it bit for bit what it was).  When hom-ref is the smallest by itself it
             // is the genotype and the quality is the gap to the smallest of the rest; any other outcome, and any column
             // with another allele, goes to k_norm_dirty.
-            const double pa = -10.0 * (R0[0] + s_prior[0]), pb = -10.0 * (R1[0] + s_prior[1]);
-            const double pc = -10.0 * (R2[0] + s_prior[2]), pd = -10.0 * (R2[0] + s_prior[3]);
+            const double pa = -10.0 * (R0[0] + pr0), pb = -10.0 * (R1[0] + pr1);
+            const double pc = -10.0 * (R2[0] + pr2), pd = -10.0 * (R2[0] + pr3);
             const double nxt = fmin(pb, fmin(pc, pd));
             const bool mine = open && slot == 255u && pa < nxt;
             const double gqf = nxt - pa;
