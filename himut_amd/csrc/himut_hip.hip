@@ -125,6 +125,7 @@ struct himut_ctx {
     DevBuf d_mask, d_recs, d_recs_out, d_keys, d_keys2, d_vals, d_vals2, d_emit, d_pos, d_tmp, d_scalars;
     DevBuf d_tilecnt, d_tileoff2, d_logpart;
     // normcounts
+    DevBuf d_nonacgt;                        // per read: SEQ holds a base outside ATGC (k_flag_bases, once per batch)
     DevBuf d_refseq, d_live, d_callable, d_dirty, d_dcount, d_redo, d_plan, d_plancnt, d_tri;
     int dbg_norm_sweep = 0, dbg_norm_pool = 0;     // himut_debug_normcounts (tests)
     int64_t dbg_norm_dirty_cap = 0;
@@ -147,6 +148,7 @@ struct himut_ctx {
     hipEvent_t ing_copied[2] = {}, ing_parsed[2] = {};
     bool ing_open = false, ing_used[2] = {false, false};
     int64_t ing_reads = 0, ing_bases = 0, ing_cs = 0;   // capacity the windows so far may need (upper bounds)
+    bool bases_flagged = false;              // d_nonacgt holds k_flag_bases' answer for the pushed reads
     int64_t win_nblk = 0;                    // d_winlo / d_winhi hold the read windows of the pushed reads for this many
                                              // 256-position blocks (0: not computed yet)
     void* h_scalars = nullptr;               // pinned landing zone of the scalars block
@@ -219,6 +221,7 @@ Reads make_reads(himut_ctx* c) {
     R.qid = c->d_qid.as<int32_t>(); R.qoff = c->d_qoff.as<int64_t>(); R.cs_off = c->d_csoff.as<int64_t>();
     R.seq = c->d_seq.as<uint8_t>(); R.bq = c->d_bq.as<uint8_t>(); R.cs = c->d_cs.as<uint8_t>();
     R.prefmax_tend = c->d_prefmax.as<int32_t>();
+    R.nonacgt = c->d_nonacgt.as<uint8_t>();
     return R;
 }
 
@@ -396,6 +399,15 @@ void run_parse_stage(himut_ctx* c, const Reads& R, const Derived& D, Scalars* sc
     run_parse_stage<false>(c, R, D, sc, [](hipStream_t) {});
 }
 
+// once per pushed batch: which reads hold a base outside ATGC somewhere (on `st`, in front of whatever looks at the flags)
+void flag_bases_once(himut_ctx* c, hipStream_t st) {
+    if (c->bases_flagged) return;             // (d_nonacgt is sized by alloc_derived)
+    if (c->n > 0)
+        hipLaunchKernelGGL(k_flag_bases, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, c->n, c->d_qoff.as<int64_t>(), c->d_qlen.as<int32_t>(),
+                           c->d_seq.as<uint8_t>(), c->d_nonacgt.as<uint8_t>());
+    c->bases_flagged = true;
+}
+
 void alloc_derived(himut_ctx* c) {
     const int64_t n = c->n;
     const int64_t segcap = (c->cs_bytes >> 1) + n + 2;
@@ -410,6 +422,7 @@ void alloc_derived(himut_ctx* c) {
     c->d_rflag.reserve((size_t)n + 64);
     c->d_ccs.reserve((size_t)n + 64);
     c->d_scalars.reserve(sizeof(Scalars));
+    c->d_nonacgt.reserve((size_t)n + 64);
 }
 
 // One pass of the scan.  spec: the candidate and column-slot buffers keep the capacities of an earlier run
@@ -500,6 +513,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow, bool defer) {
     Scalars& hs = *reinterpret_cast<Scalars*>(c->h_scalars);
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
+    flag_bases_once(c, st);
     // The cs decode sets the bits of the column positions and every kernel adds to the scalars: both are empty before
     // the run starts.  A run leaves them so (it clears them behind its last copy, while the host is already reading
     // the results): only a context that has not just been through a run of this kind pays for the fills here.
@@ -951,7 +965,7 @@ int himut_push_reads(himut_ctx* c, const himut_read_batch* b) {
         HCHECK(hipStreamSynchronize(st));
         c->have_reads = true;
         c->tables_valid = false;   // the chunk tables hold read windows
-        c->win_nblk = 0;
+        c->win_nblk = 0; c->bases_flagged = false;
         c->h_recs_valid = false;
         return HIMUT_OK;
     });
@@ -1015,7 +1029,7 @@ int himut_ingest_begin(himut_ctx* c, int64_t inflated_bound, int64_t window_byte
         HCHECK(hipMemcpy(c->d_istate.p, &z, sizeof(z), hipMemcpyHostToDevice));
         c->ing_reads = c->ing_bases = c->ing_cs = 0;
         c->ing_open = true;
-        c->have_reads = false; c->tables_valid = false; c->win_nblk = 0; c->h_recs_valid = false;
+        c->have_reads = false; c->tables_valid = false; c->win_nblk = 0; c->bases_flagged = false; c->h_recs_valid = false;
         return HIMUT_OK;
     });
 }
@@ -1127,7 +1141,7 @@ int himut_ingest_end(himut_ctx* c, int unique_qnames, himut_ingest_result* out) 
         c->d_cs.grow_keep((size_t)S.cs_n + 2048 + 256, (size_t)S.cs_n);
         HCHECK(hipStreamSynchronize(st));
         c->have_reads = S.n_unsorted == 0 && S.n_missing_cs == 0;
-        c->tables_valid = false; c->win_nblk = 0; c->h_recs_valid = false;
+        c->tables_valid = false; c->win_nblk = 0; c->bases_flagged = false; c->h_recs_valid = false;
         return HIMUT_OK;
     });
 }
@@ -1330,6 +1344,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     }
 
     HCHECK(hipEventRecord(c->ev[EV_START], st));
+    flag_bases_once(c, st);
     HCHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
     HCHECK(hipMemsetAsync(c->d_ccs.p, 0, (size_t)c->n + 1, st));
     HCHECK(hipMemsetAsync(c->d_tri.p, 0, (2 * ntri + 16) * 8, st));

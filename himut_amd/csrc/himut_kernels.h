@@ -83,6 +83,7 @@ struct Reads {
     const int64_t *qoff, *cs_off;
     const uint8_t *seq, *bq, *cs;
     const int32_t* prefmax_tend;  // running maximum of tend in file order
+    const uint8_t* nonacgt;       // per read: SEQ holds a base outside ATGC somewhere (k_flag_bases, once per pushed batch)
 };
 
 struct Derived {
@@ -180,6 +181,54 @@ __device__ __forceinline__ int char2allele(int c) {
 __device__ __forceinline__ int asc_rank(int a) { return a == 0 ? 0 : a == 3 ? 1 : a == 2 ? 2 : 3; }  // A<C<G<T
 __device__ __forceinline__ int upper(int c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
 __device__ __forceinline__ bool is_alpha(int c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+
+// ---------------------------------------------------------------------------------------
+// k_flag_bases: which reads hold a base outside ATGC anywhere in SEQ -- the reference's pile raises KeyError on one that is
+// aligned (caller.py:57, util.py:17), wherever it sits in a fetched read.  The packed bases are read once per pushed batch
+// (like the window index, the answer depends on the reads only); a flagged read -- CCS reads do not carry N -- is then
+// looked at base by base, per run, by the kernel that knows what is aligned and what is fetched (aligned_bases_ok).
+// One wave per read, 32 bases a lane and step; a BAM code is one of A C G T exactly when it has one bit set.
+__global__ void __launch_bounds__(256) k_flag_bases(int64_t n, const int64_t* qoff, const int32_t* qlen, const uint8_t* seq, uint8_t* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int64_t qo = __builtin_amdgcn_readfirstlane((int)(qoff[r] >> 32)) * 4294967296ll + (uint32_t)__builtin_amdgcn_readfirstlane((int)qoff[r]);
+    const int32_t ql = __builtin_amdgcn_readfirstlane(qlen[r]);
+    uint32_t badw = 0;
+    for (int32_t o = lane * 32; o < ql; o += 2048) {
+        const uint4 v = *reinterpret_cast<const uint4*>(seq + ((qo + o) >> 1));      // (a read's bases start at a multiple of 32)
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = w[k];
+            const int left = ql - (o + 8 * k);                   // bases of the word inside the read (byte i: bases 2i, 2i + 1, high nibble first)
+            if (left <= 0) continue;
+            uint32_t pc = x - ((x >> 1) & 0x55555555u);
+            pc = (pc & 0x33333333u) + ((pc >> 2) & 0x33333333u);   // bits set, per nibble
+            uint32_t d = pc ^ 0x11111111u;
+            if (left < 8) {                                      // nibbles behind the read's last base do not count
+                uint32_t keep = 0;
+                for (int b = 0; b < left; b++) keep |= 0xfu << (8 * (b >> 1) + ((b & 1) ? 0 : 4));
+                d &= keep;
+            }
+            badw |= d;
+        }
+    }
+    const unsigned long long any = __ballot(badw != 0);
+    if (lane == 0) out[r] = any ? 1 : 0;
+}
+
+// every aligned base of read r (the gapless segments that are not deletions) is one of ATGC?  For the lanes [l0, l0 + nl) of
+// a wave together; the answer is valid in every one of them.  (A flagged read only: k_flag_bases.)
+__device__ __forceinline__ bool aligned_bases_ok(const Reads& R, const Seg* segs, int ns, int64_t qo, int l, int nl) {
+    bool ok = true;
+    for (int j = 0; j < ns; j++) {
+        const Seg g = segs[j];
+        if ((g.flags & SEG_DEL) || g.len <= 0) continue;
+        for (int32_t i = l; i < g.len; i += nl) if (nib2allele(nib_at(R.seq, qo + g.q0 + i)) > 3) ok = false;
+    }
+    return ok;
+}
 
 template <class T>
 __device__ __forceinline__ int64_t lower_bound(const T* a, int64_t lo, int64_t hi, T x) {  // first a[i] >= x
@@ -1681,6 +1730,14 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) qsum += __shfl_down(qsum, d, 64);
             if (lane == 0) A.bqsum[r] = qsum;
+            // a read with a base outside ATGC somewhere (k_flag_bases): KeyError in the reference if the base is aligned and
+            // some chunk fetches the read (caller.py:57,299)
+            if (R.nonacgt && uni((int)R.nonacgt[r])) {
+                int64_t lo_ = 0, hi_ = A.C.n;
+                while (lo_ < hi_) { const int64_t m_ = (lo_ + hi_) >> 1; if (A.C.rec[m_].start < tend) lo_ = m_ + 1; else hi_ = m_; }
+                if (lo_ > 0 && A.C.rec[lo_ - 1].pmaxend > tstart && __ballot(!aligned_bases_ok(R, gsegs, ns, qo, lane, 64)))
+                    set_err(const_cast<int*>(A.err), HIMUT_ERR_BASE);
+            }
             // the read filters have their last input: this read's proposals
             if (A.mask) propose_read(R, A.D, A.C, A.H, A.P, r, uni(qsum), lane, 64, lane & 15, lane & 48, A.mask, A.tilecnt, A.ccs_flag, nullptr);
         }

@@ -57,6 +57,14 @@ __global__ void __launch_bounds__(256) k_read_live(Reads R, Derived D, Chunks C,
             }
         }
         if (bad) set_err(err, bad);
+        // a read with a base outside ATGC somewhere (k_flag_bases): KeyError in the reference's pile if the base is aligned
+        // and some chunk fetches the read (normcounts.py:289,117; every fetched read is piled, whatever its filters say)
+        if (R.nonacgt && R.nonacgt[r] && M.nseg > 0) {
+            int64_t lo = 0, hi = C.n;
+            while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (C.rec[m].start < M.tend) lo = m + 1; else hi = m; }
+            if (lo > 0 && C.rec[lo - 1].pmaxend > M.tstart && !aligned_bases_ok(R, D.segs + M.segbase, M.nseg, M.qoff, gl, 16))
+                set_err(err, HIMUT_ERR_BASE);
+        }
         if (gl != 0) return;
         const int32_t qlen = R.qlen[r];
         bool ok = (M.flags & RF_IDENT_OK) != 0;

@@ -385,3 +385,40 @@ def test_call_and_normcounts_interleaved_on_one_context(worker):
         assert (worker.ctx.records().tobytes(), list(worker.ctx.log())) == c1
         assert norm() == n1
         assert call(s.batch, chunks) == c1
+
+
+def test_normcounts_query_base_outside_atgc_in_a_fetched_read(worker):
+    """normcounts.py:117 piles every base of every read a chunk fetches (:289): an aligned query base outside ATGC is a KeyError
+    there even when it lies outside the chunk's own positions -- and none when it is soft-clipped or when no chunk fetches the
+    read.  The oracle restates that; here k_read_live looks at the reads k_flag_bases has flagged."""
+    from oracle import oracle as O
+    from himut_amd import _ffi, normcounts
+    from himut_amd.readbatch import batch_from_records
+    rs = np.random.RandomState(3)
+    refseq = bytes(rs.choice(np.frombuffer(b"ACGT", np.uint8), 3000))
+    ref = refseq.decode()
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=10, qlen_upper_limit=10000, md_threshold=60, min_trim=0.0)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+    reads = [dict(tstart=400 + 7 * i, tend=1000 + 7 * i, seq=ref[400 + 7 * i:1000 + 7 * i], bq=[93] * 600, cs=":600") for i in range(12)]
+
+    def both(extra, chunks, want_error):
+        recs = sorted(reads + extra, key=lambda r: r["tstart"])
+        b = batch_from_records("c", 3000, recs)
+        _configure(worker, p)
+        if want_error:
+            with pytest.raises(O.OracleError):
+                O.normcounts(b, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+            with pytest.raises(_ffi.HimutError) as e:
+                normcounts.norm_contig(worker, b, chunks, refseq, alt_order=order)
+            assert e.value.code == 4
+        else:
+            o = O.normcounts(b, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+            h = normcounts.norm_contig(worker, b, chunks, refseq, alt_order=order)
+            assert h[2] == o[2] and h[0] == o[0] and h[1] == o[1]
+
+    s = ref[100:700]
+    n_out = dict(tstart=100, tend=700, seq=s[:50] + "N" + s[51:], bq=[93] * 600, cs=":600")     # the N at position 150
+    both([n_out], [(500, 1500)], True)           # fetched by the chunk (tend > 500), the N in front of the chunk
+    both([n_out], [(800, 1500)], False)          # not fetched
+    both([dict(tstart=120, tend=700, qstart=20, seq="N" * 20 + ref[120:700], bq=[93] * 600, cs=":580")], [(500, 1500)], False)

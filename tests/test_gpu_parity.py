@@ -172,10 +172,13 @@ def test_error_codes_mirror_reference_failures(worker):
     ok = dict(tstart=10, tend=210, seq=seq, bq=[93] * 200, cs=":200")
     cand = dict(tstart=10, tend=210, seq=seq[:100] + "T" + seq[101:], bq=[93] * 200, cs=":100*at:99")
     run([ok, cand])
-    # query N inside a match: KeyError in the reference.  Detected where the N sits in an
-    # evaluated column (the reference dies wherever it sits in a fetched read).
+    # query N inside a match: KeyError in the reference, wherever it sits in a read that some chunk fetches
+    # (caller.py:57,299) -- in a candidate column or far from one
     with pytest.raises(_ffi.HimutError) as e:
         run([dict(ok, seq=seq[:100] + "N" + seq[101:]), cand])
+    assert e.value.code == 4
+    with pytest.raises(_ffi.HimutError) as e:
+        run([dict(ok, seq=seq[:30] + "N" + seq[31:]), cand])
     assert e.value.code == 4
     with pytest.raises(_ffi.HimutError) as e:   # garbage in cs
         run([dict(ok, cs=":100~ac:100")])
@@ -192,6 +195,48 @@ def test_error_codes_mirror_reference_failures(worker):
     with pytest.raises(_ffi.HimutError) as e:
         worker.call_contig(b, [(0, 1000)])
     assert e.value.code == 5
+
+
+def test_query_base_outside_atgc_raises_only_where_the_reference_does(worker):
+    """caller.py:57: base2idx has only ATGC, so an ALIGNED query base outside them (N, an IUPAC code) ends the reference with
+    a KeyError as soon as a chunk fetches the read -- and only then: a soft-clipped or inserted base is never looked up, and a
+    read no chunk fetches is never piled.  The oracle restates that (ORC_ERR_BASE); the reads are flagged once per pushed
+    batch (k_flag_bases) and a flagged read's aligned bases are looked at by its capture wave."""
+    from oracle import oracle as O
+    from himut_amd import _ffi
+    from himut_amd.readbatch import batch_from_records
+    p = dict(util.CALL_DEFAULTS, qlen_lower_limit=10, qlen_upper_limit=10000, md_threshold=52)
+    seq = "ACGT" * 50
+    base = [dict(tstart=10, tend=210, seq=seq, bq=[93] * 200, cs=":200") for _ in range(4)]
+    base.append(dict(tstart=10, tend=210, seq=seq[:100] + "T" + seq[101:], bq=[93] * 200, cs=":100*at:99"))
+
+    def both(extra, chunks=((0, 1000),), want_error=False):
+        recs = sorted(base + extra, key=lambda r: r["tstart"])
+        b = batch_from_records("c", 3000, recs)
+        _configure(worker, p, False)
+        if want_error:
+            with pytest.raises(O.OracleError) as oe:
+                O.call(b, list(chunks), p, p["germline_snv_prior"])
+            assert "KeyError" in str(oe.value)
+            with pytest.raises(_ffi.HimutError) as e:
+                worker.call_contig(b, list(chunks))
+            assert e.value.code == 4
+        else:
+            orecs, olog = O.call(b, list(chunks), p, p["germline_snv_prior"])
+            hrecs, hlog = worker.call_contig(b, list(chunks))
+            assert hlog == olog and len(hrecs) == len(orecs) and np.array_equal(hrecs["tpos"], orecs["tpos"])
+
+    n_mid = dict(tstart=10, tend=210, seq=seq[:150] + "N" + seq[151:], bq=[93] * 200, cs=":200")
+    both([n_mid], want_error=True)                                        # aligned, far from any candidate
+    both([dict(n_mid, seq=seq[:150] + "R" + seq[151:])], want_error=True)  # an IUPAC code is not in base2idx either
+    both([dict(n_mid, seq=seq[:199] + "N")], want_error=True)              # the read's last aligned base
+    # soft-clipped N (the leading 20 bases are clipped), inserted N: never looked up
+    both([dict(tstart=10, tend=190, qstart=20, seq="N" * 20 + seq[:180], bq=[93] * 200, cs=":180")])
+    both([dict(tstart=10, tend=208, seq=seq[:60] + "NN" + seq[60:198], bq=[93] * 200, cs=":60+nn:138")])
+    # a read with an aligned N that no chunk fetches: never piled
+    far = dict(tstart=2000, tend=2200, seq=seq[:150] + "N" + seq[151:], bq=[93] * 200, cs=":200")
+    both([far])
+    both([far], chunks=((0, 1000), (1500, 2001)), want_error=True)         # ... until a chunk reaches it (start < end and end > start)
 
 
 def test_full_size_chr20_properties_and_prefix_parity(worker):
