@@ -182,11 +182,10 @@ static_assert(sizeof(Scalars) == 256, "Scalars is cleared with one aligned fill"
 
 const char* err_text(int code) {
     switch (code) {
-        case HIMUT_ERR_CS: return "cs tag cannot be tokenised, has consecutive insertions, or disagrees with SEQ/CIGAR";
+        case HIMUT_ERR_CS: return "cs tag cannot be tokenised or disagrees with SEQ/CIGAR";
         case HIMUT_ERR_BASE: return "KeyError: base outside ATGC (util.py:17)";
         case HIMUT_ERR_BQ0: return "ValueError: math domain error (BQ 0 in a candidate column, gtlib.py:64)";
         case HIMUT_ERR_COVER: return "KeyError: hetSNP position missing from tpos2qbase (haplib.py:51)";
-        case HIMUT_ERR_BQ_RANGE: return "base quality out of range";
         case HIMUT_ERR_DEPTH: return "pile too deep: the contig's candidate columns need more than 2^32 column-store slots";
     }
     return "device error";

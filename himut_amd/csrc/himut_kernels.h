@@ -606,7 +606,10 @@ k_parse_cs(Reads R, Derived D, Params P, int* err, uint8_t* ccs, uint32_t* posbi
                 if (kind == '-') {
                     sg_del.t0 = tk; sg_del.q0 = qk; sg_del.len = len; sg_del.flags = SEG_DEL | (prev_kind == '+' ? SEG_INS : 0u);
                     nseg_here++;
-                } else if (prev_kind == '+') bad = HIMUT_ERR_CS;    // two insertions in a row: unsupported
+                }
+                // (an insertion straight behind an insertion -- the tokenizer splits "+a+cg" in two, cslib.py:7-10; an aligner
+                //  writes one -- is one more mismatch entry at the same position and no segment of its own: the position
+                //  still carries "an insertion precedes", and nothing the reference prints depends on how many)
             }
             const int iseg = wave_rank_incl(nseg_here >= 1) + wave_rank_incl(nseg_here == 2);
             if (nseg_here) {

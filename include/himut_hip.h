@@ -49,13 +49,13 @@ enum {
     HIMUT_OK = 0,
     HIMUT_ERR_ARG = 1,          /* bad argument / call order */
     HIMUT_ERR_HIP = 2,          /* HIP runtime failure */
-    HIMUT_ERR_CS = 3,           /* cs tag the reference's tokenizer (cslib.py:7-10) cannot split,
-                                   consecutive insertions, or cs inconsistent with SEQ/CIGAR */
+    HIMUT_ERR_CS = 3,           /* cs tag the reference's tokenizer (cslib.py:7-10) cannot split, or cs inconsistent
+                                   with SEQ/CIGAR */
     HIMUT_ERR_BASE = 4,         /* KeyError in the reference: base outside ATGC (util.py:17) */
     HIMUT_ERR_BQ0 = 5,          /* ValueError in the reference: log10(0) for BQ 0 (gtlib.py:64) */
     HIMUT_ERR_CHUNK = 6,        /* chunk with start > end (pysam raises) */
     HIMUT_ERR_COVER = 7,        /* KeyError in tpos2qbase (haplib.py:51) */
-    HIMUT_ERR_BQ_RANGE = 8,     /* BQ >= 126: not representable in the pile cell */
+    HIMUT_ERR_RESERVED8 = 8,    /* (never returned; kept so that the codes behind it do not move) */
     HIMUT_ERR_NOMEM = 9,
     HIMUT_ERR_DEPTH = 10        /* the contig's candidate columns need more than 2^32 column-store slots (or one
                                    256-position window holds more than 2^22 reads): split the contig's chunk list */
@@ -126,7 +126,9 @@ typedef struct himut_record {
     uint8_t gt_state;           /* 0 homref 1 het 2 hetalt 3 homalt */
     uint8_t flags;              /* internal; 0 in returned records */
     uint8_t pad;
-    uint32_t counts[6];         /* A T G C ins del (util.py:14-20 order) at rpos = tpos - 1 */
+    uint32_t counts[6];         /* A T G C ins del (util.py:14-20 order) at rpos = tpos - 1; ins = the reads with an insertion in
+                                   front of the position (the reference counts insertion OPERATIONS, which is one more for a read
+                                   whose cs holds two insertions in a row; nothing it prints depends on the number, only on != 0) */
     uint32_t bqsum[4];          /* sum of BQ per allele A T G C */
 } himut_record;
 

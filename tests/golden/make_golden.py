@@ -782,6 +782,31 @@ def main():
         norm_case("norm_softmask", small_cfg(204, contig_len=20000, name="chrM"), md_threshold=52, mutate_ref=mask)
     if want("worker_boundary"):
         boundary_case()
+    if want("worker_insins") or want("norm_insins"):
+        def split_insertions(b):
+            """every other insertion of two or more bases becomes two insertion operations in a row (+acg -> +a+cg): the
+            tokenizer (cslib.py:7-10) splits them, cs2tuple (:13-44) emits two state-3 tuples, the pile counts two insertions
+            at the position and the mismatch list holds two entries"""
+            import re
+            out, offs, k = [], [0], 0
+            for i in range(b.n):
+                cs = bytes(b.cs[b.cs_off[i]:b.cs_off[i + 1]]).decode()
+                def rep(m):
+                    nonlocal k
+                    k += 1
+                    return "+" + m.group(1)[0] + "+" + m.group(1)[1:] if k & 1 else m.group(0)
+                cs = re.sub(r"\+([a-z]{2,})", rep, cs)
+                out.append(cs.encode())
+                offs.append(offs[-1] + len(cs))
+            b.cs = np.frombuffer(b"".join(out), np.uint8).copy()
+            b.cs_off = np.array(offs, np.int64)
+        cfg = dict(contig_len=30000, ins_rate=2e-3, del_rate=5e-4, sub_rate=1e-3, som_rate=3e-4, frac_noisy=0.0)
+        if want("worker_insins"):
+            worker_case("worker_insins", small_cfg(131, name="chrI", **cfg), md_threshold=52, mutate=split_insertions,
+                        overrides=dict(min_sequence_identity=0.9, max_mismatch_count=2, mismatch_window_size=12))
+        if want("norm_insins"):
+            norm_case("norm_insins", small_cfg(132, name="chrJ", **cfg), md_threshold=52, mutate_batch=split_insertions,
+                      overrides=dict(min_sequence_identity=0.9, max_mismatch_count=2, mismatch_window_size=12))
 
 
 if __name__ == "__main__":

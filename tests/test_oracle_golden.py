@@ -58,7 +58,7 @@ def test_cs_tuples():
                 assert (o[3], o[4]) == (t[1], t[2])
 
 
-NORM_CASES = ["norm_basic", "norm_sets", "norm_dense", "norm_softmask", "norm_phase", "norm_nsub"]
+NORM_CASES = ["norm_basic", "norm_sets", "norm_dense", "norm_softmask", "norm_phase", "norm_nsub", "norm_insins"]
 
 
 def load_norm_case(case):

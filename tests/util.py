@@ -15,7 +15,7 @@ CALL_DEFAULTS = dict(min_qv=30, min_mapq=60, min_sequence_identity=0.99, min_gq=
                      germline_indel_prior=1 / (10 ** 4))
 
 WORKER_CASES = ["worker_basic", "worker_sets", "worker_dense", "worker_dense_sets", "worker_longcs",
-                "worker_boundary", "worker_flags", "worker_pon_params"]
+                "worker_boundary", "worker_flags", "worker_pon_params", "worker_insins"]
 PHASE_CASES = ["worker_phase", "worker_phase_dense", "worker_phase_dup"]
 
 
