@@ -54,7 +54,7 @@ EXPORTS = ["himut_abi_version", "himut_create", "himut_destroy", "himut_last_err
            "himut_copy_records_to_device", "himut_pile_counts", "himut_set_reference", "himut_run_normcounts",
            "himut_get_normcounts", "himut_ref_tricounts", "himut_run_edges", "himut_set_stage_timing", "himut_sbs96_counts", "himut_ingest_begin", "himut_ingest_buffer",
            "himut_ingest_wait", "himut_ingest_window", "himut_ingest_end", "himut_ingest_read_meta", "himut_download_reads",
-           "himut_inflate_blocks", "himut_run_begin", "himut_run_end", "himut_debug_normcounts"]
+           "himut_run_begin", "himut_run_end", "himut_debug_normcounts"]
 
 _lib = None
 
@@ -119,8 +119,6 @@ def lib():
                                      ctypes.c_void_p]
     L.himut_run_edges.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int64, ctypes.c_void_p]
-    L.himut_inflate_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                       ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
     L.himut_ingest_begin.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
     L.himut_ingest_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.himut_ingest_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -315,17 +313,6 @@ class Context:
 
     def raise_for(self, rc):
         self._check(rc)
-
-    def inflate_blocks(self, comp, blocks, out_bytes):
-        """BGZF blocks inflated on the device: comp = bytes-like of the compressed bytes, blocks = numpy structured array
-        (uoff u8, coff u4, clen u4, isize u4, pad u4).  Returns (inflated bytes as uint8 array, status bits, kernel ms)."""
-        comp = np.frombuffer(comp, np.uint8)
-        blocks = np.ascontiguousarray(blocks)
-        out = np.zeros(int(out_bytes), np.uint8)
-        status, ms = ctypes.c_int(0), ctypes.c_double(0.0)
-        self._check(self._L.himut_inflate_blocks(self._h, comp.ctypes.data, comp.shape[0], blocks.ctypes.data, blocks.shape[0],
-                                                 out.ctypes.data, out.shape[0], ctypes.byref(status), ctypes.byref(ms)))
-        return out, status.value, ms.value
 
     def ingest_wait(self, slot):
         self._check(self._L.himut_ingest_wait(self._h, int(slot)))

@@ -67,7 +67,7 @@ def build_host(force=False):
     srcs = [os.path.join(CSRC, "bam_ingest.cpp")]
     if not os.path.exists(srcs[0]):
         return None
-    if not force and _newer(HOST_LIB, srcs + [os.path.join(INCLUDE, "himut_hip.h"), os.path.join(CSRC, "himut_inflate.h")]):
+    if not force and _newer(HOST_LIB, srcs + [os.path.join(INCLUDE, "himut_hip.h")]):
         return HOST_LIB
     _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE, "-I", CSRC,
           "-o", HOST_LIB] + srcs + ["-lz", "-ldl"])

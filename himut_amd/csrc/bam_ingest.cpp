@@ -15,7 +15,6 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
-#include "himut_inflate.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1314,23 +1313,6 @@ int bam_stream_pump(void* h, void* ctx, void* wait_fn, void* window_fn, uint8_t*
                     t_wait_inf, t_wait_dev, S->t_hop - t_hop0, t_window, t_first_window, (long long)nwin);
         return 0;
     } catch (const std::exception& e) { S->err = std::string("BAM stream: ") + e.what(); return -2; }
-}
-
-// The DEFLATE decoder the GPU runs (himut_inflate.h), on the host with plain tables: what tests/test_inflate.py checks
-// against zlib.  `in` must be readable for 160 bytes past in_len, `out` writable for 8 past out_len.  Returns 0 or a himut::InfErr.
-void inflate_port_stats(long long* out8, int reset) {
-    for (int k = 0; k < 8; k++) { out8[k] = inf_stats()[k]; if (reset) inf_stats()[k] = 0; }
-}
-int inflate_port(const uint8_t* in, int64_t in_len, uint8_t* out, int64_t out_len) {
-    std::vector<uint16_t> t16(himut::INF_LDS_U16 + 288);
-    std::vector<uint8_t> t8(himut::INF_LDS_U8);
-    std::vector<uint32_t> t32(himut::INF_LDS_U32);
-    himut::InfTables T;
-    T.ring = t32.data();
-    T.stride = 1; T.lstride = 1;
-    T.lut = t16.data(); T.lcnt = t16.data() + 256; T.lnext = t16.data() + 272; T.lpos = t16.data() + 288; T.lsym = t16.data() + 304;
-    T.lens = t8.data(); T.dsym = t8.data() + 320; T.dcnt = t8.data() + 352; T.off = t8.data() + 368;
-    return himut::inf_stream(in, in_len, out, out_len, T);
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -21,7 +22,6 @@
 #include "himut_norm.h"
 #include "himut_normq.h"
 #include "himut_ingest.h"
-#include "himut_inflate_wave.h"
 
 using namespace himut;
 
@@ -160,6 +160,16 @@ struct himut_ctx {
 };
 
 namespace {
+
+// the two pinned ingest windows of the process, and the context whose ingest is open on them (himut_ingest_begin .. _end)
+void* g_pinned[2] = {nullptr, nullptr};
+size_t g_pinned_bytes = 0;
+himut_ctx* g_pinned_owner = nullptr;
+std::mutex g_pinned_mx;
+void release_pinned(himut_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_pinned_mx);
+    if (g_pinned_owner == c) g_pinned_owner = nullptr;
+}
 
 struct PopcWord {
     __host__ __device__ uint32_t operator()(uint32_t w) const { return (uint32_t)__builtin_popcount(w); }
@@ -819,6 +829,7 @@ int himut_create(int device, himut_ctx** out) {
 
 void himut_destroy(himut_ctx* c) {
     if (!c) return;
+    release_pinned(c);
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
@@ -994,9 +1005,11 @@ int himut_ingest_begin(himut_ctx* c, int64_t inflated_bound, int64_t window_byte
         HCHECK(hipStreamSynchronize(c->side));
         const size_t W = (size_t)window_bytes;
         // The two pinned windows belong to the process, not to the context (pinning 128 MB takes tens of
-        // milliseconds; a call makes one context per contig and ingests them one after the other).
-        static void* g_pinned[2] = {nullptr, nullptr};
-        static size_t g_pinned_bytes = 0;
+        // milliseconds; a call makes one context per contig and ingests them one after the other): one ingest at a time
+        std::lock_guard<std::mutex> lock(g_pinned_mx);
+        if (g_pinned_owner && g_pinned_owner != c)
+            return fail(c, HIMUT_ERR_ARG, "another context's ingest is open: the two pinned windows belong to the process");
+        g_pinned_owner = c;
         if (g_pinned_bytes < W + 4096) {
             const auto t_pin = std::chrono::steady_clock::now();
             for (int k = 0; k < 2; k++) {
@@ -1115,6 +1128,7 @@ int himut_ingest_end(himut_ctx* c, int unique_qnames, himut_ingest_result* out) 
         HCHECK(hipStreamSynchronize(c->side));
         HCHECK(hipStreamSynchronize(st));
         c->ing_open = false;
+        release_pinned(c);
         IngestState S;
         HCHECK(hipMemcpy(&S, c->d_istate.p, sizeof(S), hipMemcpyDeviceToHost));
         memset(out, 0, sizeof(*out));
@@ -1141,50 +1155,6 @@ int himut_ingest_end(himut_ctx* c, int unique_qnames, himut_ingest_result* out) 
         HCHECK(hipStreamSynchronize(st));
         c->have_reads = S.n_unsorted == 0 && S.n_missing_cs == 0;
         c->tables_valid = false; c->win_nblk = 0; c->bases_flagged = false; c->h_recs_valid = false;
-        return HIMUT_OK;
-    });
-}
-
-// ---- the BGZF inflate on the device (csrc/himut_inflate.h), as a call of its own: host buffers in, host buffers out.
-// What the tests and tools/bench_inflate.py use; the ingest path keeps everything on the device.
-int himut_inflate_blocks(himut_ctx* c, const void* comp, int64_t comp_bytes, const himut_bgzf_block* blocks, int64_t n_blocks,
-                         void* out, int64_t out_bytes, int* status, double* kernel_ms) {
-    if (!c || !comp || !blocks || !out || !status || comp_bytes < 0 || n_blocks < 0 || out_bytes < 0) return fail(c, HIMUT_ERR_ARG, "bad inflate arguments");
-    for (int64_t k = 0; k < n_blocks; k++)
-        if ((int64_t)blocks[k].coff + blocks[k].clen > comp_bytes || (int64_t)blocks[k].uoff + blocks[k].isize > out_bytes)
-            return fail(c, HIMUT_ERR_ARG, "BGZF block outside its buffer");
-    return guarded(c, [&]() -> int {
-        HCHECK(hipSetDevice(c->device));
-        hipStream_t st = c->stream;
-        static_assert(sizeof(himut_bgzf_block) == sizeof(BgzfBlock), "the C ABI's block descriptor is the kernel's");
-        c->d_stage[0].reserve((size_t)comp_bytes + 2048);
-        c->d_stage[1].reserve((size_t)out_bytes + 256);
-        c->d_desc.reserve((size_t)n_blocks * sizeof(BgzfBlock) + 256);
-        c->d_istate.reserve(256);
-        c->d_offs.reserve((size_t)std::max<int64_t>(n_blocks, 1) * 288 * 2 + 256);
-        HCHECK(hipMemcpyAsync(c->d_stage[0].p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
-        HCHECK(hipMemsetAsync((uint8_t*)c->d_stage[0].p + comp_bytes, 0, 1024, st));
-        HCHECK(hipMemcpyAsync(c->d_desc.p, blocks, (size_t)n_blocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
-        HCHECK(hipMemsetAsync(c->d_istate.p, 0, 4, st));
-        hipEvent_t e0, e1;
-        HCHECK(hipEventCreate(&e0)); HCHECK(hipEventCreate(&e1));
-        HCHECK(hipEventRecord(e0, st));
-        // HIMUT_INFLATE=lane: the lane-per-block decoder (himut_inflate.h); default: a wave per block (himut_inflate_wave.h)
-        const char* which = getenv("HIMUT_INFLATE");
-        if (n_blocks && which && strcmp(which, "lane") == 0)
-            hipLaunchKernelGGL(k_bgzf_inflate, dim3(blocks_for(n_blocks, 64)), dim3(64), 0, st, c->d_stage[0].as<uint8_t>(),
-                               c->d_desc.as<BgzfBlock>(), n_blocks, c->d_stage[1].as<uint8_t>(), c->d_istate.as<int>(), c->d_offs.as<uint16_t>());
-        else if (n_blocks)
-            hipLaunchKernelGGL(k_bgzf_inflate_wave, dim3(blocks_for(n_blocks, 4)), dim3(256), 0, st, c->d_stage[0].as<uint8_t>(),
-                               c->d_desc.as<BgzfBlock>(), n_blocks, c->d_stage[1].as<uint8_t>(), c->d_istate.as<int>());
-        HCHECK(hipEventRecord(e1, st));
-        HCHECK(hipMemcpyAsync(status, c->d_istate.p, 4, hipMemcpyDeviceToHost, st));
-        HCHECK(hipMemcpyAsync(out, c->d_stage[1].p, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
-        HCHECK(hipStreamSynchronize(st));
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        if (kernel_ms) *kernel_ms = ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         return HIMUT_OK;
     });
 }

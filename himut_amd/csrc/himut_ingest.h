@@ -16,7 +16,6 @@
 #pragma once
 
 #include "himut_kernels.h"
-#include "himut_inflate.h"
 
 namespace himut {
 
@@ -95,6 +94,7 @@ __global__ void __launch_bounds__(256) k_bam_decode(const uint8_t* win, int64_t 
                         const int sub = p[0];
                         const uint32_t cnt = ld_u32(p + 1);
                         const uint64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                        if ((uint64_t)(end - p) < 5 + es * (uint64_t)cnt) { ok = false; break; }     // the array runs past the record
                         p += 5 + es * cnt;
                         continue;
                     } else { ok = false; break; }
@@ -215,46 +215,6 @@ __global__ void k_bam_advance(const RecDesc* desc, const uint2* sizes, const uin
     S->cs_n += (unsigned long long)lo.y + ls.y;
     S->last_pos = desc[nrec - 1].pos;
     if ((int64_t)S->n_reads <= cap_reads) cs_off[S->n_reads] = (int64_t)S->cs_n;      // n + 1 entries
-}
-
-// ---------------------------------------------------------------------------------------
-// k_bgzf_inflate: one LANE per BGZF block (himut_inflate.h).  comp: the compressed bytes of the blocks (readable for 160
-// bytes behind the last one), blocks: where each block's raw DEFLATE stream sits in comp, how long it is, how many bytes
-// it inflates to (ISIZE) and where they go in out.  status: OR of 1 << InfErr over the blocks.
-struct BgzfBlock {
-    uint64_t uoff;      // offset of the block's inflated bytes in `out`
-    uint32_t coff;      // offset of its compressed bytes in `comp`
-    uint32_t clen;
-    uint32_t isize;
-    uint32_t pad;
-};
-__global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t* comp, const BgzfBlock* blocks, int64_t nblocks, uint8_t* out, int* status,
-                                                     uint16_t* lsym_scratch) {
-    __shared__ uint16_t s16[INF_LDS_U16 * 64];
-    __shared__ uint8_t s8[INF_LDS_U8 * 64];
-    __shared__ uint32_t s32[INF_LDS_U32 * 64];
-    const int lane = threadIdx.x;
-    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
-    InfTables T;
-    T.ring = s32 + lane;
-    T.stride = 64; T.lstride = 1;
-    T.lut = s16 + lane; T.lcnt = s16 + 256 * 64 + lane; T.lnext = s16 + 272 * 64 + lane; T.lpos = s16 + 288 * 64 + lane;
-    T.lens = s8 + lane; T.dsym = s8 + 320 * 64 + lane; T.dcnt = s8 + 352 * 64 + lane; T.off = s8 + 368 * 64 + lane;
-    T.lsym = lsym_scratch + (b < nblocks ? b : 0) * 288;       // the symbols with long codes: rarely read, in HBM
-    InfLane L;
-    L.mode = INF_M_DONE; L.err = 0;
-    if (b < nblocks) {
-        const BgzfBlock B = blocks[b];
-        if (B.isize) inf_begin(L, T, comp + B.coff, (int64_t)B.clen, out + B.uoff, (int64_t)B.isize);
-    }
-    // every lane of the wave goes through the same sequence of turns; a lane that is done sits them out
-    // (the modes that wait for memory -- a match reads the lane's own output, which waits for every store before it;
-    // a header builds tables -- take a turn in four: the lanes that need one gather, and the turns in between are
-    // nothing but table look-ups and byte stores)
-    for (int turn = 0; __any(L.mode != INF_M_DONE); turn++) {
-        if (L.mode == INF_M_SYMS || (L.mode != INF_M_DONE && (turn & 3) == 0)) inf_step(L, T);
-    }
-    if (L.err) atomicOr(status, 1 << L.err);
 }
 
 }  // namespace himut

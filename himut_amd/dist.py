@@ -181,14 +181,26 @@ def gather_contig_results(local, contig_names, rank, world, device_buffers=None,
     return out
 
 
+class RecordExchangeOverflow(RuntimeError):
+    """A submit held more records than its planned message carries.  Raised by ``drain`` on EVERY rank alike, with the
+    capacities the exchange must be rebuilt with (``caps``) before the pass is repeated."""
+
+    def __init__(self, caps, where):
+        RuntimeError.__init__(self, "RecordExchange: more records than planned at (rank, submit) {}".format(where))
+        self.caps = caps
+
+
 class RecordExchange:
     """The same final exchange, pipelined: the records of one finished contig travel to rank 0 while the next
     contig is scanned.  A run is a sequence of ROUNDS (round k = the k-th contig of every rank; a rank with fewer
-    contigs sends nothing in the later rounds).  The sizes are agreed once (``plan``: per round and rank the record
-    count of a rehearsal pass + 25 %), so every transfer is a point-to-point message of its own size from the
-    owner to rank 0 -- each peer on its own xGMI link, nothing padded to the largest share.  ``depth`` passes over
-    the rounds may be in flight (buffers per round and pass); the record counts and the 15 counters travel in one
-    small all-gather when the exchange is drained."""
+    contigs sends nothing in the later rounds).  A point-to-point message has one size that sender and receiver must
+    agree on beforehand, so the sizes are agreed once (``plan``: per round and rank the record count of a rehearsal
+    pass -- the scan is deterministic, so that IS the count of every later pass -- plus one record in 64 of slack):
+    every transfer is a message of its own size from the owner to rank 0, each peer on its own xGMI link, nothing
+    padded to the largest share and next to nothing padded at all.  A submit with more records than planned sends the
+    planned part and is reported by ``drain`` on every rank (RecordExchangeOverflow: rebuild with its ``caps`` and
+    repeat the pass).  ``depth`` passes over the rounds may be in flight (buffers per round and pass); the record
+    counts and the 15 counters travel in one small all-gather when the exchange is drained."""
 
     def __init__(self, rank, world, caps, depth=2, keep=False):
         import torch
@@ -228,7 +240,7 @@ class RecordExchange:
     @staticmethod
     def plan(n_local):
         """Collective.  ``n_local``: this rank's record count per round (a list; an int = one round).  Returns the
-        capacities [round][rank] every rank must construct the exchange with (count + 25 %)."""
+        capacities [round][rank] every rank must construct the exchange with (the count + one in 64 + 16)."""
         import torch
         import torch.distributed as dist
         dev = _gather_device()
@@ -243,7 +255,7 @@ class RecordExchange:
         allt = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         cnt = np.stack([x.cpu().numpy() for x in allt], axis=1)         # [round][rank]
-        return [[int(n) * 5 // 4 + 64 if n > 0 else 0 for n in row] for row in cnt]
+        return [[int(n) + int(n) // 64 + 16 if n > 0 else 0 for n in row] for row in cnt]
 
     def _finish(self, slot):
         if not self.reqs[slot] and slot not in self._pending:
@@ -263,11 +275,13 @@ class RecordExchange:
         rnd = self.k % self.rounds
         slot = self.k % (self.rounds * self.depth)
         cap = self.caps[rnd][self.rank]
-        if n > cap:
-            raise ValueError("RecordExchange: {} records exceed the planned capacity {}".format(n, cap))
         self._finish(slot)          # the transfers that last used this slot's buffers are over
         dst = self.recv[slot][0] if self.rank == 0 else self.send[slot]
-        if n:
+        if n > cap:
+            # more than the message carries: nothing of it is sent (the message keeps its planned size: the other side has
+            # posted it), the count in the table tells every rank at drain()
+            pass
+        elif n:
             if ctx is not None:
                 ctx.copy_records_to_device(dst.data_ptr(), cap)
             else:
@@ -297,9 +311,21 @@ class RecordExchange:
         m = torch.tensor(self.meta if self.meta else [[0] * 16], dtype=torch.int64, device=self.dev)
         allm = [torch.empty_like(m) for _ in range(self.world)]
         dist.all_gather(allm, m)
+        counts = [t.cpu().numpy() for t in allm]
+        # a submit that did not fit its planned message: every rank sees the same table and raises the same error
+        need = [row[:] for row in self.caps]
+        over = []
+        for r in range(self.world):
+            for k in range(len(self.meta)):
+                n, rnd = int(counts[r][k][0]), k % self.rounds
+                if n > self.caps[rnd][r]:
+                    over.append((r, k))
+                    need[rnd][r] = max(need[rnd][r], n + n // 64 + 16)
+        if over:
+            self.meta = []
+            raise RecordExchangeOverflow(need, over[:8])
         if self.rank != 0:
             return None
-        counts = [t.cpu().numpy() for t in allm]
         last = self.last_records(counts) if materialize_last else None
         return counts, last
 

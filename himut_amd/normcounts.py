@@ -129,7 +129,8 @@ def read_fasta(path):
     seqs = {}
     with open(path, "rb") as fh:
         data = fh.read()
-    for rec in data.split(b">")[1:] if data.startswith(b">") else _fasta_records(data):
+    # a record starts with '>' at the START of a line only (a '>' inside a description is text)
+    for rec in data[1:].split(b"\n>") if data.startswith(b">") else _fasta_records(data):
         header, _, body = rec.partition(b"\n")
         fields = header.split()
         if not fields:

@@ -213,7 +213,9 @@ int himut_copy_records_to_device(himut_ctx* ctx, void* dst_device, int64_t capac
  * window k + 1 (two buffers: himut_ingest_wait(slot) returns once slot's bytes have left the host).  padded_bases =
  * sum of the records' l_seq rounded up to 32, tag_bytes = an upper bound of the cs text in the window (the bytes of
  * the records' auxiliary fields): what the library must have room for.  himut_ingest_end leaves the context as
- * himut_push_reads would.  libhimut_host.so's bam_stream_* (csrc/bam_ingest.cpp) is the host side that goes with it. */
+ * himut_push_reads would.  The two pinned buffers belong to the PROCESS (pinning them takes tens of milliseconds): one
+ * ingest may be open at a time -- himut_ingest_begin on a second context before the first's himut_ingest_end (or
+ * himut_destroy) returns HIMUT_ERR_ARG.  libhimut_host.so's bam_stream_* (csrc/bam_ingest.cpp) is the host side that goes with it. */
 typedef struct himut_ingest_result {
     int64_t n_reads, bases_padded, cs_bytes, read_bases;
     int64_t n_missing_cs;       /* records without a cs tag (the reference's get_tag("cs") raises KeyError, bamlib.py:32) */
@@ -226,17 +228,6 @@ int himut_ingest_wait(himut_ctx* ctx, int slot);
 int himut_ingest_window(himut_ctx* ctx, int slot, int64_t start, int64_t nbytes, const uint32_t* rec_off, const int32_t* qid,
                         int64_t n_rec, int64_t padded_bases, int64_t tag_bytes);
 int himut_ingest_end(himut_ctx* ctx, int unique_qnames, himut_ingest_result* out);
-/* The BGZF inflate on the device, one lane per block (csrc/himut_inflate.h; the reference reads BAM through htslib,
- * caller.py:267): comp = the blocks' compressed bytes, blocks[k] = where block k's raw DEFLATE stream sits in comp, its
- * length, the number of bytes it inflates to (ISIZE) and where they go in out.  *status = OR of 1 << error over the blocks
- * (0: every block inflated to exactly its ISIZE), *kernel_ms = the kernel's time.  Host buffers in and out: for tests and
- * measurements; the ingest keeps the bytes on the device. */
-typedef struct himut_bgzf_block {
-    uint64_t uoff;
-    uint32_t coff, clen, isize, pad;
-} himut_bgzf_block;
-int himut_inflate_blocks(himut_ctx* ctx, const void* comp, int64_t comp_bytes, const himut_bgzf_block* blocks, int64_t n_blocks,
-                         void* out, int64_t out_bytes, int* status, double* kernel_ms);
 /* per-read fields the host needs for bamlib.get_thresholds (bamlib.py:137-178); any pointer may be null */
 int himut_ingest_read_meta(himut_ctx* ctx, int32_t* tstart, int32_t* tend, int32_t* qlen, uint8_t* mapq, uint8_t* tp);
 /* the resident read batch back on the host (arrays of the caller, sized by the fields of `batch` on entry) */

@@ -87,6 +87,34 @@ if rank == 0:
         w1 = fake("chr2")[0]; w1["gq"] += p
         assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), p
     print("EXCHANGE1_OK")
+# the plan is the rehearsal's count plus one record in 64 (+ 16): what travels is the count, not a quarter more
+caps9 = hdist.RecordExchange.plan(9 if rank == 0 else 5)
+assert caps9 == [[9 + 16, 5 + 16]], caps9
+big = hdist.RecordExchange.plan(64000 if rank == 0 else 0)
+assert big == [[64000 + 1000 + 16, 0]], big
+# a pass with more records than planned (rank 1's second submit): no rank hangs, drain() raises the same error on both with
+# the capacities to rebuild with; the rebuilt exchange carries the pass
+ex2 = hdist.RecordExchange(rank, world, [[3, 3]], depth=2, keep=True)
+def pass2(ex):
+    for p in range(3):
+        n = 5 if (rank == 1 and p == 1) else 2
+        recs = np.zeros(n, RECORD_DTYPE); recs["tpos"] = 100 * rank + np.arange(n) + p
+        ex.submit(n, [p] * 15, records=recs)
+try:
+    pass2(ex2)
+    ex2.drain()
+    raise SystemExit("no overflow reported")
+except hdist.RecordExchangeOverflow as e:
+    assert e.caps == [[3, 5 + 16]], e.caps
+    ex3 = hdist.RecordExchange(rank, world, e.caps, depth=2, keep=True)
+pass2(ex3)
+out = ex3.drain()
+if rank == 0:
+    counts, _ = out
+    assert [int(x[0]) for x in counts[1]] == [2, 5, 2]
+    got = ex3.records_of(counts, 1)
+    assert list(got[1]["tpos"]) == [101, 102, 103, 104, 105] and list(got[0]["tpos"]) == [1, 2]
+    print("OVERFLOW_OK")
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -114,7 +142,7 @@ def test_gather_world_size_2_gloo(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    assert "GATHER_OK" in outs[0] and "EXCHANGE_OK" in outs[0] and "EXCHANGE1_OK" in outs[0], outs[0]
+    assert "GATHER_OK" in outs[0] and "EXCHANGE_OK" in outs[0] and "EXCHANGE1_OK" in outs[0] and "OVERFLOW_OK" in outs[0], outs[0]
 
 
 ERR_WORKER = r'''

@@ -258,3 +258,15 @@ def test_bgz_phased_and_sbs_files_read_like_plain_ones(tmp_path):
     refseq = N.read_fasta(fa)
     chroms = list(refseq)
     assert N.load_sbs96_counts(sbs, refseq, chroms) == N.load_sbs96_counts(sbs + ".bgz", refseq, chroms)
+
+
+def test_read_fasta_takes_a_record_start_only_at_a_line_start(tmp_path):
+    """A '>' inside a description is text (pyfastx, which the reference reads the genome with, splits records at line
+    starts): the header's first word is the name, the sequence keeps its case, blank lines and CRs go."""
+    from himut_amd import normcounts as N
+    fa = tmp_path / "g.fa"
+    fa.write_bytes(b">chr1 a>b len=8\nACGT\r\nacgt\n\n>chr2\tdesc >x\nNNAC\n>chr3\n")
+    assert N.read_fasta(str(fa)) == {"chr1": "ACGTacgt", "chr2": "NNAC", "chr3": ""}
+    fb = tmp_path / "h.fa"
+    fb.write_bytes(b"\n\n>c1 x>y\nAC\nGT\n")
+    assert N.read_fasta(str(fb)) == {"c1": "ACGT"}
