@@ -126,6 +126,7 @@ struct himut_ctx {
     DevBuf d_tilecnt, d_tileoff2, d_logpart;
     // normcounts
     DevBuf d_nonacgt;                        // per read: SEQ holds a base outside ATGC (k_flag_bases, once per batch)
+    DevBuf d_refcode;                        // per reference position: what the sweep wants to know about the letter (k_ref_codes)
     DevBuf d_refseq, d_live, d_callable, d_dirty, d_dcount, d_redo, d_plan, d_plancnt, d_tri;
     int dbg_norm_sweep = 0, dbg_norm_pool = 0;     // himut_debug_normcounts (tests)
     int64_t dbg_norm_dirty_cap = 0;
@@ -1371,11 +1372,11 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
             const dim3 grid(q_gx, (unsigned)T.n);
             const unsigned pool_limit = c->dbg_norm_pool > 0 ? (unsigned)std::min(c->dbg_norm_pool, NQ_SLOTS) : (unsigned)NQ_SLOTS;
             if (phase) hipLaunchKernelGGL(k_norm_quad<true>, grid, dim3(NQ_WAVES * 64), 0, st, A, c->d_callable.as<uint32_t>(), (int64_t)c->bq_bytes,
-                                          c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), tpc, q_per, c->d_dirty.as<NormDirty>(),
+                                          c->d_refcode.as<uint16_t>(), c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), tpc, q_per, c->d_dirty.as<NormDirty>(),
                                           c->d_dcount.as<uint32_t>(), dirty_cap, &sc->dirty_over, c->d_redo.as<NormRedo>(),
                                           &sc->nredo, redo_cap, pool_limit);
             else hipLaunchKernelGGL(k_norm_quad<false>, grid, dim3(NQ_WAVES * 64), 0, st, A, c->d_callable.as<uint32_t>(), (int64_t)c->bq_bytes,
-                                    c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), tpc, q_per, c->d_dirty.as<NormDirty>(),
+                                    c->d_refcode.as<uint16_t>(), c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), tpc, q_per, c->d_dirty.as<NormDirty>(),
                                     c->d_dcount.as<uint32_t>(), dirty_cap, &sc->dirty_over, c->d_redo.as<NormRedo>(),
                                     &sc->nredo, redo_cap, pool_limit);
             hipLaunchKernelGGL(k_norm_dirty, dim3((unsigned)std::min<int64_t>(blocks_for(q_regions, 4), 16384)), dim3(256), 0, st, A,
@@ -1428,6 +1429,9 @@ int himut_set_reference(himut_ctx* c, const uint8_t* seq, int64_t len, const uin
         if (!seq || len <= 0 || !cls || n_classes < 5 || n_classes > 32) return fail(c, HIMUT_ERR_ARG, "bad reference / class table");
         HCHECK(hipSetDevice(c->device));
         upload(c->d_refseq, seq, (size_t)len, c->stream);
+        // the letters' codes for the sweep, with room behind the string (a tile's last lanes read past it: codes of 0)
+        c->d_refcode.reserve(((size_t)len + 512) * 2);
+        hipLaunchKernelGGL(k_ref_codes, dim3(2048), dim3(256), 0, c->stream, c->d_refseq.as<uint8_t>(), len, c->d_refcode.as<uint16_t>(), len + 512);
         HCHECK(hipStreamSynchronize(c->stream));
         c->reflen = len;
         memcpy(c->ref_cls, cls, 256);

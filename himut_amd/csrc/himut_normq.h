@@ -58,6 +58,37 @@ __device__ __forceinline__ uint64_t nq_lane64(int64_t v, int l) {
     return ((uint64_t)(uint32_t)lane_val((int)(v >> 32), l) << 32) | (uint32_t)lane_val((int)v, l);
 }
 
+// What the sweep wants to know about a reference position, worked out once per himut_set_reference (k_ref_codes): bits 0-1
+// the allele (A0 T1 G2 C3) of the letter with its case folded, bit 2 "that letter is one of ACGT", bit 3 "the letter is an
+// upper-case ACGT" (normcounts.py:320: only those positions are classified), bits 4-8 the pyrimidine trinucleotide bin of
+// NORM_TRIBINS, bit 9 "the bin is valid" (the position and both neighbours inside the string, all three upper-case ACGT).
+constexpr uint32_t NQR_FOLD_OK = 4, NQR_CLS = 8, NQR_BIN_SHIFT = 4, NQR_BIN_OK = 512;
+__global__ void __launch_bounds__(256) k_ref_codes(const uint8_t* seq, int64_t len, uint16_t* out, int64_t n_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t code = 0;
+        if (i < len) {
+            const int c = seq[i], cu = c & 0xdf;
+            const int al = cu == 'A' ? 0 : cu == 'T' ? 1 : cu == 'G' ? 2 : cu == 'C' ? 3 : -1;
+            if (al >= 0) code |= (uint32_t)al | NQR_FOLD_OK;
+            if (char2allele(c) >= 0) code |= NQR_CLS;
+            if (i - 1 >= 0 && i + 2 <= len) {
+                int t0 = seq[i - 1], t1 = c, t2 = seq[i + 1];
+                if (t1 == 'A' || t1 == 'G') {
+                    const int a0 = t2, a2 = t0;
+                    t0 = a0 == 'A' ? 'T' : a0 == 'T' ? 'A' : a0 == 'G' ? 'C' : a0 == 'C' ? 'G' : 'N';
+                    t1 = t1 == 'A' ? 'T' : 'C';
+                    t2 = a2 == 'A' ? 'T' : a2 == 'T' ? 'A' : a2 == 'G' ? 'C' : a2 == 'C' ? 'G' : 'N';
+                }
+                auto acgt = [](int x) { return x == 'A' ? 0 : x == 'C' ? 1 : x == 'G' ? 2 : x == 'T' ? 3 : -1; };
+                const int i0 = acgt(t0), i2 = acgt(t2);
+                if (i0 >= 0 && i2 >= 0 && (t1 == 'C' || t1 == 'T'))
+                    code |= NQR_BIN_OK | ((uint32_t)(i0 * 8 + (t1 == 'T' ? 4 : 0) + i2) << NQR_BIN_SHIFT);
+            }
+        }
+        out[i] = (uint16_t)code;
+    }
+}
+
 // per-wave pool of accumulators for the alleles that are not the reference's
 struct NqPool {
     double S[9][NQ_SLOTS];      // [table * 3 + slot of the allele][pool slot]
@@ -230,22 +261,21 @@ constexpr uint32_t NQF_CLS = 0, NQF_RAL = 4, NQF_ZERO = 12, NQF_INDEL = 16, NQF_
 
 template <bool PHASE>
 __global__ void __launch_bounds__(NQ_WAVES * 64, HIMUT_NQ_OCC)
-k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, const NqItem* __restrict__ items,
-            const uint32_t* __restrict__ counts, int64_t tpc, int64_t tiles_per_class, NormDirty* dirty, uint32_t* dcount,
-            int64_t dirty_cap, int* dirty_over, NormRedo* redo, unsigned int* nredo, unsigned int redo_cap, unsigned int pool_limit) {
+k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, const uint16_t* __restrict__ refcode,
+            const NqItem* __restrict__ items, const uint32_t* __restrict__ counts, int64_t tpc, int64_t tiles_per_class,
+            NormDirty* dirty, uint32_t* dcount, int64_t dirty_cap, int* dirty_over, NormRedo* redo, unsigned int* nredo,
+            unsigned int redo_cap, unsigned int pool_limit) {
     __shared__ double s_lut[3 * 257];         // three tables of 256 qualities + a zero entry each (index 256)
-    __shared__ double s_prior[4];
     __shared__ unsigned int s_log[16];
-    __shared__ unsigned int s_ccs[32], s_ref[32];
+    __shared__ unsigned long long s_bins[32];  // per pyrimidine trinucleotide: callable bases | positions << 32
     __shared__ NqPool s_pool[NQ_WAVES];
     __shared__ int s_bad;                     // a base outside ATGC was seen (the reference raises KeyError)
     __shared__ unsigned int s_ndirty;         // positions this workgroup has left to k_norm_dirty
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     for (int i = tid; i < 3 * 256; i += NQ_WAVES * 64) s_lut[(i >> 8) * 257 + (i & 255)] = A.lut->t[i >> 8][i & 255];
     if (tid < 3) s_lut[tid * 257 + 256] = 0.0;
-    if (tid < 4) s_prior[tid] = A.lut->prior[tid];
     if (tid < 16) s_log[tid] = 0;
-    if (tid < 32) { s_ccs[tid] = 0; s_ref[tid] = 0; }
+    if (tid < 32) s_bins[tid] = 0;
     if (tid == 0) { s_bad = 0; s_ndirty = 0; }
     __syncthreads();
     const uint32_t lut = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)s_lut);
@@ -257,9 +287,11 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
     const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
     constexpr bool phase = PHASE;
     const Reads& R = A.R;
+    const int32_t md_thr = A.P.p.md_threshold, min_gq = A.P.p.min_gq, min_ref = A.P.p.min_ref_count, min_hap = A.P.p.min_hap_count;
     int bad = 0;
     const uint32_t o_q = 4u * (uint32_t)lane;                   // this lane's offset into a spanning piece's 256 qualities
     constexpr int NB = HIMUT_NQ_NB;
+    static_assert(NB == 4, "the switches below are written for four places");
     const int64_t per = tiles_per_class;
     for (int64_t t = blockIdx.x >> 3; t < per; t += (int64_t)(gridDim.x >> 3)) {         // the tile mapping of k_norm_tile
         const int64_t tile = ((int64_t)(blockIdx.x & 7) * per + t) * NQ_WAVES + wv;       // this wave's 256 positions
@@ -271,7 +303,7 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
         const NqItem* plan = items + (chunk * tpc + tile) * NQ_ITEMS;
         const int32_t base = (int32_t)base64;
         const int32_t P0 = base + 4 * lane;
-        // ---- the columns: which of the four exist, their reference letters
+        // ---- the columns: which of the four exist, and what k_ref_codes knows about their letters
         uint32_t valid4 = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -281,38 +313,21 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 else valid4 |= 1u << j;
             }
         }
-        // the letters at P0 - 1 .. P0 + 6 (0 outside the string): the columns' own and, for the trinucleotides, their neighbours'
-        uint64_t six = 0;
-        if (valid4) {
-            uint32_t lo = 0, hi = 0;
-            if (P0 >= 1 && (int64_t)P0 + 7 <= A.reflen) {
-                lo = nq_ld32((uint64_t)A.refseq, (uint32_t)(P0 - 1));
-                hi = nq_ld32((uint64_t)A.refseq, (uint32_t)(P0 + 3));
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int64_t p = (int64_t)P0 - 1 + k;
-                    const uint32_t c = (p >= 0 && p < A.reflen) ? (uint32_t)A.refseq[p] : 0u;
-                    if (k < 4) lo |= c << (8 * k); else hi |= c << (8 * (k - 4));
-                }
-            }
-            six = (uint64_t)lo | ((uint64_t)hi << 32);
-        }
+        uint64_t codes = 0;                                      // four 16-bit codes
+        if (valid4) __builtin_memcpy(&codes, refcode + P0, 8);   // (the array is padded behind the string with codes of 0)
         // packed per column j: ref4 the BAM code to match (bits 12 - 4j ..) and, sixteen bits up, a never-equal mark; fl the
         // flags: "an upper-case ATGC letter: the position is classified", the allele (two bits), a zero quality seen, an
         // insertion or deletion seen, and bit NQF_OVER: the pool ran out
         uint32_t ref4 = 0, fl = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int c = (int)((six >> (8 * (j + 1))) & 255u);
-            const int al = ((valid4 >> j) & 1u) ? char2allele(c) : -1;
+            const uint32_t c = ((valid4 >> j) & 1u) ? (uint32_t)(codes >> (16 * j)) & 0xffffu : 0u;
             // a column whose letter is not one of ATGC is never classified; its cells are matched against the upper-case
             // letter so that they stay on the common path (a base outside ATGC is still found: it equals no letter)
-            const int cu = c & 0xdf;
-            const uint32_t nib = cu == 'A' ? 1u : cu == 'C' ? 2u : cu == 'G' ? 4u : cu == 'T' ? 8u : 0u;
+            const uint32_t nib = (c & NQR_FOLD_OK) ? ((0x2481u >> (4 * (c & 3u))) & 15u) : 0u;     // A 1, T 8, G 4, C 2
             ref4 |= nib << (12 - 4 * j);
             if (nib == 0) ref4 |= 0x10000u << (12 - 4 * j);
-            if (al >= 0) fl |= (1u << (NQF_CLS + j)) | ((uint32_t)al << (NQF_RAL + 2 * j));
+            if (c & NQR_CLS) fl |= (1u << (NQF_CLS + j)) | ((c & 3u) << (NQF_RAL + 2 * j));
         }
         // ---- per-column state
         double R0[4], R1[4], R2[4];
@@ -330,16 +345,19 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
         if (lane == 0) pool.n = 0;
         __builtin_amdgcn_wave_barrier();
 
-        // rare: the cells of one item again, one by one -- a cell of another allele goes to the pool, a base outside ATGC and a
-        // zero quality are noted.  qk / nk: the item's qualities and BAM codes, ck: which of the four cells are there
+        // rare: the cells of one item that are not the reference allele's -- another allele goes to the pool, a base outside
+        // ATGC and a zero quality are noted.  qk / nk: the item's qualities and BAM codes, ck: which of the four cells are there
         auto rare_item = [&](uint32_t qk, uint32_t nk, uint32_t ck) {
-            const uint32_t x = (nk ^ ref4) | (ref4 >> 16);
-#pragma unroll 1
-            for (int j = 0; j < 4; j++) {
-                if (!((ck >> j) & 1u)) continue;
+            const uint32_t keep = (ck & 1u ? 0xf000u : 0u) | (ck & 2u ? 0x0f00u : 0u) | (ck & 4u ? 0x00f0u : 0u) | (ck & 8u ? 0x000fu : 0u);
+            // zero qualities among the cells, byte by byte (exact), to the columns' flags
+            const uint32_t zb = ~(((qk & 0x7f7f7f7fu) + 0x7f7f7f7fu) | qk) & 0x80808080u;
+            fl |= (cs_pack4(zb) & ck) << NQF_ZERO;
+            uint32_t x = ((nk ^ ref4) | (ref4 >> 16)) & keep;
+            while (x) {                                                     // (a lane has one such cell, seldom two)
+                const int hb = 31 - __builtin_clz(x);
+                const int j = 3 - (hb >> 2);
+                x &= ~(0xfu << (12 - 4 * j));
                 const uint32_t q = (qk >> (8 * j)) & 255u;
-                if (q == 0u) fl |= 1u << (NQF_ZERO + j);
-                if (!((x >> (12 - 4 * j)) & 15u)) continue;
                 const uint32_t cell = (uint32_t)nib2allele((int)((nk >> (12 - 4 * j)) & 15u));
                 if (cell > 3) { s_bad = 1 << HIMUT_ERR_BASE; continue; }
                 if (!((fl >> (NQF_CLS + j)) & 1u) || q == 0u) continue;       // (never classified / ends at the classification)
@@ -381,15 +399,28 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 is_item = false;
             }
             const uint32_t ifl = lf >> 16;
-            const bool full = is_item && (ifl & NQI_TYPE) == NQI_MATCH && tlo == base && (lf & 0xffffu) == (uint32_t)NQ_COLS;
+            bool full = is_item && (ifl & NQI_TYPE) == NQI_MATCH && tlo == base && (lf & 0xffffu) == (uint32_t)NQ_COLS;
+            // The spanning pieces' first bases as 32-bit distances from a base of the batch (K0: a multiple of 8 at or in front
+            // of the nearest of them): their loads then take three scalar bases, set up once per batch, and a per-lane offset.
+            // (A piece further than 2^31 from it, which 64 reads of a window do not give, goes the general way.)
+            uint64_t kmin = full ? (uint64_t)(kq + base) : ~0ull;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(kmin >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)kmin, d, 64);
+                kmin = min(kmin, o);
+            }
+            const uint64_t K0 = (uint64_t)uni((int64_t)((kmin == ~0ull ? 0ull : kmin) & ~7ull));      // (the same in every lane: scalar registers)
+            const uint64_t dk64 = (uint64_t)(kq + base) - K0;
+            if (full && dk64 >= (1ull << 31)) full = false;
+            const uint32_t dk = full ? (uint32_t)dk64 : 0u;
+            const uint64_t s_bq = (uint64_t)R.bq + K0, s_sq = (uint64_t)R.seq + (K0 >> 1), s_cb = (uint64_t)callable + (K0 >> 3);
             const uint64_t m_full = __ballot(full);
             // ---- the items in read order.  What an item adds comes as four cells per lane: qualities qv (byte j = column j),
             //      BAM codes n4 (column j in bits 12 - 4j ..), callable bits cb.  The nine items in ten that span the tile go
-            //      NB at a time, their loads issued together: a scalar base plus a fixed offset per lane
+            //      up to NB at a time, their loads issued together
             uint64_t m = __ballot(is_item);
             // the loads of the NEXT item that covers a part of the positions are kept in flight while the spanning items in front
-            // of it are worked on (a memory round trip of its own for each was a seventh of the kernel): pl = its lane of the
-            // item vector, or -1
+            // of it are worked on: pl = its lane of the item vector, or -1
             const uint64_t m_pm = __ballot(is_item && !full && (ifl & NQI_TYPE) == NQI_MATCH);
             uint32_t pq = 0, pn = 0, pc = 0;
             int pl = -1;
@@ -411,35 +442,32 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 const uint64_t ms = m & ~m_full;
                 const uint64_t front = ms ? (m & ((ms & (0 - ms)) - 1)) : m;
                 if (front) {
-                    // up to NB of them: cnt items sit in the LAST cnt of the NB places, and both the loads and the updates are
-                    // entered at the place of the first (a switch that falls through): every update stands in the text once
-                    // and runs unconditionally from its entry on
+                    // cnt items sit in the LAST cnt of the NB places (a place in front of them asks for the first item's words
+                    // once more, so that the loads stand in the text unconditionally); the updates are entered at the place of
+                    // the first item: every one stands in the text once and runs unconditionally from its entry on
                     const int cnt = min(NB, (int)__builtin_popcountll(front));
-                    uint32_t qv[NB], n4[NB], cb[NB], shs[NB], shb[NB], ifk[NB];
-#define NQ_LOAD(k) { \
-                        const int l = (int)__builtin_ctzll(m); \
-                        m &= m - 1; \
-                        const uint64_t Kr = nq_lane64(kq, l) + (uint64_t)(int64_t)base; \
-                        ifk[k] = (uint32_t)lane_val((int)ifl, l); \
-                        shs[k] = (Kr & 1u) ? 12u : 16u; \
-                        shb[k] = (uint32_t)(Kr & 7u); \
-                        qv[k] = nq_ld32((uint64_t)R.bq + Kr, o_q); \
-                        n4[k] = nq_ld32((uint64_t)R.seq + (Kr >> 1), o_q >> 1); \
-                        cb[k] = nq_ld16((uint64_t)callable + (Kr >> 3), o_q >> 3); }
+                    uint32_t qv[NB], n4[NB], cb[NB], dd[NB], ifk[NB];
+                    {
+                        const int first = (int)__builtin_ctzll(m);
 #pragma unroll
-                    for (int k = 0; k < NB; k++) { qv[k] = 0x01010101u; n4[k] = 0; cb[k] = 0; shs[k] = 16; shb[k] = 0; ifk[k] = 0; }
-                    static_assert(NB == 4, "the switches below are written for four places");
-                    switch (cnt) {
-                        case 4: NQ_LOAD(0) [[fallthrough]];
-                        case 3: NQ_LOAD(1) [[fallthrough]];
-                        case 2: NQ_LOAD(2) [[fallthrough]];
-                        default: NQ_LOAD(3)
+                        for (int k = 0; k < NB; k++) {
+                            int l = first;
+                            if (k >= NB - cnt) { l = (int)__builtin_ctzll(m); m &= m - 1; }
+                            dd[k] = (uint32_t)lane_val((int)dk, l);
+                            ifk[k] = (uint32_t)lane_val((int)ifl, l);
+                            // (a scalar base and a 32-bit offset per lane; the offset is made opaque here so that its widening to
+                            //  64 bits is not hoisted out of the loop, where the load would lose the form)
+                            uint32_t tq = dd[k] + o_q;
+                            asm volatile("" : "+v"(tq));
+                            qv[k] = nq_ld32(s_bq, tq);
+                            n4[k] = nq_ld32(s_sq, tq >> 1);
+                            cb[k] = nq_ld16(s_cb, tq >> 3);
+                        }
                     }
-#undef NQ_LOAD
                     uint32_t rare = 0;
 #define NQ_UPDATE(k) { \
-                        n4[k] = (__builtin_bswap32(n4[k]) >> shs[k]) & 0xffffu; \
-                        uint32_t cbk = (cb[k] >> (shb[k] + (o_q & 4u))) & 15u; \
+                        n4[k] = (__builtin_bswap32(n4[k]) >> ((dd[k] & 1u) ? 12u : 16u)) & 0xffffu; \
+                        uint32_t cbk = (cb[k] >> ((dd[k] + o_q) & 7u)) & 15u;          /* (the sixteen bits begin at a byte) */ \
                         if (ifk[k] & NQI_INS) fl |= (lane == 0 ? 1u : 0u) << NQF_INDEL;     /* an insertion in front of the piece: counted at its first position */ \
                         if (phase) { \
                             const uint32_t hap = (ifk[k] >> NQI_HAP_SHIFT) & 3u; \
@@ -447,11 +475,11 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                             else if (hap == HAP_1) h1b += 0x01010101u; \
                             else cbk = 0;                                        /* the read carries no haplotype in this chunk: no bit of it counts */ \
                         } \
-                        const uint32_t x = (n4[k] ^ ref4) | (ref4 >> 16);           /* a nibble of zeros: the reference allele */ \
+                        const uint32_t x = (n4[k] ^ ref4) | (ref4 >> 16);          /* a nibble of zeros: the reference allele */ \
                         tri4b += nq_spread4(cbk); \
                         nq_pair<0>(R0[0], R1[0], R2[0], nref[0], R0[1], R1[1], R2[1], nref[1], qv[k], x, lut); \
                         nq_pair<2>(R0[2], R1[2], R2[2], nref[2], R0[3], R1[3], R2[3], nref[3], qv[k], x, lut); \
-                        if ((x & 0xffffu) | nq_zero_bytes(qv[k])) rare |= 1u << k; }
+                        if ((x & 0xffffu) | nq_zero_bytes(qv[k])) rare |= 1u << (k); }
                     switch (cnt) {
                         case 4: NQ_UPDATE(0) [[fallthrough]];
                         case 3: NQ_UPDATE(1) [[fallthrough]];
@@ -526,20 +554,20 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
             }
             continue;
         }
-        // ---- the positions' classes (normcounts.py:317-402), in the order of the general text (NORM_CLASSIFY), the lane's four
-        //      columns one after the other through one text (the state is rotated).  The counters nearly every position adds
-        //      to are summed over the lane's columns and the wave first
+        // ---- the positions' classes (normcounts.py:317-402), in the order of the general text (NORM_CLASSIFY); straight-line
+        //      for the lane's four columns, what is rare behind a test of the whole wave.  The counters nearly every position
+        //      adds to are summed over the lane's columns and the wave first
         uint32_t w1 = 0, w2 = 0, w6 = 0, w13 = 0;
 #pragma unroll 1
         for (int j = 0; j < 4; j++) {
-            const int64_t rpos = (int64_t)P0 + j;
+            const uint32_t code = (uint32_t)codes & 0xffffu;
             const uint32_t tri_sum = tri[0];
             const bool cls = ((fl >> NQF_CLS) & 1u) && tri_sum != 0;
             uint32_t h0 = 0, h1 = 0;
             if (phase) { h0 = h0g[0]; h1 = h1g[0]; }
-            const bool hapfail = phase && cls && !((int64_t)h0 >= A.P.p.min_hap_count && (int64_t)h1 >= A.P.p.min_hap_count);
+            const bool hapfail = phase && cls && !((int32_t)h0 >= min_hap && (int32_t)h1 >= min_hap);
             const bool q0 = cls && !hapfail && ((fl >> NQF_ZERO) & 1u);
-            if (q0) bad |= 1 << HIMUT_ERR_BQ0;
+            bad |= q0 ? (1 << HIMUT_ERR_BQ0) : 0;
             const bool open = cls && !hapfail && !q0;
             const uint32_t slot = slotmap & 255u;
             // Nothing but the reference allele in the column: the ten genotype sums are four numbers (an allele that was not
@@ -547,25 +575,40 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
             // is the genotype and the quality is the gap to the smallest of the rest; any other outcome, and any column
             // with another allele, goes to k_norm_dirty.
             const double pa = -10.0 * (R0[0] + pr0), pb = -10.0 * (R1[0] + pr1);
-            const double pc = -10.0 * (R2[0] + pr2), pd = -10.0 * (R2[0] + pr3);
-            const double nxt = fmin(pb, fmin(pc, pd));
+            const double pc_ = -10.0 * (R2[0] + pr2), pd = -10.0 * (R2[0] + pr3);
+            const double nxt = fmin(pb, fmin(pc_, pd));
             const bool mine = open && slot == 255u && pa < nxt;
             const double gqf = nxt - pa;
             const int gq = (gqf < 99.0) ? (int)gqf : 99;
             const bool indel = (fl >> NQF_INDEL) & 1u;
-            int slotn = 13;
-            if (indel) slotn = 7;
-            else if ((int64_t)nref[0] > A.P.p.md_threshold) slotn = 8;
-            else if (gq < A.P.p.min_gq) slotn = 10;
-            else if ((int64_t)nref[0] < A.P.p.min_ref_count) slotn = 9;
+            // (depths beyond 2^31 do not occur; the thresholds are 32-bit)
+            const int slotn = indel ? 7 : (int32_t)nref[0] > md_thr ? 8 : gq < min_gq ? 10 : (int32_t)nref[0] < min_ref ? 9 : 13;
             w1 += (mine || hapfail) ? tri_sum : 0u;
             w2 += hapfail ? tri_sum : 0u;
             w6 += mine ? tri_sum : 0u;
-            w13 += (mine && slotn == 13) ? tri_sum : 0u;
-            if (mine && slotn != 13) atomicAdd(&s_log[slotn], tri_sum);
-            if (mine && slotn == 13) {
-                const int refc = (int)((six >> 8) & 255u);
-                NORM_TRIBINS((int)(six & 255u), (int)((six >> 16) & 255u))
+            const bool call = mine && slotn == 13;
+            w13 += call ? tri_sum : 0u;
+            if (__ballot(mine && !call)) { if (mine && !call) atomicAdd(&s_log[slotn], tri_sum); }
+            // the trinucleotide bins of a callable position (row 13 of norm.log): the bin is k_ref_codes', one LDS word for
+            // both of its counters; a context with a letter outside upper-case ACGT takes NORM_TRIBINS' general way
+            if (call && (code & NQR_BIN_OK)) atomicAdd(&s_bins[(code >> NQR_BIN_SHIFT) & 31u], (unsigned long long)tri_sum | (1ull << 32));
+            if (__ballot(call && !(code & NQR_BIN_OK))) {
+                if (call && !(code & NQR_BIN_OK)) {
+                    const int64_t rpos = (int64_t)P0 + j;
+                    int t0 = 'N', t1 = 'N', t2 = 'N';
+                    if (rpos - 1 >= 0 && rpos + 2 <= A.reflen) {
+                        t0 = (int)A.refseq[rpos - 1]; t1 = (int)A.refseq[rpos]; t2 = (int)A.refseq[rpos + 1];
+                        if (t1 == 'A' || t1 == 'G') {
+                            const int a0 = t2, a2 = t0;
+                            t0 = a0 == 'A' ? 'T' : a0 == 'T' ? 'A' : a0 == 'G' ? 'C' : a0 == 'C' ? 'G' : 'N';
+                            t1 = t1 == 'A' ? 'T' : 'C';
+                            t2 = a2 == 'A' ? 'T' : a2 == 'T' ? 'A' : a2 == 'G' ? 'C' : a2 == 'C' ? 'G' : 'N';
+                        }
+                    }
+                    const int64_t k = ((int64_t)A.cls[t0] * A.K + A.cls[t1]) * A.K + A.cls[t2];
+                    atomicAdd(&A.ccs_tri[k], (unsigned long long)tri_sum);
+                    atomicAdd(&A.ref_tri[k], 1ULL);
+                }
             }
             // a position left to k_norm_dirty: the next places in this workgroup's part of the list (one LDS atomic per wave)
             const bool left = open && !mine;
@@ -577,7 +620,7 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 if (left) {
                     if ((int64_t)at < dirty_cap) {
                         NormDirty* d = dirty + (dregion * dirty_cap + at);
-                        d->rpos = rpos; d->nref = nref[0]; d->tri_sum = tri_sum; d->n_ins = indel ? 1u : 0u; d->n_del = 0; d->h0 = h0; d->h1 = h1;
+                        d->rpos = (int64_t)P0 + j; d->nref = nref[0]; d->tri_sum = tri_sum; d->n_ins = indel ? 1u : 0u; d->n_del = 0; d->h0 = h0; d->h1 = h1;
                         d->R[0] = R0[0]; d->R[1] = R1[0]; d->R[2] = R2[0];
                         if (slot != 255u) {
 #pragma unroll
@@ -599,7 +642,7 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
             nref[0] = nref[1]; nref[1] = nref[2]; nref[2] = nref[3]; tri[0] = tri[1]; tri[1] = tri[2]; tri[2] = tri[3];
             if (phase) { h0g[0] = h0g[1]; h0g[1] = h0g[2]; h0g[2] = h0g[3]; h1g[0] = h1g[1]; h1g[1] = h1g[2]; h1g[2] = h1g[3]; }
             fl = (fl >> 1) & 0x77007u;                       // (the one-bit fields move down; the alleles are not looked at here)
-            slotmap >>= 8; six >>= 8;
+            slotmap >>= 8; codes >>= 16;
         }
         {
             const uint32_t s1 = (uint32_t)lane_val(wave_incl_add((int)w1, lane), 63);
@@ -619,11 +662,11 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
     __syncthreads();
     if (tid == 0) dcount[dregion] = min(s_ndirty, (unsigned int)min(dirty_cap, (int64_t)0x7fffffff));
     if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
-    if (tid < 32 && (s_ccs[tid] || s_ref[tid])) {
+    if (tid < 32 && s_bins[tid]) {
         const int cl[4] = {A.cA, A.cC, A.cG, A.cT};
         const int64_t k = ((int64_t)cl[tid >> 3] * A.K + ((tid & 4) ? A.cT : A.cC)) * A.K + cl[tid & 3];
-        atomicAdd(&A.ccs_tri[k], (unsigned long long)s_ccs[tid]);
-        atomicAdd(&A.ref_tri[k], (unsigned long long)s_ref[tid]);
+        atomicAdd(&A.ccs_tri[k], s_bins[tid] & 0xffffffffull);
+        atomicAdd(&A.ref_tri[k], s_bins[tid] >> 32);
     }
     if (tid == 0 && s_bad) bad |= s_bad;
     if (bad) atomicOr(A.err, bad);
