@@ -1370,6 +1370,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
                                     nblk, tpc, c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), c->d_redo.as<NormRedo>(),
                                     &sc->nredo, redo_cap);
             const dim3 grid(q_gx, (unsigned)T.n);
+            stage_event(c, EV_INDEX, 1, st);                                            // (around k_norm_quad: stats.ms_capture)
             const unsigned pool_limit = c->dbg_norm_pool > 0 ? (unsigned)std::min(c->dbg_norm_pool, NQ_SLOTS) : (unsigned)NQ_SLOTS;
             if (phase) hipLaunchKernelGGL(k_norm_quad<true>, grid, dim3(NQ_WAVES * 64), 0, st, A, c->d_callable.as<uint32_t>(), (int64_t)c->bq_bytes,
                                           c->d_refcode.as<uint16_t>(), c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), tpc, q_per, c->d_dirty.as<NormDirty>(),
@@ -1379,6 +1380,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
                                     c->d_refcode.as<uint16_t>(), c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), tpc, q_per, c->d_dirty.as<NormDirty>(),
                                     c->d_dcount.as<uint32_t>(), dirty_cap, &sc->dirty_over, c->d_redo.as<NormRedo>(),
                                     &sc->nredo, redo_cap, pool_limit);
+            stage_event(c, EV_GATHER, 1, st);
             hipLaunchKernelGGL(k_norm_dirty, dim3((unsigned)std::min<int64_t>(blocks_for(q_regions, 4), 16384)), dim3(256), 0, st, A,
                                c->d_dirty.as<NormDirty>(), c->d_dcount.as<uint32_t>(), dirty_cap, q_regions);
             // (returns at once unless a tile was listed)
@@ -1414,7 +1416,11 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
         c->stats.ms_index = (double)f;      // the read pass: filters, callable bits, window index
     }
     (void)hipEventElapsedTime(&f, c->ev[EV_EMIT], c->ev[EV_FINAL]);
-    c->stats.ms_eval = (double)f;           // the position sweep
+    c->stats.ms_eval = (double)f;           // the position sweep: plan, k_norm_quad, k_norm_dirty, listed tiles
+    if (c->timing >= 1 && sweep_quad && c->n > 0 && T.n > 0) {
+        (void)hipEventElapsedTime(&f, c->ev[EV_INDEX], c->ev[EV_GATHER]);
+        c->stats.ms_capture = (double)f;    // k_norm_quad by itself, the pass's dominant kernel
+    }
     c->stats.n_reads = c->n; c->stats.read_bases = c->read_bases; c->stats.positions = T.positions;
     c->stats.column_slots = hs.nredo;        // (normcounts: tiles k_norm_quad left to k_norm_tile)
     c->have_norm = true;

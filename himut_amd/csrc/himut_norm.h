@@ -101,6 +101,228 @@ constexpr int CAL_NM = 256;     // mismatch entries kept in LDS per wave
 constexpr int CAL_BM = 64;      // dwords of the bitmap of words to redo: reads of up to 65,536 bases (a longer one: every word exact)
 constexpr int CAL_LIST = 128;   // words gathered before a round of pass B
 
+// A read's segment and mismatch lists, in LDS when they fit there (nearly always) or in memory: two types with
+// address-space-qualified pointers, chosen once per wave.  (A choice per access -- `k < CAL_NM ? lds[k] : mem[k]` through
+// generic pointers -- is compiled into a select between the two POINTERS and a flat load; the chain of those in the
+// binary searches made pass B more than half of this kernel's time.)
+typedef int cal_v4i __attribute__((ext_vector_type(4)));
+struct CalListsLds {
+    const __attribute__((address_space(3))) int32_t* mis;
+    const __attribute__((address_space(3))) uint32_t* mq;
+    const __attribute__((address_space(3))) cal_v4i* seg;
+    __device__ __forceinline__ int32_t MIS(int k) const { return mis[k]; }
+    __device__ __forceinline__ uint32_t MQ(int k) const { return mq[k]; }
+    __device__ __forceinline__ int4 SEG(int j) const { const cal_v4i v = seg[j]; return make_int4(v.x, v.y, v.z, v.w); }
+};
+struct CalListsMem {
+    const __attribute__((address_space(1))) int32_t* mis;
+    const __attribute__((address_space(1))) uint32_t* mq;
+    const __attribute__((address_space(1))) cal_v4i* seg;
+    __device__ __forceinline__ int32_t MIS(int k) const { return mis[k]; }
+    __device__ __forceinline__ uint32_t MQ(int k) const { return mq[k]; }
+    __device__ __forceinline__ int4 SEG(int j) const { const cal_v4i v = seg[j]; return make_int4(v.x, v.y, v.z, v.w); }
+};
+
+// What the tests of one read need (wave-uniform).
+struct CalRead {
+    const __attribute__((address_space(1))) uint8_t* bq;      // the read's qualities
+    __attribute__((address_space(1))) uint32_t* words;        // the read's words of the bit array
+    const __attribute__((address_space(1))) uint32_t* nq_top; // N-reference substitutions: query offsets at nq_top[-k] >> 5, ascending
+    int32_t qlen, qstart, ns, nm, nN;
+    int32_t w, maxmm, min_bq, min_bq_c, trim_lo, trim_hi;
+
+    __device__ __forceinline__ int32_t NQ(int k) const { return (int32_t)(nq_top[-k] >> 5); }
+
+    // the quality and trim tests of the 32 bases from qa on, given their qualities (bytes behind the read are masked by the trim)
+    __device__ __forceinline__ uint32_t quality_trim(const uint32_t (&bw)[8], int32_t qa) const {
+        uint32_t okq = 0;    // four bytes at a time: the low seven bits compared, bit 7 by itself
+        const uint32_t hb = (bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) & 0x80808080u;   // a quality of 128 or more among them
+        if (min_bq <= 127 && !hb) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) okq |= cs_pack4(cs_ge_bytes(bw[k], (uint32_t)min_bq_c)) << (4 * k);
+        } else if (min_bq <= 127) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                okq |= cs_pack4(cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)min_bq_c) | (bw[k] & 0x80808080u)) << (4 * k);
+        } else if (min_bq <= 255) {                           // (a threshold above 127: only a quality of 128 or more can pass)
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                okq |= cs_pack4((min_bq > 128 ? cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)(min_bq - 128)) : 0x80808080u) &
+                                (bw[k] & 0x80808080u)) << (4 * k);
+        }
+        if (min_bq <= 0) okq = ~0u;
+        // not trimmed: trim_lo <= q <= trim_hi (the two bounds are whole numbers), and q < qlen
+        const int32_t lo_q = max(trim_lo, 0), hi_q = min(trim_hi, qlen - 1);
+        const int32_t a0 = max(lo_q - qa, 0), a1 = min(hi_q - qa, 31);
+        return okq & ((a0 <= a1) ? ((a1 - a0 >= 31 ? ~0u : ((1u << (a1 - a0 + 1)) - 1u)) << a0) : 0u);
+    }
+
+    // Which words lie within two windows of a mismatch entry: around every segment boundary (an indel: from the last base in
+    // front of it to the first base behind it) and every substitution, in query coordinates.  (A base and an entry that are
+    // D reference positions apart with no indel between them are D query bases apart; with indels between them the nearest
+    // of those is an entry itself and no further from the base.)  2 w + 2 either way: a base's window reaches w reference
+    // positions to each side, up to 2 w to one side where its match operation starts near an end of the read, one more for
+    // the 0-based positions against the 1-based list.
+    template <class L>
+    __device__ __forceinline__ void mark_words(const L& ls, uint32_t* bm, int lane) const {
+        const int32_t reach = 2 * w + 2;
+        auto mark = [&](int32_t qlo, int32_t qhi) {
+            qlo = max(qlo, 0); qhi = min(qhi, qlen - 1);
+            for (int32_t wd = qlo >> 5; wd <= (qhi >> 5); wd++) atomicOr(&bm[wd >> 5], 1u << (wd & 31));
+        };
+        for (int j = lane - 1; j + 1 < ns; j += 64) {             // boundary between segment j and j + 1 (j = -1: in front of the first)
+            const int4 sb = ls.SEG(j + 1);
+            if (j < 0) { if ((uint32_t)sb.w & SEG_INS) mark(qstart - reach, sb.y + reach); continue; }
+            const int4 sa = ls.SEG(j);
+            const int32_t qa_end = sa.y + ((((uint32_t)sa.w & SEG_DEL) || sa.z <= 0) ? 0 : sa.z);
+            mark(qa_end - 1 - reach, sb.y + reach);
+        }
+        for (int k = lane; k < nm; k += 64) { const uint32_t v = ls.MQ(k); if (v & 16u) { const int32_t q = (int32_t)(v >> 5); mark(q - reach, q + reach); } }
+        for (int k = lane; k < nN; k += 64) { const int32_t q = NQ(k); mark(q - reach, q + reach); }
+    }
+
+    // Pass B: the word whose first base is qa, the exact way.
+    template <class L>
+    __device__ __forceinline__ void exact_word(const L& ls, int32_t qa) const {
+        auto lower = [&](int32_t x) { int lo = 0, hi = nm; while (lo < hi) { const int m = (lo + hi) >> 1; if (ls.MIS(m) < x) lo = m + 1; else hi = m; } return lo; };
+        auto upper = [&](int32_t x) { int lo = 0, hi = nm; while (lo < hi) { const int m = (lo + hi) >> 1; if (x < ls.MIS(m)) hi = m; else lo = m + 1; } return lo; };
+        uint32_t bw[8];
+        {
+            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+            const v4u b0 = *reinterpret_cast<const __attribute__((address_space(1))) v4u*>(bq + qa);
+            const v4u b1 = *reinterpret_cast<const __attribute__((address_space(1))) v4u*>(bq + qa + 16);
+            bw[0] = b0.x; bw[1] = b0.y; bw[2] = b0.z; bw[3] = b0.w; bw[4] = b1.x; bw[5] = b1.y; bw[6] = b1.z; bw[7] = b1.w;
+        }
+        const uint32_t okq = quality_trim(bw, qa);
+        uint32_t word = 0;
+        // the first segment that reaches behind qa (segments are in query order)
+        int jc = 0;
+        {
+            int lo = 0, hi = ns;
+            while (lo < hi) {
+                const int m = (lo + hi) >> 1;
+                const int4 sg = ls.SEG(m);
+                const int32_t qspan = (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) ? 0 : sg.z;
+                if (sg.y + qspan <= qa) lo = m + 1; else hi = m;
+            }
+            jc = lo;
+        }
+        for (int j = jc; j < ns; j++) {
+            const int4 sg = ls.SEG(j);
+            if (sg.y >= qa + 32) break;
+            if (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) continue;
+            const int32_t a = max(sg.y, qa), b = min(sg.y + sg.z, qa + 32);     // query overlap
+            if (a >= b) continue;
+            const int32_t tlo = sg.x + (a - sg.y), thi = sg.x + (b - 1 - sg.y);  // 0-based reference positions
+            uint32_t nsub_bits = 0;      // N-reference substitutions among these bases; the last one in front of them
+            int32_t nsub_prev = -1;
+            for (int k = 0; k < nN; k++) {
+                const int32_t q = NQ(k);
+                if (q >= a && q < b) nsub_bits |= 1u << (q - qa);
+                else if (q >= sg.y && q < a) nsub_prev = q;
+            }
+            // any list entry that could fall into a window of these bases?
+            const int k0 = lower(tlo - 2 * w - 1);
+            if (k0 >= nm || ls.MIS(k0) > thi + 2 * w + 1) {
+                word |= (okq & (((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa))) | nsub_bits;
+                continue;
+            }
+            // the few entries near these bases, in registers (value, query offset | substitution flag); a lane with more
+            // than NE nearby takes the exact loop over its bases below
+            constexpr int NE = 4;
+            int32_t ev[NE];
+            uint32_t eq[NE];
+            int ne = 0;
+#pragma unroll
+            for (int i = 0; i < NE; i++) {
+                ev[i] = 0x7fffffff; eq[i] = 0;
+                if (k0 + i < nm) { const int32_t m = ls.MIS(k0 + i); if (m <= thi + 2 * w + 1) { ev[i] = m; eq[i] = ls.MQ(k0 + i); ne = i + 1; } }
+            }
+            const bool overflow = k0 + NE < nm && ls.MIS(k0 + NE) <= thi + 2 * w + 1;   // more than NE entries nearby
+            // start of the match operation the first base belongs to: behind the previous substitution of this
+            // segment, else the segment start
+            int32_t osq = sg.y;
+            {
+                const int kp = lower(tlo + 1) - 1;
+                if (kp >= 0) {
+                    const uint32_t pv = ls.MQ(kp);
+                    const int32_t pq = (int32_t)(pv >> 5);
+                    if ((pv & 16u) && pq >= sg.y && pq < a) osq = pq + 1;
+                }
+                if (nsub_prev >= 0) osq = max(osq, nsub_prev + 1);
+            }
+            // "How many entries see this base" as a sum of bit ranges: bit-sliced counters instead of a loop over the
+            // bases.  A match operation that starts at least w bases from either end of the read has the window (w, w)
+            // (bamlib.py:245-258) -- every operation that starts among these 32 bases, given where the word lies; the one
+            // that started in front of them (osq) may begin within w of the read's start and has (osq, 2 w - osq) then: it
+            // holds the bases up to the first substitution among them.
+            // (Where none of the bases passes its quality and trim tests -- the trimmed ends of the read -- the counts decide
+            // nothing and the same code gives the substitutions' bits.)
+            const uint32_t span = ((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa);
+            if (!overflow && ((qa >= w && (int64_t)qa + 32 + w <= (int64_t)qlen) || !(okq & span))) {
+                const int32_t shift = sg.y - sg.x - qa;           // bit of reference position t = t + shift
+                const int32_t ur0 = min(osq, w), dr0 = 2 * w - ur0;
+                uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, sub = 0;
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    const int32_t sq = (int32_t)(eq[i] >> 5);
+                    if (i < ne && (eq[i] & 16u) && sq >= a && sq < b && ev[i] == sg.x + (sq - sg.y) + 1) sub |= 1u << (sq - qa);
+                }
+                const uint32_t starts = sub | nsub_bits;          // behind each of these a new operation begins
+                const uint32_t old_op = (ur0 == w) ? 0u : starts ? ((1u << __builtin_ctz(starts)) - 1u) : ~0u;
+                auto bits_of = [](int lo, int hi) -> uint32_t {
+                    lo = max(lo, 0); hi = min(hi, 31);
+                    return lo <= hi ? ((hi - lo) >= 31 ? ~0u : ((1u << (hi - lo + 1)) - 1u)) << lo : 0u;
+                };
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    if (i >= ne) continue;
+                    uint32_t rr = bits_of(ev[i] - w + shift, ev[i] + w + shift);         // base t sees entry e: e - dr <= t <= e + ur
+                    if (old_op) rr = (rr & ~old_op) | (bits_of(ev[i] - dr0 + shift, ev[i] + ur0 + shift) & old_op);
+                    const uint32_t k0_ = c0 & rr; c0 ^= rr;
+                    const uint32_t k1_ = c1 & k0_; c1 ^= k0_;
+                    const uint32_t k2_ = c2 & k1_; c2 ^= k1_;
+                    c3 ^= k2_;
+                }
+                uint32_t gt = 0;                                   // bases seen by more than maxmm entries
+                if (maxmm < 8) {
+                    uint32_t same = ~0u;
+                    const uint32_t planes[4] = {c0, c1, c2, c3};
+#pragma unroll
+                    for (int pbit = 3; pbit >= 0; pbit--) {
+                        const uint32_t kb = ((maxmm >> pbit) & 1) ? ~0u : 0u;
+                        gt |= same & planes[pbit] & ~kb;
+                        same &= ~(planes[pbit] ^ kb);
+                    }
+                }
+                word |= (span & ((okq & ~gt) | sub)) | nsub_bits;
+                continue;
+            }
+            for (int32_t q = a; q < b; q++) {
+                const int32_t t = sg.x + (q - sg.y);
+                const int bit = q - qa;
+                bool is_sub = false;
+#pragma unroll
+                for (int i = 0; i < NE; i++) if (ev[i] == t + 1 && (eq[i] & 16u) && (int32_t)(eq[i] >> 5) == q) is_sub = true;
+                if (overflow && !is_sub)
+                    for (int kk = lower(t + 1); kk < nm && ls.MIS(kk) == t + 1; kk++) { const uint32_t v = ls.MQ(kk); if ((v & 16u) && (int32_t)(v >> 5) == q) is_sub = true; }
+                if (is_sub || ((nsub_bits >> bit) & 1u)) { word |= 1u << bit; osq = q + 1; continue; }
+                int64_t qs = (int64_t)osq - w, qe = (int64_t)osq + w, ur, dr;      // bamlib.py:245-258
+                if (qs < 0) { ur = w + qs; dr = w - qs; }
+                else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - osq; }
+                else { ur = w; dr = w; }
+                int cnt = 0;
+                if (!overflow) {
+#pragma unroll
+                    for (int i = 0; i < NE; i++) cnt += (ev[i] >= t - ur && ev[i] <= t + dr) ? 1 : 0;
+                } else cnt = upper((int32_t)(t + dr)) - lower((int32_t)(t - ur));
+                if (cnt <= maxmm && ((okq >> bit) & 1u)) word |= 1u << bit;
+            }
+        }
+        words[qa >> 5] = word;
+    }
+};
+
 __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, uint8_t* live, uint32_t* cbits, uint8_t* ccs_flag) {
     __shared__ int32_t s_mis[4][CAL_NM];
     __shared__ uint32_t s_mq[4][CAL_NM];
@@ -123,81 +345,39 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
     const Seg* gsegs = D.segs + segbase;
     const int32_t* gmis = D.mis + segbase;
     const uint32_t* gmq = D.mq + segbase;
-    int32_t* lmis = s_mis[wv];
-    uint32_t* lmq = s_mq[wv];
-    int4* lseg = s_seg[wv];
     uint32_t* bm = s_bm[wv];
     uint16_t* list = s_list[wv];
-    for (int k = lane; k < min(nm, CAL_NM); k += 64) { lmis[k] = gmis[k]; lmq[k] = gmq[k]; }
-    if (lane < min(ns, 64)) lseg[lane] = *reinterpret_cast<const int4*>(gsegs + lane);
+    const bool in_lds = nm <= CAL_NM && ns <= 64;              // (the wave's choice, made once)
+    if (in_lds) {
+        for (int k = lane; k < nm; k += 64) { s_mis[wv][k] = gmis[k]; s_mq[wv][k] = gmq[k]; }
+        if (lane < ns) s_seg[wv][lane] = *reinterpret_cast<const int4*>(gsegs + lane);
+    }
     bm[lane] = 0;
     __builtin_amdgcn_wave_barrier();
+    CalListsLds ll;
+    ll.mis = (const __attribute__((address_space(3))) int32_t*)s_mis[wv];
+    ll.mq = (const __attribute__((address_space(3))) uint32_t*)s_mq[wv];
+    ll.seg = (const __attribute__((address_space(3))) cal_v4i*)s_seg[wv];
+    CalListsMem lm;
+    lm.mis = (const __attribute__((address_space(1))) int32_t*)gmis;
+    lm.mq = (const __attribute__((address_space(1))) uint32_t*)gmq;
+    lm.seg = (const __attribute__((address_space(1))) cal_v4i*)gsegs;
+    CalRead cr;
+    cr.bq = (const __attribute__((address_space(1))) uint8_t*)(R.bq + qo);
+    cr.words = (__attribute__((address_space(1))) uint32_t*)(cbits + (qo >> 5));
     // substitutions with an N reference base (rare): not in the mismatch list, their bases always count, and each one
     // starts a new match operation behind it (normcounts.py:75-110 walks the cs operations).  Query offsets, ascending.
-    const int nN = uni(D.nnsub[r]);
-    const int64_t top = (uni(R.cs_off[r + 1]) >> 1) - (uni(R.cs_off[r]) >> 1);
-    auto NQ = [&](int k) -> int32_t { return (int32_t)(gmq[top - k] >> 5); };
-    auto MIS = [&](int k) -> int32_t { return k < CAL_NM ? lmis[k] : gmis[k]; };
-    auto MQ = [&](int k) -> uint32_t { return k < CAL_NM ? lmq[k] : gmq[k]; };
-    auto SEG = [&](int j) -> int4 { return j < 64 ? lseg[j] : *reinterpret_cast<const int4*>(gsegs + j); };
-    auto lower = [&](int32_t x) { int lo = 0, hi = nm; while (lo < hi) { const int m = (lo + hi) >> 1; if (MIS(m) < x) lo = m + 1; else hi = m; } return lo; };
-    auto upper = [&](int32_t x) { int lo = 0, hi = nm; while (lo < hi) { const int m = (lo + hi) >> 1; if (x < MIS(m)) hi = m; else lo = m + 1; } return lo; };
-    const int32_t w = P.p.mismatch_window_size;
-    const double trim_start = floor(P.p.min_trim * (double)qlen);
-    const double trim_end = ceil((1.0 - P.p.min_trim) * (double)qlen);
-    const int min_bq = P.p.min_bq;
-    const int min_bq_c = min(max(min_bq, 1), 127);
-    const int32_t trim_lo = (int32_t)trim_start, trim_hi = (int32_t)trim_end;
-    const int maxmm = P.p.max_mismatch_count;
+    cr.nN = uni(D.nnsub[r]);
+    cr.nq_top = (const __attribute__((address_space(1))) uint32_t*)(gmq + ((uni(R.cs_off[r + 1]) >> 1) - (uni(R.cs_off[r]) >> 1)));
+    cr.qlen = qlen; cr.qstart = uni(R.qstart[r]); cr.ns = ns; cr.nm = nm;
+    cr.w = P.p.mismatch_window_size; cr.maxmm = P.p.max_mismatch_count;
+    cr.min_bq = P.p.min_bq; cr.min_bq_c = min(max(cr.min_bq, 1), 127);
+    cr.trim_lo = (int32_t)floor(P.p.min_trim * (double)qlen);
+    cr.trim_hi = (int32_t)ceil((1.0 - P.p.min_trim) * (double)qlen);
     const int32_t nwords = (qlen + 31) >> 5;
     const bool big = nwords > CAL_BM * 32;                      // a read the bitmap does not hold: every word the exact way
 
-    // the quality and trim tests of the 32 bases from qa on, given their qualities (bytes behind the read are masked by the trim)
-    auto quality_trim = [&](const uint32_t (&bw)[8], int32_t qa) -> uint32_t {
-        uint32_t okq = 0;    // four bytes at a time: the low seven bits compared, bit 7 by itself
-        const uint32_t hb = (bw[0] | bw[1] | bw[2] | bw[3] | bw[4] | bw[5] | bw[6] | bw[7]) & 0x80808080u;   // a quality of 128 or more among them
-        if (min_bq <= 127 && !hb) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) okq |= cs_pack4(cs_ge_bytes(bw[k], (uint32_t)min_bq_c)) << (4 * k);
-        } else if (min_bq <= 127) {
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                okq |= cs_pack4(cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)min_bq_c) | (bw[k] & 0x80808080u)) << (4 * k);
-        } else if (min_bq <= 255) {                           // (a threshold above 127: only a quality of 128 or more can pass)
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                okq |= cs_pack4((min_bq > 128 ? cs_ge_bytes(bw[k] & 0x7f7f7f7fu, (uint32_t)(min_bq - 128)) : 0x80808080u) &
-                                (bw[k] & 0x80808080u)) << (4 * k);
-        }
-        if (min_bq <= 0) okq = ~0u;
-        // not trimmed: trim_lo <= q <= trim_hi (the two bounds are whole numbers), and q < qlen
-        const int32_t lo_q = max(trim_lo, 0), hi_q = min(trim_hi, qlen - 1);
-        const int32_t a0 = max(lo_q - qa, 0), a1 = min(hi_q - qa, 31);
-        return okq & ((a0 <= a1) ? ((a1 - a0 >= 31 ? ~0u : ((1u << (a1 - a0 + 1)) - 1u)) << a0) : 0u);
-    };
-
-    // ---- which words lie within two windows of a mismatch entry: around every segment boundary (an indel: from the last
-    //      base in front of it to the first base behind it) and every substitution, in query coordinates.  (A base and an
-    //      entry that are D reference positions apart with no indel between them are D query bases apart; with indels
-    //      between them the nearest of those is an entry itself and no further from the base.)
-    if (!big) {
-        // (2 w + 2 either way: a base's window reaches w reference positions to each side, up to 2 w to one side where its match
-        //  operation starts near an end of the read, one more for the 0-based positions against the 1-based list)
-        auto reach = [&](int32_t) -> int32_t { return 2 * w + 2; };
-        auto mark = [&](int32_t qlo, int32_t qhi) {
-            qlo = max(qlo, 0); qhi = min(qhi, qlen - 1);
-            for (int32_t wd = qlo >> 5; wd <= (qhi >> 5); wd++) atomicOr(&bm[wd >> 5], 1u << (wd & 31));
-        };
-        for (int j = lane - 1; j + 1 < ns; j += 64) {             // boundary between segment j and j + 1 (j = -1: in front of the first)
-            const int4 sb = SEG(j + 1);
-            if (j < 0) { if ((uint32_t)sb.w & SEG_INS) { const int32_t q0 = uni(R.qstart[r]); mark(q0 - reach(q0), sb.y + reach(sb.y)); } continue; }
-            const int4 sa = SEG(j);
-            const int32_t qa_end = sa.y + ((((uint32_t)sa.w & SEG_DEL) || sa.z <= 0) ? 0 : sa.z);
-            mark(qa_end - 1 - reach(qa_end), sb.y + reach(sb.y));
-        }
-        for (int k = lane; k < nm; k += 64) { const uint32_t v = MQ(k); if (v & 16u) { const int32_t q = (int32_t)(v >> 5); mark(q - reach(q), q + reach(q)); } }
-        for (int k = lane; k < nN; k += 64) { const int32_t q = NQ(k); mark(q - reach(q), q + reach(q)); }
-    }
+    if (!big) { if (in_lds) cr.mark_words(ll, bm, lane); else cr.mark_words(lm, bm, lane); }
     __builtin_amdgcn_wave_barrier();
 
     // ---- pass A: the qualities once; quality-and-trim words everywhere
@@ -231,157 +411,40 @@ __global__ void __launch_bounds__(256) k_callable(Reads R, Derived D, Params P, 
                         qsum = __builtin_amdgcn_sad_u8(x, 0u, qsum);
                     }
                 }
-                cbits[(qo + qa) >> 5] = quality_trim(bw, qa);
+                cbits[(qo + qa) >> 5] = cr.quality_trim(bw, qa);
             }
         }
     }
 
-    // ---- pass B: a word with a mismatch entry nearby, the exact way (qa: its first base)
-    auto exact_word = [&](int32_t qa) {
-        uint32_t bw[8];
-        {
-            const uint4 b0 = *reinterpret_cast<const uint4*>(R.bq + qo + qa), b1 = *reinterpret_cast<const uint4*>(R.bq + qo + qa + 16);
-            bw[0] = b0.x; bw[1] = b0.y; bw[2] = b0.z; bw[3] = b0.w; bw[4] = b1.x; bw[5] = b1.y; bw[6] = b1.z; bw[7] = b1.w;
-        }
-        const uint32_t okq = quality_trim(bw, qa);
-        uint32_t word = 0;
-        // the first segment that reaches behind qa (segments are in query order)
-        int jc = 0;
-        {
-            int lo = 0, hi = ns;
-            while (lo < hi) {
-                const int m = (lo + hi) >> 1;
-                const int4 sg = SEG(m);
-                const int32_t qspan = (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) ? 0 : sg.z;
-                if (sg.y + qspan <= qa) lo = m + 1; else hi = m;
-            }
-            jc = lo;
-        }
-        for (int j = jc; j < ns; j++) {
-            const int4 sg = SEG(j);
-            if (sg.y >= qa + 32) break;
-            if (((uint32_t)sg.w & SEG_DEL) || sg.z <= 0) continue;
-            const int32_t a = max(sg.y, qa), b = min(sg.y + sg.z, qa + 32);     // query overlap
-            if (a >= b) continue;
-            const int32_t tlo = sg.x + (a - sg.y), thi = sg.x + (b - 1 - sg.y);  // 0-based reference positions
-            uint32_t nsub_bits = 0;      // N-reference substitutions among these bases; the last one in front of them
-            int32_t nsub_prev = -1;
-            for (int k = 0; k < nN; k++) {
-                const int32_t q = NQ(k);
-                if (q >= a && q < b) nsub_bits |= 1u << (q - qa);
-                else if (q >= sg.y && q < a) nsub_prev = q;
-            }
-            // any list entry that could fall into a window of these bases?
-            const int k0 = lower(tlo - 2 * w - 1);
-            if (k0 >= nm || MIS(k0) > thi + 2 * w + 1) {
-                word |= (okq & (((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa))) | nsub_bits;
-                continue;
-            }
-            // the few entries near these bases, in registers (value, query offset | substitution flag); a lane with more
-            // than NE nearby takes the exact loop over its bases below
-            constexpr int NE = 4;
-            int32_t ev[NE];
-            uint32_t eq[NE];
-            int ne = 0;
-#pragma unroll
-            for (int i = 0; i < NE; i++) {
-                ev[i] = 0x7fffffff; eq[i] = 0;
-                if (k0 + i < nm) { const int32_t m = MIS(k0 + i); if (m <= thi + 2 * w + 1) { ev[i] = m; eq[i] = MQ(k0 + i); ne = i + 1; } }
-            }
-            const bool overflow = k0 + NE < nm && MIS(k0 + NE) <= thi + 2 * w + 1;   // more than NE entries nearby
-            // start of the match operation the first base belongs to: behind the previous substitution of this
-            // segment, else the segment start
-            int32_t osq = sg.y;
-            {
-                const int kp = lower(tlo + 1) - 1;
-                if (kp >= 0) {
-                    const uint32_t pv = MQ(kp);
-                    const int32_t pq = (int32_t)(pv >> 5);
-                    if ((pv & 16u) && pq >= sg.y && pq < a) osq = pq + 1;
-                }
-                if (nsub_prev >= 0) osq = max(osq, nsub_prev + 1);
-            }
-            // Away from the read's ends every match operation has the window (w, w), so "how many entries see
-            // this base" is a sum of bit ranges: bit-sliced counters instead of a loop over the bases.
-            if (!overflow && osq >= w && (int64_t)qa + 32 + w <= (int64_t)qlen) {
-                const int32_t shift = sg.y - sg.x - qa;           // bit of reference position t = t + shift
-                const uint32_t span = ((b - a) >= 32 ? ~0u : ((1u << (b - a)) - 1u)) << (a - qa);
-                uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, sub = 0;
-#pragma unroll
-                for (int i = 0; i < NE; i++) {
-                    if (i >= ne) continue;
-                    const int lo = max(ev[i] - w + shift, 0), hi = min(ev[i] + w + shift, 31);
-                    uint32_t rr = 0;
-                    if (lo <= hi) rr = ((hi - lo) >= 31 ? ~0u : ((1u << (hi - lo + 1)) - 1u)) << lo;
-                    const uint32_t k0_ = c0 & rr; c0 ^= rr;
-                    const uint32_t k1_ = c1 & k0_; c1 ^= k0_;
-                    const uint32_t k2_ = c2 & k1_; c2 ^= k1_;
-                    c3 ^= k2_;
-                    const int32_t sq = (int32_t)(eq[i] >> 5);
-                    if ((eq[i] & 16u) && sq >= a && sq < b && ev[i] == sg.x + (sq - sg.y) + 1) sub |= 1u << (sq - qa);
-                }
-                uint32_t gt = 0;                                   // bases seen by more than maxmm entries
-                if (maxmm < 8) {
-                    uint32_t same = ~0u;
-                    const uint32_t planes[4] = {c0, c1, c2, c3};
-#pragma unroll
-                    for (int pbit = 3; pbit >= 0; pbit--) {
-                        const uint32_t kb = ((maxmm >> pbit) & 1) ? ~0u : 0u;
-                        gt |= same & planes[pbit] & ~kb;
-                        same &= ~(planes[pbit] ^ kb);
-                    }
-                }
-                word |= (span & ((okq & ~gt) | sub)) | nsub_bits;
-                continue;
-            }
-            for (int32_t q = a; q < b; q++) {
-                const int32_t t = sg.x + (q - sg.y);
-                const int bit = q - qa;
-                bool is_sub = false;
-#pragma unroll
-                for (int i = 0; i < NE; i++) if (ev[i] == t + 1 && (eq[i] & 16u) && (int32_t)(eq[i] >> 5) == q) is_sub = true;
-                if (overflow && !is_sub)
-                    for (int kk = lower(t + 1); kk < nm && MIS(kk) == t + 1; kk++) { const uint32_t v = MQ(kk); if ((v & 16u) && (int32_t)(v >> 5) == q) is_sub = true; }
-                if (is_sub || ((nsub_bits >> bit) & 1u)) { word |= 1u << bit; osq = q + 1; continue; }
-                int64_t qs = (int64_t)osq - w, qe = (int64_t)osq + w, ur, dr;      // bamlib.py:245-258
-                if (qs < 0) { ur = w + qs; dr = w - qs; }
-                else if (qe > qlen) { ur = w + (qe - qlen); dr = qlen - osq; }
-                else { ur = w; dr = w; }
-                int cnt = 0;
-                if (!overflow) {
-#pragma unroll
-                    for (int i = 0; i < NE; i++) cnt += (ev[i] >= t - ur && ev[i] <= t + dr) ? 1 : 0;
-                } else cnt = upper((int32_t)(t + dr)) - lower((int32_t)(t - ur));
-                if (cnt <= maxmm && ((okq >> bit) & 1u)) word |= 1u << bit;
-            }
-        }
-        cbits[(qo + qa) >> 5] = word;
-    };
-    if (big) {
-        for (int32_t w0 = 0; w0 < nwords; w0 += 64) if (w0 + lane < nwords) exact_word((w0 + lane) * 32);
-    } else {
-        // the marked words, gathered into a list and worked off 64 at a time
+    // ---- pass B: the words with a mismatch entry nearby (every word of a read the bitmap does not hold), gathered into a
+    //      list and worked off 64 at a time, a lane each.  One place in the code for each of the two kinds of lists.
+    const int ndw = (nwords + 31) >> 5;
+    for (int32_t next = 0;;) {                                  // next: the bitmap dword (big: the word) to go on from
         int nl = 0;
-        const int ndw = (nwords + 31) >> 5;
-        for (int d0 = 0; d0 < ndw; d0 += 2) {
-            const uint64_t bits2 = (uint64_t)uni(bm[d0]) | ((uint64_t)(d0 + 1 < ndw ? uni(bm[d0 + 1]) : 0u) << 32);
-            if (!bits2) continue;
-            const int here = __builtin_popcountll(bits2);
-            if (nl + here > CAL_LIST) {
-                __builtin_amdgcn_wave_barrier();
-                for (int i0 = 0; i0 < nl; i0 += 64) if (i0 + lane < nl) exact_word((int32_t)list[i0 + lane] * 32);
-                __builtin_amdgcn_wave_barrier();
-                nl = 0;
+        if (big) {
+            nl = min(CAL_LIST, nwords - next);
+            for (int i = lane; i < nl; i += 64) list[i] = (uint16_t)i;      // (offsets from `next`: a word number may not fit 16 bits)
+        } else {
+            for (; next < ndw; next += 2) {
+                const uint64_t bits2 = (uint64_t)uni(bm[next]) | ((uint64_t)(next + 1 < ndw ? uni(bm[next + 1]) : 0u) << 32);
+                if (!bits2) continue;
+                const int here = __builtin_popcountll(bits2);
+                if (nl + here > CAL_LIST) break;
+                if ((bits2 >> lane) & 1ull) {
+                    const int rank = __builtin_popcountll(bits2 & ((1ull << lane) - 1ull));
+                    const int32_t wd = next * 32 + lane;
+                    list[nl + rank] = (uint16_t)min(wd, nwords - 1);
+                }
+                nl += here;
             }
-            if ((bits2 >> lane) & 1ull) {
-                const int rank = __builtin_popcountll(bits2 & ((1ull << lane) - 1ull));
-                const int32_t wd = d0 * 32 + lane;
-                if (wd < nwords) list[nl + rank] = (uint16_t)wd; else list[nl + rank] = (uint16_t)(nwords - 1);
-            }
-            nl += here;
         }
+        if (nl <= 0) break;
         __builtin_amdgcn_wave_barrier();
-        for (int i0 = 0; i0 < nl; i0 += 64) if (i0 + lane < nl) exact_word((int32_t)list[i0 + lane] * 32);
+        const int32_t wbase = big ? next : 0;
+        if (in_lds) { for (int i0 = 0; i0 < nl; i0 += 64) if (i0 + lane < nl) cr.exact_word(ll, (wbase + (int32_t)list[i0 + lane]) * 32); }
+        else { for (int i0 = 0; i0 < nl; i0 += 64) if (i0 + lane < nl) cr.exact_word(lm, (wbase + (int32_t)list[i0 + lane]) * 32); }
+        __builtin_amdgcn_wave_barrier();
+        if (big) next += nl;
     }
     // ---- the mean quality (np.mean of the whole query against min_qv, as in k_read_live's other tests)
     const uint32_t qtot = (uint32_t)lane_val(wave_incl_add((int)qsum, lane), 63);

@@ -32,7 +32,7 @@ namespace himut {
 #define HIMUT_NQ_OCC 4           // waves per SIMD asked of the register allocator
 #endif
 #ifndef HIMUT_NQ_Q
-#define HIMUT_NQ_Q 8             // workgroups per XCD class and chunk (neighbouring tiles: the mapping of k_norm_tile)
+#define HIMUT_NQ_Q 2             // workgroups per XCD class and chunk (neighbouring tiles: the mapping of k_norm_tile)
 #endif
 constexpr int NQ_WAVES = 4;
 constexpr int NQ_COLS = 256;                       // positions per wave

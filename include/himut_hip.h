@@ -146,7 +146,9 @@ typedef struct himut_run_stats {
     double ms_index;            /* k_mark_positions (bitmap of substitution positions) + rank, column windows /
                                    offsets, column-store fill: runs in front of the capture */
     double ms_capture;          /* k_stream_capture: streams every read once, fills the column store, sums the
-                                   qualities of every read */
+                                   qualities of every read.  After himut_run_normcounts: k_norm_quad, the sweep's
+                                   dominant kernel, by itself (ms_parse = the decode, ms_index = the read pass,
+                                   ms_eval = the whole position sweep) */
     double ms_eval;             /* k_eval_columns: counts, ordered likelihood sums, genotype, filters */
     double ms_finalize;         /* cross-chunk som_seen / counters / compaction */
     int64_t n_reads;

@@ -2,6 +2,7 @@
 
 usage: python profiles/summarize.py stats <dir> <out.csv>       (from --kernel-trace --stats --output-format csv)
        python profiles/summarize.py pmc <fetch_dir> <write_dir> <out.json>   (from the two --pmc passes)
+       python profiles/summarize.py normpmc <fetch_dir> <write_dir> <rows_fetch_dir> <out.json> <tag>   (the normcounts pass)
 """
 import csv
 import glob
@@ -54,7 +55,7 @@ def pmc(fetch_dir, write_dir, out):
     f = pmc_avg(fetch_dir, "FETCH_SIZE")
     w = pmc_avg(write_dir, "WRITE_SIZE")
     doc = {"contig_len": 64444167, "depth": 30.0,      # bench.py's default workload (what collect.sh runs)
-           "collected": "profiles/collect.sh " + (os.environ.get("HIMUT_PROFILE_TAG") or "r02") + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes",
+           "collected": "profiles/collect.sh " + (os.environ.get("HIMUT_PROFILE_TAG") or "r03") + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes",
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 2 --warmup 1). "
                    "Counter unit = KiB. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports 1/2 of the bytes "
                    "of a wide coalesced streaming read, so fetch bytes are doubled for the streaming kernels ("
@@ -73,10 +74,66 @@ def pmc(fetch_dir, write_dir, out):
         json.dump(doc, fh, indent=1, sort_keys=True)
 
 
+def rows_calibration(d):
+    """tools/ubench_rows.hip under --pmc FETCH_SIZE: bytes the kernels are known to read (every row once) over the bytes
+    counted, per (rows in flight, arrays read, aligned) variant."""
+    L, STEP, npos = 15008, 500, 64444167
+    nreads, ntiles = npos // STEP, npos // 256
+    rows = 0
+    for t in range(ntiles):
+        base = t * 256
+        lo = max(0, -((-(base + 256 - L)) // STEP))
+        hi = min(nreads, base // STEP + 1)
+        rows += max(0, hi - lo)
+    acc = {}
+    for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+        if r["Counter_Name"] != "FETCH_SIZE" or "k_rows" not in r["Kernel_Name"]:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        a = acc.setdefault(name, [0.0, 0])
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+    out = {}
+    for name, (tot, n) in sorted(acc.items()):
+        args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")
+        mode = int(args[1])
+        known = rows * ((256 if mode & 1 else 0) + (128 if mode & 2 else 0) + (32 if mode & 4 else 0))
+        out[name] = {"known_bytes": known, "FETCH_SIZE_bytes": tot / n * 1024, "known_over_counted": known / (tot / n * 1024)}
+    return out
+
+
+def normpmc(fetch_dir, write_dir, rows_dir, out, tag):
+    f = pmc_avg(fetch_dir, "FETCH_SIZE")
+    w = pmc_avg(write_dir, "WRITE_SIZE")
+    cal = rows_calibration(rows_dir)
+    # the sweep's three arrays read with rows of four in flight at any alignment: k_norm_quad's own pattern
+    key = [k for k in cal if k.replace(" ", "").endswith("<4,7,false>")]
+    quad_mult = cal[key[0]]["known_over_counted"] if key else 1.0
+    mult = {"k_parse_cs": 2.0, "k_callable": 2.0, "k_flag_bases": 2.0, "k_norm_quad": quad_mult}
+    doc = {"collected": "profiles/collect_normcounts.sh " + tag,
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/bench_normcounts.py, chr20-sized 30x contig; KiB per "
+                   "launch as counted in raw_kib_per_launch.  FETCH_SIZE reports half of the bytes of a wide coalesced streaming read on "
+                   "gfx950 (MI355X_MICROARCH.md): doubled for k_parse_cs and k_callable (16 bytes per lane).  k_norm_quad reads rows of "
+                   "256 bases with a dword per lane at any alignment, a width the guide calls uncalibrated: its factor is measured on "
+                   "tools/ubench_rows.hip, which reads the same three arrays in the same pattern and every byte once "
+                   "(rows_calibration; the <4, 7, false> variant).  The other kernels are taken as counted.  WRITE_SIZE as is.",
+           "rows_calibration": cal, "k_norm_quad_fetch_factor": quad_mult, "raw_kib_per_launch": {}}
+    for k in sorted(set(f) | set(w)):
+        short = k.split("::")[-1].split("<")[0]
+        doc["raw_kib_per_launch"][k] = {"FETCH_SIZE": f.get(k, 0.0), "WRITE_SIZE": w.get(k, 0.0)}
+        doc[short] = int(f.get(k, 0.0) * 1024 * mult.get(short, 1.0) + w.get(k, 0.0) * 1024)
+    doc["sweep_total"] = int(sum(doc.get(k, 0) for k in ("k_norm_plan", "k_norm_quad", "k_norm_dirty", "k_norm_tile")))
+    doc["pass_total"] = int(sum(v for k, v in doc.items() if k.startswith("k_") and isinstance(v, int)))
+    with open(out, "w") as fh:
+        json.dump(doc, fh, indent=1, sort_keys=True)
+    print({k: round(v / 1e9, 3) for k, v in doc.items() if isinstance(v, int)}, "quad factor", round(quad_mult, 3))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "normpmc":
+        normpmc(*sys.argv[2:7])
     else:
         raise SystemExit(__doc__)
