@@ -1362,7 +1362,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
             const int64_t tpc = (int64_t)blocks_for(maxspan, NQ_COLS);                  // tiles per chunk (the plan's stride)
             c->d_plan.reserve((size_t)T.n * (size_t)tpc * NQ_ITEMS * sizeof(NqItem) + 256);
             c->d_plancnt.reserve((size_t)T.n * (size_t)tpc * 4 + 256);
-            const dim3 pgrid((unsigned)blocks_for(tpc, 4), (unsigned)T.n);
+            const dim3 pgrid((unsigned)blocks_for(blocks_for(tpc, NQ_PLAN_TILES), 4), (unsigned)T.n);
             if (phase) hipLaunchKernelGGL(k_norm_plan<true>, pgrid, dim3(256), 0, st, A, D, c->d_winlo.as<int32_t>(), c->d_winhi.as<int32_t>(),
                                           nblk, tpc, c->d_plan.as<NqItem>(), c->d_plancnt.as<uint32_t>(), c->d_redo.as<NormRedo>(),
                                           &sc->nredo, redo_cap);

@@ -161,7 +161,13 @@ constexpr uint32_t NQ_PLAN_OVER = 0xffffffffu;         // count of a tile that h
 
 // ---------------------------------------------------------------------------------------
 // k_norm_plan: tile k of chunk blockIdx.y is positions [cs + 256 k, cs + 256 k + 256) below the chunk's end; its items go
-// to items[(chunk * tpc + k) * NQ_ITEMS ..], their number to counts[chunk * tpc + k].
+// to items[(chunk * tpc + k) * NQ_ITEMS ..], their number to counts[chunk * tpc + k].  A wave plans NQ_PLAN_TILES
+// consecutive tiles: the reads over them are nearly the same, and a lane fetches its read's header and first segment starts
+// once for all of them.
+#ifndef HIMUT_NQ_PLAN_TILES
+#define HIMUT_NQ_PLAN_TILES 4
+#endif
+constexpr int NQ_PLAN_TILES = HIMUT_NQ_PLAN_TILES;
 template <bool PHASE>
 __global__ void __launch_bounds__(256) k_norm_plan(NormArgs A, Derived D, const int32_t* winlo, const int32_t* winhi, int64_t nblk,
                                                    int64_t tpc, NqItem* items, uint32_t* counts, NormRedo* redo,
@@ -169,34 +175,50 @@ __global__ void __launch_bounds__(256) k_norm_plan(NormArgs A, Derived D, const 
     const int lane = threadIdx.x & 63, wv = uni((int)(threadIdx.x >> 6));
     const int chunk = blockIdx.y;
     const int32_t cs_ = A.C.start[chunk], ce_ = A.C.end[chunk];
-    const int64_t k = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t base64 = (int64_t)cs_ + k * NQ_COLS;
-    if (base64 >= ce_) return;
-    const int32_t base = (int32_t)base64;
-    const int32_t tile_end = (int32_t)min((int64_t)base + NQ_COLS, (int64_t)ce_);
+    const int64_t k_first = ((int64_t)blockIdx.x * 4 + wv) * NQ_PLAN_TILES;
+    const int64_t first64 = (int64_t)cs_ + k_first * NQ_COLS;
+    if (first64 >= ce_) return;
+    const int32_t span_end = (int32_t)min(first64 + (int64_t)NQ_PLAN_TILES * NQ_COLS, (int64_t)ce_);
     constexpr bool phase = PHASE;
     const int64_t pairbase = phase ? A.C.pairoff[chunk] - A.C.rlo[chunk] : 0;
-    NqItem* out = items + (chunk * tpc + k) * NQ_ITEMS;
-    const int64_t b0 = min(max(base64, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min((base64 + NQ_COLS - 1) >> WIN_SHIFT, nblk - 1);
-    const int32_t lo = uni(winlo[b0]), hi = uni(winhi[b1]);
-    uint32_t total = 0;
+    const int64_t b0 = min(max(first64, (int64_t)0) >> WIN_SHIFT, nblk - 1), b1 = min(((int64_t)span_end - 1) >> WIN_SHIFT, nblk - 1);
+    const int32_t lo = uni(winlo[b0]), hi = uni(winhi[max(b1, b0)]);
+    uint32_t total[NQ_PLAN_TILES];
+    bool over[NQ_PLAN_TILES];
+#pragma unroll
+    for (int t = 0; t < NQ_PLAN_TILES; t++) { total[t] = 0; over[t] = false; }
     for (int32_t r0 = lo; r0 < hi; r0 += 64) {
         const int nb = min(64, hi - r0);
-        bool live = false;
+        bool live_any = false;
         ReadMeta M;
         M.tstart = 0; M.tend = 0; M.nseg = 0; M.flags = RF_SECONDARY; M.segbase = 0; M.qoff = 0;
-        int j0 = 0;
         uint32_t hp = HAP_NONE;
+        // the starts of the read's first eight segments in one round trip: where a tile begins among them, without a search
+        constexpr int NP = 8;
+        int32_t tp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) tp[q] = 0x7fffffff;
         if (lane < nb) {
             M = D.meta[r0 + lane];
-            live = !(M.flags & RF_SECONDARY) && M.nseg > 0 && M.tstart < tile_end && M.tend >= base;
-            if (live) {
-                // the last segment that starts at or before the tile: the starts of the read's first eight segments in one
-                // round trip, the binary search only where the segment lies further on
-                constexpr int NP = 8;
-                int32_t tp[NP];
+            live_any = !(M.flags & RF_SECONDARY) && M.nseg > 0 && M.tstart < span_end && (int64_t)M.tend >= first64;
+            if (live_any) {
 #pragma unroll
                 for (int q = 0; q < NP; q++) tp[q] = D.segs[M.segbase + min(q, M.nseg - 1)].t0;
+                if (phase && M.tstart < ce_ && M.tend > cs_) hp = A.H.hap[pairbase + r0 + lane];   // fetched by the chunk
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NQ_PLAN_TILES; t++) {
+            const int64_t base64 = first64 + (int64_t)t * NQ_COLS;
+            if (base64 >= ce_ || over[t]) continue;
+            const int32_t base = (int32_t)base64;
+            const int32_t tile_end = (int32_t)min(base64 + NQ_COLS, (int64_t)ce_);
+            const int64_t k = k_first + t;
+            NqItem* out = items + (chunk * tpc + k) * NQ_ITEMS;
+            const bool live = live_any && M.tstart < tile_end && M.tend >= base;
+            int j0 = 0;
+            if (live) {
+                // the last segment that starts at or before the tile; the binary search only where it lies beyond the eight
                 int a = 0;
 #pragma unroll
                 for (int q = 0; q < NP; q++) a += (q < M.nseg && tp[q] <= base) ? 1 : 0;
@@ -205,24 +227,28 @@ __global__ void __launch_bounds__(256) k_norm_plan(NormArgs A, Derived D, const 
                     while (a < e) { const int mm = (a + e) >> 1; if (D.segs[M.segbase + mm].t0 <= base) a = mm + 1; else e = mm; }
                 }
                 j0 = max(a - 1, 0);
-                if (phase && M.tstart < ce_ && M.tend > cs_) hp = A.H.hap[pairbase + r0 + lane];   // fetched by the chunk
             }
-        }
-        // the pieces of this lane's read inside the tile; pass 0 counts them, pass 1 writes them behind the rows in front
-        uint32_t mine = 0, at = 0;
-        for (int pass = 0; pass < 2; pass++) {
-            uint32_t n = 0;
+            // the pieces of this lane's read inside the tile; pass 0 counts them, pass 1 writes them behind the rows in front.
+            // The first NG segments from j0 on come in one round trip and serve both passes (a tile seldom holds more of one read).
+            constexpr int NG = 3;
+            Seg gs[NG];
+#pragma unroll
+            for (int q = 0; q < NG; q++) { gs[q].t0 = 0x7fffffff; gs[q].q0 = 0; gs[q].len = 0; gs[q].flags = 0; }
             if (live) {
-                for (int j = j0; j < M.nseg; j++) {
-                    const Seg g = D.segs[M.segbase + j];
-                    if (g.t0 >= tile_end) break;
+#pragma unroll
+                for (int q = 0; q < NG; q++) if (j0 + q < M.nseg) gs[q] = D.segs[M.segbase + j0 + q];
+            }
+            uint32_t at = 0, batch = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                uint32_t n = 0;
+                auto piece = [&](const Seg& g) {
                     const int32_t span = g.len > 0 ? g.len : ((g.flags & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
                     int32_t tlo = max(g.t0, base);
                     const int32_t thi = (int32_t)min((int64_t)g.t0 + span, (int64_t)tile_end);
                     // a read this chunk did not fetch (normcounts.py:289) adds nothing: only its trailing insertion can reach in
                     if (!(M.tend > cs_)) tlo = max(tlo, cs_ + 1);
-                    if (tlo >= thi) continue;
-                    if (pass == 1 && total + at + n < (uint32_t)NQ_ITEMS) {
+                    if (tlo >= thi) return;
+                    if (pass == 1 && total[t] + at + n < (uint32_t)NQ_ITEMS) {
                         NqItem it;
                         it.kq = M.qoff + g.q0 - (int64_t)g.t0;
                         it.tlo = tlo;
@@ -231,29 +257,45 @@ __global__ void __launch_bounds__(256) k_norm_plan(NormArgs A, Derived D, const 
                         if ((g.flags & SEG_INS) && tlo == g.t0) f |= NQI_INS;
                         f |= hp << NQI_HAP_SHIFT;
                         it.flags = (uint16_t)f;
-                        out[total + at + n] = it;
+                        out[total[t] + at + n] = it;
                     }
                     n++;
-                }
-            }
-            if (pass == 0) {
-                mine = n;
-                const uint32_t incl = (uint32_t)wave_incl_add((int)n, lane);
-                at = incl - n;
-                const uint32_t batch = (uint32_t)lane_val((int)incl, 63);
-                if (total + batch > (uint32_t)NQ_ITEMS) {           // more than the plan holds: the tile goes to k_norm_tile
-                    if (lane == 0) {
-                        counts[chunk * tpc + k] = NQ_PLAN_OVER;
-                        const unsigned int w = atomicAdd(nredo, 1u);
-                        if (w < redo_cap) { NormRedo z; z.chunk = chunk; z.base = base; redo[w] = z; }
+                };
+                if (live) {
+                    bool more = true;
+#pragma unroll
+                    for (int q = 0; q < NG; q++) {
+                        if (more && (j0 + q >= M.nseg || gs[q].t0 >= tile_end)) more = false;
+                        if (more) piece(gs[q]);
                     }
-                    return;
+                    if (more)
+                        for (int j = j0 + NG; j < M.nseg; j++) {
+                            const Seg g = D.segs[M.segbase + j];
+                            if (g.t0 >= tile_end) break;
+                            piece(g);
+                        }
+                }
+                if (pass == 0) {
+                    const uint32_t incl = (uint32_t)wave_incl_add((int)n, lane);
+                    at = incl - n;
+                    batch = (uint32_t)lane_val((int)incl, 63);
+                    if (total[t] + batch > (uint32_t)NQ_ITEMS) {        // more than the plan holds: the tile goes to k_norm_tile
+                        if (lane == 0) {
+                            counts[chunk * tpc + k] = NQ_PLAN_OVER;
+                            const unsigned int w = atomicAdd(nredo, 1u);
+                            if (w < redo_cap) { NormRedo z; z.chunk = chunk; z.base = base; redo[w] = z; }
+                        }
+                        over[t] = true;
+                        break;
+                    }
                 }
             }
+            if (!over[t]) total[t] += batch;
         }
-        total += (uint32_t)lane_val(wave_incl_add((int)mine, lane), 63);
     }
-    if (lane == 0) counts[chunk * tpc + k] = total;
+#pragma unroll
+    for (int t = 0; t < NQ_PLAN_TILES; t++)
+        if (first64 + (int64_t)t * NQ_COLS < ce_ && !over[t] && lane == 0) counts[chunk * tpc + k_first + t] = total[t];
 }
 
 // packed per-lane column flags
