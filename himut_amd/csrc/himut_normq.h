@@ -54,6 +54,14 @@ __device__ __forceinline__ uint32_t nq_spread4(uint32_t b) {           // bits 0
 __device__ __forceinline__ uint32_t nq_zero_bytes(uint32_t w) {        // non-zero iff one of the four bytes is zero
     return (w - 0x01010101u) & ~w & 0x80808080u;
 }
+// a lane's cells (bits 0..3: positions P0 .. P0 + 3) of a piece of len positions from tlo on
+__device__ __forceinline__ uint32_t nq_cells(int32_t P0, int32_t tlo, int32_t len) {
+    const int32_t jlo = min(max(tlo - P0, 0), 4), jhi = min(max(tlo + len - P0, 0), 4);
+    return jhi > jlo ? (((1u << (jhi - jlo)) - 1u) << jlo) : 0u;
+}
+__device__ __forceinline__ uint32_t nq_nibbles(uint32_t c4) {          // cell j -> the nibble at bits 12 - 4 j
+    return (c4 & 1u ? 0xf000u : 0u) | (c4 & 2u ? 0x0f00u : 0u) | (c4 & 4u ? 0x00f0u : 0u) | (c4 & 8u ? 0x000fu : 0u);
+}
 __device__ __forceinline__ uint64_t nq_lane64(int64_t v, int l) {
     return ((uint64_t)(uint32_t)lane_val((int)(v >> 32), l) << 32) | (uint32_t)lane_val((int)v, l);
 }
@@ -441,142 +449,116 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 is_item = false;
             }
             const uint32_t ifl = lf >> 16;
-            bool full = is_item && (ifl & NQI_TYPE) == NQI_MATCH && tlo == base && (lf & 0xffffu) == (uint32_t)NQ_COLS;
-            // The spanning pieces' first bases as 32-bit distances from a base of the batch (K0: a multiple of 8 at or in front
-            // of the nearest of them): their loads then take three scalar bases, set up once per batch, and a per-lane offset.
-            // (A piece further than 2^31 from it, which 64 reads of a window do not give, goes the general way.)
-            uint64_t kmin = full ? (uint64_t)(kq + base) : ~0ull;
+            const bool is_match = is_item && (ifl & NQI_TYPE) == NQI_MATCH;
+            const bool full = is_match && tlo == base && (lf & 0xffffu) == (uint32_t)NQ_COLS;
+            // ---- what only sets flags, in any order: an insertion in front of a piece is counted at the piece's first
+            //      position, a deletion at each of its positions
+            {
+                uint64_t mf = __ballot(is_item && ((ifl & NQI_INS) || (ifl & NQI_TYPE) == NQI_DEL));
+                while (mf) {
+                    const int gl = (int)__builtin_ctzll(mf);
+                    mf &= mf - 1;
+                    const int32_t g_tlo = lane_val(tlo, gl);
+                    const uint32_t g_lf = (uint32_t)lane_val((int)lf, gl);
+                    const uint32_t c4 = nq_cells(P0, g_tlo, (int32_t)(g_lf & 0xffffu)) & valid4;
+                    const uint32_t first = (P0 <= g_tlo && g_tlo < P0 + 4) ? (1u << (g_tlo - P0)) : 0u;
+                    if ((g_lf >> 16) & NQI_INS) fl |= (c4 & first) << NQF_INDEL;
+                    if (((g_lf >> 16) & NQI_TYPE) == NQI_DEL) fl |= c4 << NQF_INDEL;
+                }
+            }
+            // ---- the pieces with bases, in read order, NB at a time with their loads issued together.  A piece's first cell
+            //      of the tile is query base kq + base of the arrays whether or not the piece reaches that far: addresses are
+            //      32-bit distances from a base of the batch (K0: a multiple of 8 at least 256 in front of the nearest piece's
+            //      first base), so that a load takes a scalar base, set up once per batch, and a per-lane offset.  A piece
+            //      that covers a part of the positions (an indel or a read end inside them, one in ten) goes the same way
+            //      under a mask of cells; its lanes outside the piece load the piece's first base and use nothing of it.
+            //      (A piece further than 2^31 from K0, which 64 reads of a window do not give, or one that starts within the
+            //      arrays' first bytes, sends the tile to k_norm_tile.)
+            uint64_t kmin = is_match ? (uint64_t)(kq + tlo) : ~0ull;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
                 const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(kmin >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)kmin, d, 64);
                 kmin = min(kmin, o);
             }
-            const uint64_t K0 = (uint64_t)uni((int64_t)((kmin == ~0ull ? 0ull : kmin) & ~7ull));      // (the same in every lane: scalar registers)
-            const uint64_t dk64 = (uint64_t)(kq + base) - K0;
-            if (full && dk64 >= (1ull << 31)) full = false;
-            const uint32_t dk = full ? (uint32_t)dk64 : 0u;
-            const uint64_t s_bq = (uint64_t)R.bq + K0, s_sq = (uint64_t)R.seq + (K0 >> 1), s_cb = (uint64_t)callable + (K0 >> 3);
+            const int64_t K0 = uni((int64_t)((kmin == ~0ull ? 0ull : kmin) & ~7ull)) - NQ_COLS;      // (the same in every lane: scalar registers)
+            const uint64_t dk64 = (uint64_t)(kq + base - K0);
+            const bool far = is_match && (dk64 >= (1ull << 31) || (!full && kq + tlo < 8));
+            if (__ballot(far)) { fl |= 1u << NQF_OVER; break; }
+            const uint32_t dk = is_match ? (uint32_t)dk64 : 0u;
+            const uint64_t s_bq = (uint64_t)((int64_t)(uint64_t)R.bq + K0), s_sq = (uint64_t)((int64_t)(uint64_t)R.seq + (K0 >> 1)),
+                           s_cb = (uint64_t)((int64_t)(uint64_t)callable + (K0 >> 3));
             const uint64_t m_full = __ballot(full);
-            // ---- the items in read order.  What an item adds comes as four cells per lane: qualities qv (byte j = column j),
-            //      BAM codes n4 (column j in bits 12 - 4j ..), callable bits cb.  The nine items in ten that span the tile go
-            //      up to NB at a time, their loads issued together
-            uint64_t m = __ballot(is_item);
-            // the loads of the NEXT item that covers a part of the positions are kept in flight while the spanning items in front
-            // of it are worked on: pl = its lane of the item vector, or -1
-            const uint64_t m_pm = __ballot(is_item && !full && (ifl & NQI_TYPE) == NQI_MATCH);
-            uint32_t pq = 0, pn = 0, pc = 0;
-            int pl = -1;
-            auto part_issue = [&](uint64_t from) {
-                const uint64_t c = m_pm & from;
-                pl = c ? (int)__builtin_ctzll(c) : -1;
-                if (pl < 0) return;
-                const int32_t t_ = lane_val(tlo, pl);
-                const int32_t last = t_ + (int32_t)((uint32_t)lane_val((int)lf, pl) & 0xffffu) - 1;
-                if (P0 + 3 >= t_ && P0 <= last) {                  // (a lane the piece reaches: nothing else is touched)
-                    const uint64_t ks = nq_lane64(kq, pl) + (uint64_t)(int64_t)max(P0, t_);
-                    pq = nq_ld32((uint64_t)R.bq + ks, 0u);
-                    pn = nq_ld32((uint64_t)R.seq + (ks >> 1), 0u);
-                    pc = nq_ld16((uint64_t)callable + (ks >> 3), 0u);
-                }
-            };
-            part_issue(m);
+            uint64_t m = __ballot(is_match);
             while (m) {
-                const uint64_t ms = m & ~m_full;
-                const uint64_t front = ms ? (m & ((ms & (0 - ms)) - 1)) : m;
-                if (front) {
-                    // cnt items sit in the LAST cnt of the NB places (a place in front of them asks for the first item's words
-                    // once more, so that the loads stand in the text unconditionally); the updates are entered at the place of
-                    // the first item: every one stands in the text once and runs unconditionally from its entry on
-                    const int cnt = min(NB, (int)__builtin_popcountll(front));
-                    uint32_t qv[NB], n4[NB], cb[NB], dd[NB], ifk[NB];
-                    {
-                        const int first = (int)__builtin_ctzll(m);
+                // cnt pieces sit in the LAST cnt of the NB places (a place in front of them asks for the first piece's words once
+                // more, so that the loads stand in the text unconditionally); the updates are entered at the place of the first
+                // piece: every one stands in the text once and runs unconditionally from its entry on
+                const int cnt = min(NB, (int)__builtin_popcountll(m));
+                uint32_t qv[NB], n4[NB], cb[NB], dd[NB], ifk[NB];
+                int32_t gt[NB], gn[NB];             // (scalar) a partial piece's first position and length; gn = 0: the piece spans the tile
+                {
+                    const int first = (int)__builtin_ctzll(m);
 #pragma unroll
-                        for (int k = 0; k < NB; k++) {
-                            int l = first;
-                            if (k >= NB - cnt) { l = (int)__builtin_ctzll(m); m &= m - 1; }
-                            dd[k] = (uint32_t)lane_val((int)dk, l);
-                            ifk[k] = (uint32_t)lane_val((int)ifl, l);
-                            // (a scalar base and a 32-bit offset per lane; the offset is made opaque here so that its widening to
-                            //  64 bits is not hoisted out of the loop, where the load would lose the form)
-                            uint32_t tq = dd[k] + o_q;
-                            asm volatile("" : "+v"(tq));
-                            qv[k] = nq_ld32(s_bq, tq);
-                            n4[k] = nq_ld32(s_sq, tq >> 1);
-                            cb[k] = nq_ld16(s_cb, tq >> 3);
+                    for (int k = 0; k < NB; k++) {
+                        int l = first;
+                        if (k >= NB - cnt) { l = (int)__builtin_ctzll(m); m &= m - 1; }
+                        dd[k] = (uint32_t)lane_val((int)dk, l);
+                        ifk[k] = phase ? (uint32_t)lane_val((int)ifl, l) : 0u;
+                        // (a scalar base and a 32-bit offset per lane; the offset is made opaque here so that its widening to
+                        //  64 bits is not hoisted out of the loop, where the load would lose the form)
+                        uint32_t tq = dd[k] + o_q;
+                        gt[k] = 0; gn[k] = 0;
+                        if (!((m_full >> l) & 1ull)) {
+                            gt[k] = lane_val(tlo, l);
+                            gn[k] = (int32_t)((uint32_t)lane_val((int)lf, l) & 0xffffu);
+                            if (!(nq_cells(P0, gt[k], gn[k]) & valid4)) tq = dd[k] + (uint32_t)(gt[k] - base);
                         }
+                        asm volatile("" : "+v"(tq));
+                        qv[k] = nq_ld32(s_bq, tq);
+                        n4[k] = nq_ld32(s_sq, tq >> 1);
+                        cb[k] = nq_ld16(s_cb, tq >> 3);
                     }
-                    uint32_t rare = 0;
+                }
+                uint32_t rare = 0;
 #define NQ_UPDATE(k) { \
-                        n4[k] = (__builtin_bswap32(n4[k]) >> ((dd[k] & 1u) ? 12u : 16u)) & 0xffffu; \
-                        uint32_t cbk = (cb[k] >> ((dd[k] + o_q) & 7u)) & 15u;          /* (the sixteen bits begin at a byte) */ \
-                        if (ifk[k] & NQI_INS) fl |= (lane == 0 ? 1u : 0u) << NQF_INDEL;     /* an insertion in front of the piece: counted at its first position */ \
-                        if (phase) { \
-                            const uint32_t hap = (ifk[k] >> NQI_HAP_SHIFT) & 3u; \
-                            if (hap == HAP_0) h0b += 0x01010101u; \
-                            else if (hap == HAP_1) h1b += 0x01010101u; \
-                            else cbk = 0;                                        /* the read carries no haplotype in this chunk: no bit of it counts */ \
-                        } \
-                        const uint32_t x = (n4[k] ^ ref4) | (ref4 >> 16);          /* a nibble of zeros: the reference allele */ \
-                        tri4b += nq_spread4(cbk); \
-                        nq_pair<0>(R0[0], R1[0], R2[0], nref[0], R0[1], R1[1], R2[1], nref[1], qv[k], x, lut); \
-                        nq_pair<2>(R0[2], R1[2], R2[2], nref[2], R0[3], R1[3], R2[3], nref[3], qv[k], x, lut); \
-                        if ((x & 0xffffu) | nq_zero_bytes(qv[k])) rare |= 1u << (k); }
-                    switch (cnt) {
-                        case 4: NQ_UPDATE(0) [[fallthrough]];
-                        case 3: NQ_UPDATE(1) [[fallthrough]];
-                        case 2: NQ_UPDATE(2) [[fallthrough]];
-                        default: NQ_UPDATE(3)
-                    }
+                    n4[k] = (__builtin_bswap32(n4[k]) >> ((dd[k] & 1u) ? 12u : 16u)) & 0xffffu; \
+                    uint32_t cbk = (cb[k] >> ((dd[k] + o_q) & 7u)) & 15u;          /* (the sixteen bits begin at a byte) */ \
+                    uint32_t x = (n4[k] ^ ref4) | (ref4 >> 16);                /* a nibble of zeros: the reference allele */ \
+                    uint32_t xr = x & 0xffffu, zq = qv[k], hadd = 0x01010101u; \
+                    if (gn[k]) {                                                /* a part of the positions: the cells outside add nothing */ \
+                        const uint32_t c4 = nq_cells(P0, gt[k], gn[k]) & valid4; \
+                        const uint32_t keep = nq_nibbles(c4); \
+                        xr = x & keep; x |= ~keep; cbk &= c4; \
+                        zq |= ~(nq_spread4(c4) * 255u); \
+                        hadd = nq_spread4(c4); \
+                    } \
+                    if (phase) { \
+                        const uint32_t hap = (ifk[k] >> NQI_HAP_SHIFT) & 3u; \
+                        if (hap == HAP_0) h0b += hadd; \
+                        else if (hap == HAP_1) h1b += hadd; \
+                        else cbk = 0;                                        /* the read carries no haplotype in this chunk: no bit of it counts */ \
+                    } \
+                    tri4b += nq_spread4(cbk); \
+                    nq_pair<0>(R0[0], R1[0], R2[0], nref[0], R0[1], R1[1], R2[1], nref[1], qv[k], x, lut); \
+                    nq_pair<2>(R0[2], R1[2], R2[2], nref[2], R0[3], R1[3], R2[3], nref[3], qv[k], x, lut); \
+                    if (xr | nq_zero_bytes(zq)) rare |= 1u << (k); }
+                switch (cnt) {
+                    case 4: NQ_UPDATE(0) [[fallthrough]];
+                    case 3: NQ_UPDATE(1) [[fallthrough]];
+                    case 2: NQ_UPDATE(2) [[fallthrough]];
+                    default: NQ_UPDATE(3)
+                }
 #undef NQ_UPDATE
-                    if (__builtin_expect(__ballot(rare != 0) != 0, 0)) {
+                if (__builtin_expect(__ballot(rare != 0) != 0, 0)) {
 #pragma unroll 1
-                        for (int k = NB - cnt; k < NB; k++) {
-                            uint32_t qk = qv[0], nk = n4[0];
+                    for (int k = NB - cnt; k < NB; k++) {
+                        uint32_t qk = qv[0], nk = n4[0];
+                        int32_t tk = gt[0], lk = gn[0];
 #pragma unroll
-                            for (int kk = 1; kk < NB; kk++) if (k == kk) { qk = qv[kk]; nk = n4[kk]; }
-                            if ((rare >> k) & 1u) rare_item(qk, nk, 15u);
-                        }
-                    }
-                    continue;
-                }
-                // ---- an item that covers a part of the positions (an indel or a read end inside them, the chunk's last tile): the
-                //      same update under a mask of cells
-                const int gl = (int)__builtin_ctzll(m);
-                m &= m - 1;
-                // (its words were asked for when the partial item in front of it was done; now the next one's are)
-                const uint32_t qraw = pq, sraw = pn, braw = pc;
-                if (gl == pl) part_issue(m);
-                const int32_t g_tlo = lane_val(tlo, gl);
-                const uint32_t g_lf = (uint32_t)lane_val((int)lf, gl);
-                const uint32_t g_fl = g_lf >> 16, g_len = g_lf & 0xffffu, g_hap = (g_fl >> NQI_HAP_SHIFT) & 3u;
-                // this lane's cells of the piece: columns jlo .. jhi - 1
-                const int32_t jlo = min(max(g_tlo - P0, 0), 4), jhi = (int32_t)min(max((int64_t)g_tlo + g_len - P0, (int64_t)0), (int64_t)4);
-                const uint32_t c4 = (jhi > jlo ? (((1u << (jhi - jlo)) - 1u) << jlo) : 0u) & valid4;
-                // an insertion in front of the piece is counted at its first position
-                if ((g_fl & NQI_INS) && P0 <= g_tlo && g_tlo < P0 + 4 && ((c4 >> (g_tlo - P0)) & 1u)) fl |= 1u << (NQF_INDEL + (g_tlo - P0));
-                if ((g_fl & NQI_TYPE) == NQI_DEL) { fl |= c4 << NQF_INDEL; continue; }
-                if ((g_fl & NQI_TYPE) != NQI_MATCH || !__ballot(c4 != 0)) continue;
-                uint32_t qv1 = 0x01010101u, n41 = 0, cb1 = 0;
-                if (c4) {
-                    // the loaded words begin at the lane's first cell, query base ks of the arrays: brought to the columns' places
-                    const uint32_t ks_lo = (uint32_t)lane_val((int)kq, gl) + (uint32_t)(P0 + jlo);
-                    const uint32_t js = (uint32_t)(jlo & 3);
-                    qv1 = (qraw << (8 * js)) | ~(0xffffffffu << (8 * js));      // (bytes in front: not zero)
-                    n41 = ((__builtin_bswap32(sraw) >> ((ks_lo & 1u) ? 12u : 16u)) & 0xffffu) >> (4 * js);
-                    cb1 = (((braw >> (ks_lo & 7u)) & 15u) << js) & c4;
-                    if (phase) {
-                        if (g_hap == HAP_0) h0b += nq_spread4(c4);
-                        else if (g_hap == HAP_1) h1b += nq_spread4(c4);
-                        else cb1 = 0;
+                        for (int kk = 1; kk < NB; kk++) if (k == kk) { qk = qv[kk]; nk = n4[kk]; tk = gt[kk]; lk = gn[kk]; }
+                        if ((rare >> k) & 1u) rare_item(qk, nk, lk ? (nq_cells(P0, tk, lk) & valid4) : 15u);
                     }
                 }
-                const uint32_t keep = (c4 & 1u ? 0xf000u : 0u) | (c4 & 2u ? 0x0f00u : 0u) | (c4 & 4u ? 0x00f0u : 0u) | (c4 & 8u ? 0x000fu : 0u);
-                const uint32_t x = (n41 ^ ref4) | (ref4 >> 16);
-                tri4b += nq_spread4(cb1);
-                nq_pair<0>(R0[0], R1[0], R2[0], nref[0], R0[1], R1[1], R2[1], nref[1], qv1, x | ~keep, lut);
-                nq_pair<2>(R0[2], R1[2], R2[2], nref[2], R0[3], R1[3], R2[3], nref[3], qv1, x | ~keep, lut);
-                if (__builtin_expect(__ballot(((x & keep) | nq_zero_bytes(qv1)) != 0) != 0, 0)) rare_item(qv1, n41, c4);
             }
             // ---- the batch's byte counters into the columns' words
 #pragma unroll
