@@ -423,10 +423,14 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 }
                 const uint32_t rj = (fl >> (NQF_RAL + 2 * j)) & 3u;
                 const uint32_t a_ = min(cell - (cell > rj ? 1u : 0u), 2u);   // allele c sits in slot c - (c > ref)
-                pool.S[a_][slot] = pool.S[a_][slot] + s_lut[q];
-                pool.S[3 + a_][slot] = pool.S[3 + a_][slot] + s_lut[257 + q];
-                pool.S[6 + a_][slot] = pool.S[6 + a_][slot] + s_lut[514 + q];
-                pool.cnt[cell][slot] = pool.cnt[cell][slot] + 1u;
+                // (the seven reads first, then the writes: written as three updates in a row the compiler keeps them in order)
+                const double s0 = pool.S[a_][slot], s1 = pool.S[3 + a_][slot], s2 = pool.S[6 + a_][slot];
+                const double l0 = s_lut[q], l1 = s_lut[257 + q], l2 = s_lut[514 + q];
+                const uint32_t c0 = pool.cnt[cell][slot];
+                pool.S[a_][slot] = s0 + l0;
+                pool.S[3 + a_][slot] = s1 + l1;
+                pool.S[6 + a_][slot] = s2 + l2;
+                pool.cnt[cell][slot] = c0 + 1u;
             }
         };
 
@@ -552,6 +556,7 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 if (__builtin_expect(__ballot(rare != 0) != 0, 0)) {
 #pragma unroll 1
                     for (int k = NB - cnt; k < NB; k++) {
+                        if (!__ballot((rare >> k) & 1u)) continue;
                         uint32_t qk = qv[0], nk = n4[0];
                         int32_t tk = gt[0], lk = gn[0];
 #pragma unroll
@@ -582,31 +587,40 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
         //      for the lane's four columns, what is rare behind a test of the whole wave.  The counters nearly every position
         //      adds to are summed over the lane's columns and the wave first
         uint32_t w1 = 0, w2 = 0, w6 = 0, w13 = 0;
+#ifndef NQ_CLS_UNROLL
+#define NQ_CLS_UNROLL 0
+#endif
+#if NQ_CLS_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int j = 0; j < 4; j++) {
-            const uint32_t code = (uint32_t)codes & 0xffffu;
-            const uint32_t tri_sum = tri[0];
-            const bool cls = ((fl >> NQF_CLS) & 1u) && tri_sum != 0;
+            constexpr bool rot = !NQ_CLS_UNROLL;
+            const int jj = rot ? 0 : j;
+            const uint32_t code = (uint32_t)(codes >> (rot ? 0 : 16 * j)) & 0xffffu;
+            const uint32_t tri_sum = tri[jj];
+            const bool cls = ((fl >> (NQF_CLS + (rot ? 0 : j))) & 1u) && tri_sum != 0;
             uint32_t h0 = 0, h1 = 0;
-            if (phase) { h0 = h0g[0]; h1 = h1g[0]; }
+            if (phase) { h0 = h0g[jj]; h1 = h1g[jj]; }
             const bool hapfail = phase && cls && !((int32_t)h0 >= min_hap && (int32_t)h1 >= min_hap);
-            const bool q0 = cls && !hapfail && ((fl >> NQF_ZERO) & 1u);
+            const bool q0 = cls && !hapfail && ((fl >> (NQF_ZERO + (rot ? 0 : j))) & 1u);
             bad |= q0 ? (1 << HIMUT_ERR_BQ0) : 0;
             const bool open = cls && !hapfail && !q0;
-            const uint32_t slot = slotmap & 255u;
+            const uint32_t slot = (slotmap >> (rot ? 0 : 8 * j)) & 255u;
             // Nothing but the reference allele in the column: the ten genotype sums are four numbers (an allele that was not
             // seen adds +0.0 to a sum, which leaves it bit for bit what it was).  When hom-ref is the smallest by itself it
             // is the genotype and the quality is the gap to the smallest of the rest; any other outcome, and any column
             // with another allele, goes to k_norm_dirty.
-            const double pa = -10.0 * (R0[0] + pr0), pb = -10.0 * (R1[0] + pr1);
-            const double pc_ = -10.0 * (R2[0] + pr2), pd = -10.0 * (R2[0] + pr3);
+            const double pa = -10.0 * (R0[jj] + pr0), pb = -10.0 * (R1[jj] + pr1);
+            const double pc_ = -10.0 * (R2[jj] + pr2), pd = -10.0 * (R2[jj] + pr3);
             const double nxt = fmin(pb, fmin(pc_, pd));
             const bool mine = open && slot == 255u && pa < nxt;
             const double gqf = nxt - pa;
             const int gq = (gqf < 99.0) ? (int)gqf : 99;
-            const bool indel = (fl >> NQF_INDEL) & 1u;
+            const bool indel = (fl >> (NQF_INDEL + (rot ? 0 : j))) & 1u;
             // (depths beyond 2^31 do not occur; the thresholds are 32-bit)
-            const int slotn = indel ? 7 : (int32_t)nref[0] > md_thr ? 8 : gq < min_gq ? 10 : (int32_t)nref[0] < min_ref ? 9 : 13;
+            const int slotn = indel ? 7 : (int32_t)nref[jj] > md_thr ? 8 : gq < min_gq ? 10 : (int32_t)nref[jj] < min_ref ? 9 : 13;
             w1 += (mine || hapfail) ? tri_sum : 0u;
             w2 += hapfail ? tri_sum : 0u;
             w6 += mine ? tri_sum : 0u;
@@ -644,8 +658,8 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                 if (left) {
                     if ((int64_t)at < dirty_cap) {
                         NormDirty* d = dirty + (dregion * dirty_cap + at);
-                        d->rpos = (int64_t)P0 + j; d->nref = nref[0]; d->tri_sum = tri_sum; d->n_ins = indel ? 1u : 0u; d->n_del = 0; d->h0 = h0; d->h1 = h1;
-                        d->R[0] = R0[0]; d->R[1] = R1[0]; d->R[2] = R2[0];
+                        d->rpos = (int64_t)P0 + j; d->nref = nref[jj]; d->tri_sum = tri_sum; d->n_ins = indel ? 1u : 0u; d->n_del = 0; d->h0 = h0; d->h1 = h1;
+                        d->R[0] = R0[jj]; d->R[1] = R1[jj]; d->R[2] = R2[jj];
                         if (slot != 255u) {
 #pragma unroll
                             for (int k = 0; k < 4; k++) d->cnt[k] = pool.cnt[k][slot];
@@ -660,13 +674,14 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                     } else *dirty_over = 1;          // more of them than there is room for: the host repeats the contig with k_norm_tile
                 }
             }
-            // the next column into place
-            R0[0] = R0[1]; R0[1] = R0[2]; R0[2] = R0[3]; R1[0] = R1[1]; R1[1] = R1[2]; R1[2] = R1[3];
-            R2[0] = R2[1]; R2[1] = R2[2]; R2[2] = R2[3];
-            nref[0] = nref[1]; nref[1] = nref[2]; nref[2] = nref[3]; tri[0] = tri[1]; tri[1] = tri[2]; tri[2] = tri[3];
-            if (phase) { h0g[0] = h0g[1]; h0g[1] = h0g[2]; h0g[2] = h0g[3]; h1g[0] = h1g[1]; h1g[1] = h1g[2]; h1g[2] = h1g[3]; }
-            fl = (fl >> 1) & 0x77007u;                       // (the one-bit fields move down; the alleles are not looked at here)
-            slotmap >>= 8; codes >>= 16;
+            if (rot) {                                       // the next column into place
+                R0[0] = R0[1]; R0[1] = R0[2]; R0[2] = R0[3]; R1[0] = R1[1]; R1[1] = R1[2]; R1[2] = R1[3];
+                R2[0] = R2[1]; R2[1] = R2[2]; R2[2] = R2[3];
+                nref[0] = nref[1]; nref[1] = nref[2]; nref[2] = nref[3]; tri[0] = tri[1]; tri[1] = tri[2]; tri[2] = tri[3];
+                if (phase) { h0g[0] = h0g[1]; h0g[1] = h0g[2]; h0g[2] = h0g[3]; h1g[0] = h1g[1]; h1g[1] = h1g[2]; h1g[2] = h1g[3]; }
+                fl = (fl >> 1) & 0x77007u;                   // (the one-bit fields move down; the alleles are not looked at here)
+                slotmap >>= 8; codes >>= 16;
+            }
         }
         {
             const uint32_t s1 = (uint32_t)lane_val(wave_incl_add((int)w1, lane), 63);
