@@ -166,7 +166,7 @@ def _pmc(name):
         return None
 
 
-def leg_normcounts(ctx, sample, chunks, params, pon, com, steps, cpu=True, cpu_sample_mb=2.0):
+def leg_normcounts(ctx, sample, chunks, params, pon, com, steps, cpu=True, cpu_sample_mb=16.0):
     """himut normcounts' per-contig worker (normcounts.py:206-421) on the resident contig: K passes of
     himut_run_normcounts."""
     import numpy as np
@@ -255,13 +255,14 @@ def leg_edges(ctx, sample, steps, cpu=True):
                         "note": "scattered 64-byte sectors and atomics: bound by the random-access rate, not by bytes"}}
     if cpu:
         from oracle import oracle as O
-        n, sub = _prefix_batch(b, 8_000_000)
-        sh = [h for h in hets if h[0] < 8_100_000]
+        span = min(b.length, 64_000_000)                      # (about 2 s of one core: the whole of a chr20-sized contig)
+        n, sub = _prefix_batch(b, span)
+        sh = [h for h in hets if h[0] < span + 100_000]
         t0 = time.perf_counter()
         O.edges(sub, sh, 20, 20)
         dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": min(8.0, b.length / 1e6) / dt, "unit": "Mbp/s", "cores": 1, "kind": "port",
-                               "sample": "reads of the first 8 Mb ({}), oracle orc_edges single thread, {:.1f} s".format(n, dt)}
+        out["cpu_baseline"] = {"value": span / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "port",
+                               "sample": "reads of the first {:.0f} Mb ({}), oracle orc_edges single thread, {:.1f} s".format(span / 1e6, n, dt)}
     return out
 
 

@@ -45,7 +45,7 @@ def pmc_avg(d, counter):
 # kernels whose reads are wide coalesced streams (16 bytes per lane): FETCH_SIZE on gfx950 reports half of their bytes.
 # (k_parse_cs streams the qualities only in its <true> form, which the call path does not use; there its reads are the cs
 # text, 16 bytes per lane as well.)
-STREAMING = ("k_parse_cs", "k_stream_capture")
+STREAMING = ("k_parse_cs", "k_stream_capture", "k_flag_bases")
 # the kernels of one himut_run (bench.py's step): their sum is roofline_step's counter figure
 STEP_KERNELS = ("k_parse_cs", "k_stream_capture", "k_mask_emit", "k_eval_columns", "k_block_sums", "k_block_table3", "k_scan_small",
                 "k_finalize_flags", "k_compact", "k_run_totals", "k_window_index", "k_read_hap")

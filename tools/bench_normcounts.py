@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--contig-len", type=int, default=64_444_167)
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mb", type=float, default=2.0)
+    ap.add_argument("--cpu-sample-mb", type=float, default=16.0)
     a = ap.parse_args()
     from himut_amd import bamlib, caller, synth, util as hutil
     import bench as B
