@@ -596,12 +596,12 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow, bool defer) {
         }
         CaptureArgs G;
         G.R = R; G.D = D; G.X = X; G.colstore = c->d_colstore.as<uint16_t>(); G.nslots = (int64_t)slot_cap;
-        G.r_begin = 0; G.r_end = c->n; G.callable = nullptr; G.bqsum = c->d_bqsum.as<uint32_t>(); G.err = &sc->err;
+        G.r_begin = 0; G.r_end = c->n; G.bqsum = c->d_bqsum.as<uint32_t>(); G.err = &sc->err;
         // the proposals of a read (read filters, trim / window filters -> mask) are the tail of its capture wave
         G.C = C; G.H = H; G.P = c->params; G.mask = c->d_mask.as<uint32_t>(); G.tilecnt = c->d_tilecnt.as<uint32_t>();
         G.ccs_flag = c->d_ccs.as<uint8_t>();
         stage_event(c, EV_INDEX, 1, st);
-        hipLaunchKernelGGL(k_stream_capture<false>, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
+        hipLaunchKernelGGL(k_stream_capture, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, G);
         stage_event(c, EV_GATHER, 1, st);
     } else {
         stage_event(c, EV_INDEX, 1, st);

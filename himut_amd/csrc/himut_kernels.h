@@ -29,8 +29,6 @@
 //                      set() de-duplication (caller.py:622-624), the totals, the emitted records to the front
 //   k_pile_dense       dense per-position pile (counts + BQ sums for EVERY position of a range): LDS-staged base/BQ
 //                      tiles, one workgroup per tile.  Used by himut_pile_counts.
-//   k_word_popc / k_block_slots / k_block_table / k_fill_bits
-//                      the column index of the normcounts sweep's column-store form (HIMUT_NORM_SWEEP=store)
 //
 // Integer work plus a small fp64 tail; no MFMA.  Wave size 64 throughout.
 #pragma once
@@ -1075,7 +1073,7 @@ __device__ __forceinline__ uint64_t nib16_to_cells(uint64_t x) {
 // One 16-bit slot per (read of the window, position), walked in fetch order:
 //   bits 0-2 cell (0-3 allele A T G C, 4 base outside ATGC, 5 deletion, 7 not in the pile)
 //   bit 3    an insertion precedes the position
-//   bit 4    (normcounts) the base counts as callable for its read (normcounts.py:66-110)
+//   bit 4    unused
 //   bits 8-15 base quality
 // k_stream_capture fills it while streaming every read once with coalesced loads;
 // k_eval_columns consumes it, one thread per candidate.
@@ -1257,47 +1255,8 @@ __device__ __forceinline__ int64_t dev_count(const unsigned long long* n_dev, in
     return n < (unsigned long long)cap ? (int64_t)n : cap;
 }
 
-__global__ void __launch_bounds__(256) k_word_popc(const uint32_t* bits, int64_t nwords, uint32_t* out) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < nwords) out[w] = (uint32_t)__popc(bits[w]);
-}
 
-// slots per 256-position block = candidate positions in it x reads in its window
-__global__ void __launch_bounds__(256) k_block_slots(const uint32_t* rank, int64_t nwords, const int32_t* winlo,
-                                                     const int32_t* winhi, int64_t nblk, uint32_t* out,
-                                                     unsigned long long* total) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long s = 0;
-    if (b < nblk) {
-        const int64_t w0 = min(b * 8, nwords), w1 = min(b * 8 + 8, nwords);
-        s = (unsigned long long)(rank[w1] - rank[w0]) * (unsigned long long)(uint32_t)(winhi[b] - winlo[b]);
-        s = (s + 15ULL) & ~15ULL;      // every block starts on a 32-byte boundary of the column store
-        out[b] = (uint32_t)s;
-    }
-    if (total) {     // the sum in 64 bits: tells the host when the 32-bit offsets have wrapped
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
-    }
-}
 
-// err (optional): HIMUT_ERR_DEPTH when the column store of the contig needs more than 2^32 slots (a block's
-// product or the running offset no longer fits the 32-bit fields) or a window holds more than 2^22 reads
-__global__ void __launch_bounds__(256) k_block_table(const uint32_t* rank, int64_t nwords, const int32_t* winlo,
-                                                     const int32_t* winhi, const uint32_t* boff, int64_t nblk, BlockTab* bt,
-                                                     int* err) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblk) return;
-    BlockTab t;
-    const uint32_t u0 = rank[min(b * 8, nwords)], u1 = rank[min(b * 8 + 8, nwords)];
-    const uint32_t nr = (uint32_t)(winhi[b] - winlo[b]);
-    t.lo = winlo[b]; t.ncnt = nr | ((u1 - u0) << 22); t.boff = boff[b]; t.ufirst = u0;
-    bt[b] = t;
-    if (err) {
-        const unsigned long long s = ((unsigned long long)(u1 - u0) * nr + 15ULL) & ~15ULL;
-        if (nr > BT_N_MASK || s > 0xffffffffULL || (unsigned long long)boff[b] + s > 0xffffffffULL) set_err(err, HIMUT_ERR_DEPTH);
-    }
-}
 
 struct CaptureArgs {
     Reads R;
@@ -1306,7 +1265,6 @@ struct CaptureArgs {
     uint16_t* colstore;
     int64_t nslots;
     int64_t r_begin, r_end;      // reads of this launch
-    const uint32_t* callable;    // normcounts: one bit per query base (bit q of read r at word (qoff[r] + q) >> 5)
     uint32_t* bqsum;             // call path: per read, the sum of the qualities of the whole query (bamlib.py:34-36)
     const int* err;              // a device error raised by an earlier kernel of the run: nothing is captured then
     // call path: the read's proposals follow its stream (propose_read); mask null = none
@@ -1342,15 +1300,11 @@ constexpr int CPD = 2;      // windows in flight (register sets, at most 4); the
 #ifndef HIMUT_CAP_WAVES
 #define HIMUT_CAP_WAVES 7
 #endif
-template <bool NORM>
 __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     __shared__ __align__(16) uint8_t s_bq[4][CWQ];
     __shared__ __align__(16) uint8_t s_sq[4][CWQ / 2];
     __shared__ __align__(16) int4 s_seg[4][CSG + 1];
     __shared__ __align__(16) uint32_t s_bt[4][64];        // 16 block-table entries
-    __shared__ uint32_t s_cb[4][NORM ? 64 : 1];            // normcounts: the window's callable bits
-    __shared__ uint32_t s_wb[4][NORM ? 128 : 1];           // normcounts: the bitmap words under the window
-    __shared__ __align__(16) uint16_t s_out[4][NORM ? 1024 : 8];   // normcounts: the cells of 1024 positions, one 32-byte row per lane
     __shared__ uint2 s_list[4][CLQ];
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const Reads& R = A.R;
@@ -1362,7 +1316,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     const int32_t qlen = uni(R.qlen[r]);
     if (uni(Mv.flags) & RF_SECONDARY) return;
     if (uni(Mv.nseg) <= 0) {                 // nothing aligned (an empty cs tag): only the quality sum is wanted
-        if constexpr (!NORM) {
+        {
             if (A.bqsum) {
                 const uint8_t* q = R.bq + uni(Mv.qoff);
                 uint32_t sum = 0;
@@ -1398,21 +1352,17 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
 #define CAP_LANDED4(V) asm volatile("" : "+v"(V.x), "+v"(V.y), "+v"(V.z), "+v"(V.w))
 #define CAP_LANDED2(V) asm volatile("" : "+v"(V.x), "+v"(V.y))
     // the five loads of one window (addresses clamped into the read, so every lane always loads)
-#define CAP_ISSUE(BA, BB, SQ, S1, BT, CB, K, TA) do { \
+#define CAP_ISSUE(BA, BB, SQ, S1, BT, K, TA) do { \
         const int32_t _c = c0 + min((K), nwin - 1) * CWQ; \
         const int32_t _qa = min(_c + lane * 16, qpad - 16), _qb = min(_c + 1024 + lane * 16, qpad - 16), _qs = min(_c + lane * 32, qpad - 32); \
         BA = *reinterpret_cast<const uint4*>(R.bq + qo + _qa); \
         BB = *reinterpret_cast<const uint4*>(R.bq + qo + _qb); \
         SQ = *reinterpret_cast<const uint4*>(R.seq + ((qo + _qs) >> 1)); \
-        if (NORM) {   /* dense: words (TA >> 5) + lane and + 64 + lane, word aligned */ \
-            S1.x = X.bits[min((int64_t)((TA) >> 5) + lane, X.nwords - 1)]; \
-            S1.y = X.bits[min((int64_t)((TA) >> 5) + 64 + lane, X.nwords - 1)]; \
-        } else { \
+        { \
             const int64_t _w = min(((int64_t)(TA) + CPL * lane) >> 5, X.nwords - 1); \
             __builtin_memcpy(&S1, X.bits + _w, 8);             /* nwords + 2 words are allocated */ \
         } \
         BT = reinterpret_cast<const uint32_t*>(X.bt + min((int64_t)((TA) >> 8) + (lane >> 2), X.nblk - 1))[lane & 3]; \
-        if (NORM) CB = A.callable[((qo + min(_c, qpad - 32)) >> 5) + min(lane, ((qpad - 1 - min(_c, qpad - 32)) >> 5))]; \
     } while (0)
 #define CAP_SEGWIN() do { if (lane <= nw) { int4 z = make_int4(0x7fffffff, 0, 0, 0); if (jb + lane < ns) z = *reinterpret_cast<const int4*>(gsegs + jb + lane); \
         lseg[lane] = z; } } while (0)
@@ -1423,8 +1373,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     uint4 ba0, bb0, sq0, ba1, bb1, sq1, ba2, bb2, sq2, ba3, bb3, sq3;
     uint2 s10, s11, s12, s13;
     uint32_t bt0r, bt1r, bt2r, bt3r;
-    uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
-    CAP_ISSUE(ba0, bb0, sq0, s10, bt0r, cb0, 0, tstart);
+    CAP_ISSUE(ba0, bb0, sq0, s10, bt0r, 0, tstart);
     // rank of the first column position at or behind tstart: the block's first rank + the bits in front of tstart
     const uint32_t rk0 = uni(X.bt[min((int64_t)(tstart >> 8), X.nblk - 1)].ufirst) +
                          uni(pos_rank_in_block(X.bits, (int32_t)min((int64_t)tstart, (X.nblk << 8) - 1) & ~31));
@@ -1458,10 +1407,10 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     int32_t ta[5];
     ta[0] = tstart;
     ta[1] = window_end(0);
-    CAP_ISSUE(ba1, bb1, sq1, s11, bt1r, cb1, 1, ta[1]);
+    CAP_ISSUE(ba1, bb1, sq1, s11, bt1r, 1, ta[1]);
     ta[2] = window_end(1);
-    if constexpr (CPD > 2) { CAP_ISSUE(ba2, bb2, sq2, s12, bt2r, cb2, 2, ta[2]); ta[3] = window_end(2); }
-    if constexpr (CPD > 3) { CAP_ISSUE(ba3, bb3, sq3, s13, bt3r, cb3, 3, ta[3]); ta[4] = window_end(3); }
+    if constexpr (CPD > 2) { CAP_ISSUE(ba2, bb2, sq2, s12, bt2r, 2, ta[2]); ta[3] = window_end(2); }
+    if constexpr (CPD > 3) { CAP_ISSUE(ba3, bb3, sq3, s13, bt3r, 3, ta[3]); ta[4] = window_end(3); }
     // rank of the first candidate position at or behind tstart
     uint32_t ubase = 0;
     {
@@ -1472,8 +1421,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     int head = 0, n = 0;   // the list: entries head .. head + n - 1 (mod CLQ)
     int jcur = 0;          // segment cursor of the candidate walk
 
-    uint32_t* wcb = s_cb[wv];
-    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint2& s1, uint32_t& btv, uint32_t& cbv, const int k) {
+    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint2& s1, uint32_t& btv, const int k) {
         const int32_t tA = ta[0], tB = ta[1];
         const int32_t cq = c0 + k * CWQ;
         // ---- this window's bytes and tables -> LDS; its registers take window k + 2
@@ -1481,8 +1429,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
         *reinterpret_cast<uint4*>(wbq + 1024 + lane * 16) = bb;
         *reinterpret_cast<uint4*>(wsq + lane * 16) = sq;
         lbt[lane] = btv;                                   // lane = entry * 4 + field
-        if (NORM) wcb[lane] = cbv;
-        if constexpr (!NORM) {
+        {
             // np.mean(bq_int_lst) of caller.py:310 / bamlib.py:34-36: the bytes are here anyway.  A window behind the
             // read (k >= nwin) holds a reloaded copy of the last one; bytes behind qlen are masked off
             if (k < nwin) {
@@ -1509,7 +1456,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
         uint32_t mylo, myhi;
         asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mylo), "=&v"(myhi) : "v"(s1.x), "v"(s1.y));
         const unsigned long long mybits = ((unsigned long long)myhi << 32) | mylo;
-        CAP_ISSUE(ba, bb, sq, s1, btv, cbv, k + CPD, ta[CPD]);
+        CAP_ISSUE(ba, bb, sq, s1, btv, k + CPD, ta[CPD]);
         const int32_t ta_next = window_end(k + CPD);
         __builtin_amdgcn_wave_barrier();
         const int64_t btb = tA >> 8;
@@ -1548,7 +1495,6 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
                     const uint32_t qv = wbq[o], sb = wsq[o >> 1];
                     const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
                     val = insb | (uint32_t)nib2allele(nib) | (qv << 8);
-                    if (NORM) val |= ((wcb[o >> 5] >> (o & 31)) & 1u) << 4;
                 }
                 if (store) {
                     const int64_t bi = (int64_t)(rpos >> 8) - btb;
@@ -1561,107 +1507,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
                 }
             }
         };
-        if constexpr (NORM) {
-            // ---- dense: (nearly) every position of [tA, tB) is a candidate, so lane = position, 64 at a time; the
-            // bitmap words under the window sit in LDS, the rank is a running count
-            uint32_t* wb = s_wb[wv];
-            wb[lane] = mylo; wb[64 + lane] = myhi;
-            __builtin_amdgcn_wave_barrier();
-            const int64_t wbase = tA >> 5;
-            // generic form: lane = position, 64 at a time, rank from a running count
-            auto generic = [&](const int32_t x0, const int32_t x1) {
-                for (int32_t pg = x0; pg < x1; pg += 64) {
-                    const int32_t p = pg + lane;
-                    bool bit = false;
-                    if (p < x1) {
-                        const int64_t wi = ((int64_t)p >> 5) - wbase;
-                        uint32_t word;
-                        if (wi < 128) word = wb[wi];
-                        else { word = X.bits[min((int64_t)p >> 5, X.nwords - 1)]; asm volatile("" : "+v"(word)); }   // long deletions
-                        bit = (word >> (p & 31)) & 1u;
-                    }
-                    const unsigned long long m = __ballot(bit);
-                    if (!m) continue;
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    batch(bit, (uint32_t)p, ubase + below, pg + 63 - (int)__builtin_clzll(m));
-                    ubase += (uint32_t)__popcll(m);
-                }
-            };
-            // Pieces of 1024 positions, aligned to 16: lane l owns positions P + 16 l .. + 15, which lie in one
-            // 256-position block.  Where every block under the piece is full (all 256 positions are candidates),
-            // a position's column index is its offset in the block, the lane's 16 cells are 32 contiguous,
-            // 32-byte aligned bytes of the column store, and the piece goes out as two 16-byte stores per lane.
-            uint16_t* ob = s_out[wv];
-            for (int32_t P = tA & ~15; P < tB; P += 1024) {
-                const int32_t x0 = max(P, tA), x1 = min(P + 1024, tB);
-                const int32_t p = P + 16 * lane;
-                const bool valid = p < x1 && p + 16 > x0;
-                uint4 bt = make_uint4(0, 256u << 22, 0, 0);
-                if (valid) {
-                    const int64_t bi = (int64_t)(p >> 8) - btb;
-                    if (bi >= 0 && bi < 16) bt = *reinterpret_cast<const uint4*>(lbt + 4 * bi);
-                    else { bt = *reinterpret_cast<const uint4*>(X.bt + min((int64_t)(p >> 8), X.nblk - 1)); CAP_LANDED4(bt); }
-                }
-                if (__ballot(valid && (bt.y >> 22) != 256u)) { generic(x0, x1); continue; }   // a block at a chunk edge
-                {
-                    const uint4 e = make_uint4(0x00070007u, 0x00070007u, 0x00070007u, 0x00070007u);   // CELL_EMPTY
-                    reinterpret_cast<uint4*>(ob)[2 * lane] = e;
-                    reinterpret_cast<uint4*>(ob)[2 * lane + 1] = e;
-                }
-                __builtin_amdgcn_wave_barrier();
-                int j = jcur;
-                while (j < ns) {
-                    if (j < jb || j >= jb + nw) {        // lists longer than the LDS window: reload it from j
-                        jb = j; nw = min(ns - jb, CSG);
-                        __builtin_amdgcn_wave_barrier();
-                        CAP_SEGWIN();
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    const int4 sv = lseg[j - jb];
-                    const int32_t t0 = uni(sv.x), q0 = uni(sv.y), len = uni(sv.z);
-                    const uint32_t fl = (uint32_t)uni(sv.w);
-                    if (t0 >= x1) break;
-                    const int32_t span = len > 0 ? len : ((fl & SEG_INS) ? 1 : 0);      // a trailing insertion marks one position
-                    if (t0 + span > x0) {
-                        const int32_t a = max(max(p, x0), t0), b = min(min(p + 16, x1), t0 + span);
-                        if (fl & SEG_DEL) {
-                            for (int32_t i = a; i < b; i++) ob[i - P] = (uint16_t)(CELL_DEL | ((i == t0 && (fl & SEG_INS)) ? CELL_INS : 0u));
-                        } else if (len == 0) {
-                            if (a < b) ob[t0 - P] = (uint16_t)(CELL_EMPTY | CELL_INS);
-                        } else {
-                            for (int32_t i = a; i < b; i++) {
-                                const int32_t q = q0 + (i - t0);
-                                const int32_t o = (q - cq) & (CWQ - 1);             // inside the window by construction
-                                const uint32_t qv = wbq[o], sb = wsq[o >> 1];
-                                const int nib = (q & 1) ? (int)(sb & 15u) : (int)(sb >> 4);
-                                uint32_t val = (uint32_t)nib2allele(nib) | (qv << 8) | (((wcb[o >> 5] >> (o & 31)) & 1u) << 4);
-                                if (i == t0 && (fl & SEG_INS)) val |= CELL_INS;
-                                ob[i - P] = (uint16_t)val;
-                            }
-                        }
-                    }
-                    j++;
-                }
-                jcur = max(j - 1, jcur);
-                __builtin_amdgcn_wave_barrier();
-                if (valid) {
-                    // BlockTab: x = lo, y = n | cnt << 22, z = boff (a multiple of 16), w = ufirst
-                    const int64_t slot = (int64_t)bt.z + (int64_t)(r - (int32_t)bt.x) * 256 + (p & 255);
-                    if (p >= x0 && p + 16 <= x1) {
-                        if (slot + 16 <= A.nslots) {
-                            uint4* dst = reinterpret_cast<uint4*>(A.colstore + slot);
-                            dst[0] = reinterpret_cast<const uint4*>(ob)[2 * lane];
-                            dst[1] = reinterpret_cast<const uint4*>(ob)[2 * lane + 1];
-                        }
-                    } else {
-                        for (int32_t i = max(p, x0); i < min(p + 16, x1); i++)
-                            if (slot + (i - p) < A.nslots) A.colstore[slot + (i - p)] = ob[i - P];
-                    }
-                }
-                ubase += (uint32_t)(x1 - x0);
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
+        {
         // ---- candidate bits of [tA, tB): lane l takes the CPL positions from tA + CPL * l
         for (int32_t pg = tA; pg < tB; pg += 64 * CPL) {
             const int32_t p0 = pg + CPL * lane;
@@ -1723,12 +1569,12 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     // CPD windows per trip, each with its own registers; the last ones of a trip may lie behind the
     // read (empty range): it still issues its loads, so the number in flight never depends on the path
     for (int k = 0; k < nwin; k += CPD) {
-        window(ba0, bb0, sq0, s10, bt0r, cb0, k);
-        window(ba1, bb1, sq1, s11, bt1r, cb1, k + 1);
-        if constexpr (CPD > 2) window(ba2, bb2, sq2, s12, bt2r, cb2, k + 2);
-        if constexpr (CPD > 3) window(ba3, bb3, sq3, s13, bt3r, cb3, k + 3);
+        window(ba0, bb0, sq0, s10, bt0r, k);
+        window(ba1, bb1, sq1, s11, bt1r, k + 1);
+        if constexpr (CPD > 2) window(ba2, bb2, sq2, s12, bt2r, k + 2);
+        if constexpr (CPD > 3) window(ba3, bb3, sq3, s13, bt3r, k + 3);
     }
-    if constexpr (!NORM) {
+    {
         if (A.bqsum) {
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) qsum += __shfl_down(qsum, d, 64);
@@ -1751,8 +1597,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
 #undef CAP_LANDED2
 }
 
-template <bool NORM>
-__global__ void __launch_bounds__(256, NORM ? 1 : HIMUT_CAP_WAVES) k_stream_capture(CaptureArgs A) { capture_wave<NORM>(A); }
+__global__ void __launch_bounds__(256, HIMUT_CAP_WAVES) k_stream_capture(CaptureArgs A) { capture_wave(A); }
 
 // ---------------------------------------------------------------------------------------
 // k_eval_columns: one THREAD per candidate column: walks the column's slots in fetch
