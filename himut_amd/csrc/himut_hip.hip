@@ -130,6 +130,7 @@ struct himut_ctx {
     DevBuf d_refseq, d_live, d_callable, d_dirty, d_dcount, d_redo, d_plan, d_plancnt, d_tri;
     int dbg_norm_sweep = 0, dbg_norm_pool = 0;     // himut_debug_normcounts (tests)
     int64_t dbg_norm_dirty_cap = 0;
+    int64_t norm_dirty_room = 0;                   // positions per part of k_norm_dirty's list an earlier pass of this context needed
     int64_t reflen = 0;
     uint8_t ref_cls[256] = {};
     int ref_K = 0;
@@ -1258,7 +1259,7 @@ int himut_copy_records_to_device(himut_ctx* c, void* dst, int64_t capacity_recor
 
 namespace {
 
-int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool force_tile = false) {
+int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool force_tile = false, int attempt = 0) {
     if (!c->have_params) return fail(c, HIMUT_ERR_ARG, "himut_set_params has not been called");
     if (!c->have_lut) return fail(c, HIMUT_ERR_ARG, "himut_set_gt_lut has not been called");
     if (!c->have_reads) return fail(c, HIMUT_ERR_ARG, "himut_push_reads has not been called");
@@ -1305,8 +1306,11 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     const int64_t q_regions = (int64_t)q_gx * (int64_t)std::max<int64_t>(T.n, 1);
     const int64_t q_tiles_per_wg = (q_per + (q_gx / 8) - 1) / (q_gx / 8);
     int64_t dirty_cap = std::max<int64_t>(q_tiles_per_wg * NQ_WG_COLS / 6, 128);
-    if (c->dbg_norm_dirty_cap > 0) dirty_cap = c->dbg_norm_dirty_cap;           // (tests: the overflow path)
-    const unsigned redo_cap = (unsigned)std::min<int64_t>(T.positions / NQ_COLS / 16 + 1024, 1 << 24);   // tiles left to k_norm_tile: room for one in sixteen
+    dirty_cap = std::min<int64_t>(std::max(dirty_cap, c->norm_dirty_room), q_tiles_per_wg * NQ_WG_COLS);
+    if (c->dbg_norm_dirty_cap > 0 && attempt == 0) dirty_cap = c->dbg_norm_dirty_cap;   // (tests: the first pass overflows)
+    // tiles left to k_norm_tile (more pieces than the plan holds, more columns with another allele than a wave's pool): room for
+    // every tile of the contig
+    const unsigned redo_cap = (unsigned)std::min<int64_t>((int64_t)std::max<int64_t>(T.n, 1) * blocks_for(maxspan, NQ_COLS) + 64, (int64_t)1 << 28);
     if (sweep_quad) {
         c->d_dirty.reserve((size_t)dirty_cap * (size_t)q_regions * sizeof(NormDirty) + 256);
         c->d_dcount.reserve((size_t)q_regions * 4 + 256);
@@ -1401,9 +1405,20 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     HCHECK(hipMemcpyAsync(c->h_tri.data(), c->d_tri.p, (2 * ntri + 16) * 8, hipMemcpyDeviceToHost, st));
     HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
     HCHECK(hipStreamSynchronize(st));
-    // one of the two lists was too short: the whole contig again with k_norm_tile
-    if ((hs.dirty_over || hs.nredo > redo_cap) && !force_tile) return do_normcounts(c, alt_order, non_human, true);
-    c->stats.reran = force_tile ? 1 : 0;
+    // The list of positions left to k_norm_dirty was too short in some part (a region where more than one position in six
+    // holds another allele: deep piles, a sample far from the reference): the same sweep once more with the room the
+    // counters say it needs -- the context keeps it for its later passes, as himut_run keeps its capacities.  The list of
+    // tiles was too short (or the room still is, which the counters rule out): the whole contig with k_norm_tile.
+    if (hs.dirty_over && !force_tile && attempt == 0 && hs.nredo <= redo_cap) {
+        std::vector<uint32_t> need((size_t)q_regions);
+        HCHECK(hipMemcpy(need.data(), c->d_dcount.p, (size_t)q_regions * 4, hipMemcpyDeviceToHost));
+        uint32_t mx = 0;
+        for (uint32_t v : need) mx = std::max(mx, v);
+        c->norm_dirty_room = (int64_t)mx + (int64_t)mx / 8 + 64;
+        return do_normcounts(c, alt_order, non_human, false, 1);
+    }
+    if ((hs.dirty_over || hs.nredo > redo_cap) && !force_tile) return do_normcounts(c, alt_order, non_human, true, attempt + 1);
+    c->stats.reran = (force_tile || attempt > 0) ? 1 : 0;
     if (hs.err) return check_device_err(c, hs.err);
     c->h_tri[2 * ntri + 0] = hs.nccs;
     float f = 0;

@@ -699,7 +699,7 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
         __builtin_amdgcn_wave_barrier();           // (the pool is handed out anew by the next tile)
     }
     __syncthreads();
-    if (tid == 0) dcount[dregion] = min(s_ndirty, (unsigned int)min(dirty_cap, (int64_t)0x7fffffff));
+    if (tid == 0) dcount[dregion] = s_ndirty;      // (what was asked for: k_norm_dirty stops at the part's room, the host sizes a second pass by it)
     if (tid < 14 && s_log[tid]) atomicAdd(&A.log[tid], (unsigned long long)s_log[tid]);
     if (tid < 32 && s_bins[tid]) {
         const int cl[4] = {A.cA, A.cC, A.cG, A.cT};

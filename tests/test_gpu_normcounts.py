@@ -107,8 +107,9 @@ def test_normcounts_golden_tile_sweep(worker, case):
 @pytest.mark.parametrize("case", ["norm_dense", "norm_sets", "norm_phase"])
 def test_normcounts_left_over_positions_do_not_fit(worker, case):
     """k_norm_quad hands the positions it does not classify itself (a column with another allele) to k_norm_dirty through
-    a list sized for one position in eight; when the list is too short the contig is repeated with k_norm_tile.  A list
-    with one entry per part, the same golden vectors."""
+    a list with a part per workgroup, sized for one position in six; when a part is too short the sweep is repeated once
+    with the room its counters ask for, and the context keeps that room.  A list with one entry per part: the same golden
+    vectors, one repeat."""
     reran, _ = _golden_with(worker, case, dirty_cap=1)
     assert reran == 1
 
@@ -120,6 +121,26 @@ def test_normcounts_pool_runs_out(worker, case, slots):
     tile of the goldens goes that way: the same vectors, no repeat of the contig."""
     reran, redo = _golden_with(worker, case, pool_slots=slots)
     assert reran == 0 and redo > 0
+
+
+def test_normcounts_noisy_contig_goes_tile_by_tile_to_the_tile_kernel(worker):
+    """Reads with one error in 120 bases at 35x: a quarter of the positions hold another allele, more than a wave of
+    k_norm_quad has accumulators for (32 of its 256 columns), so nearly every tile is listed for k_norm_tile -- the list
+    has room for every tile of the contig: no repeat of the contig, the oracle's counts."""
+    from oracle import oracle as O
+    from himut_amd import normcounts, synth, util as hutil
+    s = synth.generate(synth.SynthConfig(seed=46, contig_len=150_000, depth=35.0, sub_rate=8e-3, name="chrZ"), want_ref=True)
+    refseq = bytes(s.ref)
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((s.batch.name, 0, s.batch.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=9000, qlen_upper_limit=22500, md_threshold=60, min_sequence_identity=0.9)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+    o_ccs, o_ref, o_log = O.normcounts(s.batch, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+    _configure(worker, p)
+    ccs, rf, log = normcounts.norm_contig(worker, s.batch, chunks, refseq, alt_order=order)
+    st = worker.ctx.stats()
+    assert log == o_log and ccs == o_ccs and rf == o_ref
+    assert st["reran"] == 0 and st["column_slots"] > 150_000 // 256 // 2
 
 
 def test_normcounts_soft_clips_and_failing_reads(worker):
