@@ -37,7 +37,7 @@ namespace himut {
 constexpr int NQ_WAVES = 4;
 constexpr int NQ_COLS = 256;                       // positions per wave
 constexpr int NQ_WG_COLS = NQ_WAVES * NQ_COLS;     // positions per workgroup and step
-constexpr int NQ_SLOTS = 32;                       // pool of other-allele accumulators per wave
+constexpr int NQ_SLOTS = 64;                       // pool of other-allele accumulators per wave
 constexpr int NQ_Q = HIMUT_NQ_Q;
 
 typedef const __attribute__((address_space(1))) uint8_t* nq_g8;

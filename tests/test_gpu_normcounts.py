@@ -116,7 +116,7 @@ def test_normcounts_left_over_positions_do_not_fit(worker, case):
 
 @pytest.mark.parametrize("case,slots", [("norm_dense", 1), ("norm_sets", 2), ("norm_phase", 1), ("norm_nsub", 1), ("norm_dense", 4)])
 def test_normcounts_pool_runs_out(worker, case, slots):
-    """A wave of k_norm_quad keeps the sums of the alleles that are not the reference's in a pool of 32 accumulators for its
+    """A wave of k_norm_quad keeps the sums of the alleles that are not the reference's in a pool of 64 accumulators for its
     256 columns; a wave that needs more leaves its tile to k_norm_tile through a list.  With one to four slots nearly every
     tile of the goldens goes that way: the same vectors, no repeat of the contig."""
     reran, redo = _golden_with(worker, case, pool_slots=slots)
@@ -124,12 +124,12 @@ def test_normcounts_pool_runs_out(worker, case, slots):
 
 
 def test_normcounts_noisy_contig_goes_tile_by_tile_to_the_tile_kernel(worker):
-    """Reads with one error in 120 bases at 35x: a quarter of the positions hold another allele, more than a wave of
-    k_norm_quad has accumulators for (32 of its 256 columns), so nearly every tile is listed for k_norm_tile -- the list
+    """Reads with one error in 80 bases at 35x: a third of the positions hold another allele, more than a wave of
+    k_norm_quad has accumulators for (64 of its 256 columns), so nearly every tile is listed for k_norm_tile -- the list
     has room for every tile of the contig: no repeat of the contig, the oracle's counts."""
     from oracle import oracle as O
     from himut_amd import normcounts, synth, util as hutil
-    s = synth.generate(synth.SynthConfig(seed=46, contig_len=150_000, depth=35.0, sub_rate=8e-3, name="chrZ"), want_ref=True)
+    s = synth.generate(synth.SynthConfig(seed=46, contig_len=150_000, depth=35.0, sub_rate=1.2e-2, name="chrZ"), want_ref=True)
     refseq = bytes(s.ref)
     chunks = [(c[1], c[2]) for c in hutil.chunkloci((s.batch.name, 0, s.batch.length))]
     p = dict(util.CALL_DEFAULTS)
