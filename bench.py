@@ -251,7 +251,8 @@ def leg_edges(ctx, sample, steps, cpu=True):
            "pair_counts": pairs, "read_hetsnp_lookups": nhits,
            "roofline": {"bound": "hbm", "kernel": "k_parse_cs + k_edges", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
-                        "avg_launch_ms": dev_s * 1e3, "traffic": None,
+                        "avg_launch_ms": dev_s * 1e3, "traffic": (_pmc("pmc_traffic_edges.json") or {}).get("pass_total"),
+                        "traffic_source": "profiles/pmc_traffic_edges.json" if _pmc("pmc_traffic_edges.json") else None,
                         "note": "scattered 64-byte sectors and atomics: bound by the random-access rate, not by bytes"}}
     if cpu:
         from oracle import oracle as O

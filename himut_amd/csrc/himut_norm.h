@@ -243,9 +243,18 @@ struct CalRead {
             // segment, else the segment start
             int32_t osq = sg.y;
             {
-                const int kp = lower(tlo + 1) - 1;
+                // the last entry at or in front of the first base: counted among the entries in registers (those in front of
+                // them lie further back still), a search only when all NE of them do and there are more
+                int le = 0;
+#pragma unroll
+                for (int i = 0; i < NE; i++) le += (ev[i] <= tlo) ? 1 : 0;
+                const int kp = (le == NE && overflow) ? lower(tlo + 1) - 1 : k0 + le - 1;
                 if (kp >= 0) {
-                    const uint32_t pv = ls.MQ(kp);
+                    uint32_t pv;
+                    if (kp < k0 || kp >= k0 + NE) pv = ls.MQ(kp);
+                    else { pv = eq[0];
+#pragma unroll
+                        for (int i = 1; i < NE; i++) if (kp - k0 == i) pv = eq[i]; }
                     const int32_t pq = (int32_t)(pv >> 5);
                     if ((pv & 16u) && pq >= sg.y && pq < a) osq = pq + 1;
                 }

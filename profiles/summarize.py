@@ -128,11 +128,35 @@ def normpmc(fetch_dir, write_dir, rows_dir, out, tag):
     print({k: round(v / 1e9, 3) for k, v in doc.items() if isinstance(v, int)}, "quad factor", round(quad_mult, 3))
 
 
+def edgespmc(fetch_dir, write_dir, out, tag):
+    """The edge-count leg (bench.py --legs edges): k_parse_cs<false> + k_edges per pass."""
+    f = pmc_avg(fetch_dir, "FETCH_SIZE")
+    w = pmc_avg(write_dir, "WRITE_SIZE")
+    doc = {"collected": "profiles/collect.sh " + tag + " (bench.py --legs edges under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+           "note": "KiB per launch as counted in raw_kib_per_launch.  k_parse_cs reads the cs text 16 bytes per lane: FETCH_SIZE doubled "
+                   "(MI355X_MICROARCH.md).  k_edges reads scattered 64-byte sectors (a byte or a nibble per usable (read, hetSNP)): an "
+                   "uncalibrated width, taken as counted.  The averages are over every launch of the process: k_parse_cs also runs in "
+                   "the headline's steps, with the same input.",
+           "raw_kib_per_launch": {}}
+    for k in sorted(set(f) | set(w)):
+        short = k.split("::")[-1].split("<")[0]
+        if short not in ("k_parse_cs", "k_edges"):
+            continue
+        doc["raw_kib_per_launch"][k] = {"FETCH_SIZE": f.get(k, 0.0), "WRITE_SIZE": w.get(k, 0.0)}
+        doc[short] = int(f.get(k, 0.0) * 1024 * (2.0 if short == "k_parse_cs" else 1.0) + w.get(k, 0.0) * 1024)
+    doc["pass_total"] = int(doc.get("k_parse_cs", 0) + doc.get("k_edges", 0))
+    with open(out, "w") as fh:
+        json.dump(doc, fh, indent=1, sort_keys=True)
+    print({k: round(v / 1e9, 3) for k, v in doc.items() if isinstance(v, int)})
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "edgespmc":
+        edgespmc(*sys.argv[2:6])
     elif sys.argv[1] == "normpmc":
         normpmc(*sys.argv[2:7])
     else:
