@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 for c in "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" "SQ_INSTS_BRANCH SQ_INSTS_SMEM" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT"; do
   tag=$(echo $c | tr ' ' '_')
   rm -rf gpurun_out/pmcc_$tag
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcc_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcc.log 2>&1 || echo "failed $c"
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcc_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs '' > gpurun_out/pmcc.log 2>&1 || echo "failed $c"
 done
 python3 - <<'PY'
 import csv, glob, collections
