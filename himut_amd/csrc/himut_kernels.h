@@ -1275,26 +1275,25 @@ struct CaptureArgs {
     uint8_t* ccs_flag;
 };
 
-constexpr int CLQ = 128;    // candidate list entries per wave (circular, power of two)
+constexpr int CLQ = 512;    // marked positions a wave keeps at a time: 16-bit offsets from the list's first word
 constexpr int CSG = 63;     // segments per LDS window (+ 1 sentinel = one per lane)
 constexpr int CWQ = 2048;   // query bases per window
-constexpr int CPL = 33;     // reference positions per lane when the bitmap is enumerated: 31 + 33 = 64 bits of a
-                            // word pair at most; 64 lanes take 2112 positions per pass
+constexpr int CPL = 256;    // reference positions per lane when the bitmap is enumerated (eight words): 64 lanes take 16 k
+                            // positions per pass, a read's span in one or two
 constexpr int CPD = 2;      // windows in flight (register sets, at most 4); the loop is unrolled by it
 
 // One wave per read; a software pipeline over windows of 2048 query bases.
 //
 // Window k is [c_k, c_k + 2048) of the query.  The segment list turns it into a reference
 // range [tA_k, tB_k) (a deleted position goes with the base that follows it); those ranges
-// tile the read's span.  Every turn of the loop
+// tile the read's span.  The read's marked positions (the bitmap of column positions under its span) are listed once,
+// 16 k positions a turn, as 16-bit offsets in LDS (refill).  Every turn of the loop
 //   * stores the window's bytes -- 2 KB of qualities + 1 KB of packed bases, loaded two
-//     turns earlier (four, CPD) with 16-byte coalesced loads -- in LDS,
-//   * issues the same five loads for window k + 4 (three for the bytes, one for the
-//     candidate bitmap under it, one for the block table under it): the addresses depend
-//     only on the segment list, never on loaded data, so nothing in the loop waits on a
-//     load younger than four turns and the count of loads in flight is the same every turn,
-//   * compacts the candidate bits of [tA_k, tB_k) -- one wave prefix sum -- into a list, and
-//     handles the list one candidate per lane: segment by binary search in LDS, query
+//     turns earlier (CPD) with 16-byte coalesced loads -- in LDS,
+//   * issues the same four loads for window k + CPD (three for the bytes, one for the block table under it): the
+//     addresses depend only on the segment list, never on loaded data, so nothing in the loop waits on a
+//     load younger than CPD turns and the count of loads in flight is the same every turn,
+//   * takes the list's next entries below tB_k, one per lane: segment from a cursor that walks the list once, query
 //     offset, base and quality out of the window in LDS, slot from the block table.
 // Every byte of the read is fetched exactly once; stores return nothing.
 #ifndef HIMUT_CAP_WAVES
@@ -1305,7 +1304,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     __shared__ __align__(16) uint8_t s_sq[4][CWQ / 2];
     __shared__ __align__(16) int4 s_seg[4][CSG + 1];
     __shared__ __align__(16) uint32_t s_bt[4][64];        // 16 block-table entries
-    __shared__ uint2 s_list[4][CLQ];
+    __shared__ uint16_t s_list[4][CLQ];
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
     const Reads& R = A.R;
     const PosIndex& X = A.X;
@@ -1337,7 +1336,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     uint8_t* wsq = s_sq[wv];
     int4* lseg = s_seg[wv];
     uint32_t* lbt = s_bt[wv];
-    uint2* list = s_list[wv];
+    uint16_t* list = s_list[wv];
     const bool all_lds = ns <= CSG;     // the whole segment list fits the LDS window
 
     // the windows start at query offset 0, soft clip included: the quality mean of the read filter is over the
@@ -1351,17 +1350,13 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     // does not have to wait for every load in flight
 #define CAP_LANDED4(V) asm volatile("" : "+v"(V.x), "+v"(V.y), "+v"(V.z), "+v"(V.w))
 #define CAP_LANDED2(V) asm volatile("" : "+v"(V.x), "+v"(V.y))
-    // the five loads of one window (addresses clamped into the read, so every lane always loads)
-#define CAP_ISSUE(BA, BB, SQ, S1, BT, K, TA) do { \
+    // the four loads of one window (addresses clamped into the read, so every lane always loads)
+#define CAP_ISSUE(BA, BB, SQ, BT, K, TA) do { \
         const int32_t _c = c0 + min((K), nwin - 1) * CWQ; \
         const int32_t _qa = min(_c + lane * 16, qpad - 16), _qb = min(_c + 1024 + lane * 16, qpad - 16), _qs = min(_c + lane * 32, qpad - 32); \
         BA = *reinterpret_cast<const uint4*>(R.bq + qo + _qa); \
         BB = *reinterpret_cast<const uint4*>(R.bq + qo + _qb); \
         SQ = *reinterpret_cast<const uint4*>(R.seq + ((qo + _qs) >> 1)); \
-        { \
-            const int64_t _w = min(((int64_t)(TA) + CPL * lane) >> 5, X.nwords - 1); \
-            __builtin_memcpy(&S1, X.bits + _w, 8);             /* nwords + 2 words are allocated */ \
-        } \
         BT = reinterpret_cast<const uint32_t*>(X.bt + min((int64_t)((TA) >> 8) + (lane >> 2), X.nblk - 1))[lane & 3]; \
     } while (0)
 #define CAP_SEGWIN() do { if (lane <= nw) { int4 z = make_int4(0x7fffffff, 0, 0, 0); if (jb + lane < ns) z = *reinterpret_cast<const int4*>(gsegs + jb + lane); \
@@ -1371,9 +1366,8 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     int jb = 0, nw = min(ns, CSG);
     CAP_SEGWIN();
     uint4 ba0, bb0, sq0, ba1, bb1, sq1, ba2, bb2, sq2, ba3, bb3, sq3;
-    uint2 s10, s11, s12, s13;
     uint32_t bt0r, bt1r, bt2r, bt3r;
-    CAP_ISSUE(ba0, bb0, sq0, s10, bt0r, 0, tstart);
+    CAP_ISSUE(ba0, bb0, sq0, bt0r, 0, tstart);
     // rank of the first column position at or behind tstart: the block's first rank + the bits in front of tstart
     const uint32_t rk0 = uni(X.bt[min((int64_t)(tstart >> 8), X.nblk - 1)].ufirst) +
                          uni(pos_rank_in_block(X.bits, (int32_t)min((int64_t)tstart, (X.nblk << 8) - 1) & ~31));
@@ -1407,21 +1401,80 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     int32_t ta[5];
     ta[0] = tstart;
     ta[1] = window_end(0);
-    CAP_ISSUE(ba1, bb1, sq1, s11, bt1r, 1, ta[1]);
+    CAP_ISSUE(ba1, bb1, sq1, bt1r, 1, ta[1]);
     ta[2] = window_end(1);
-    if constexpr (CPD > 2) { CAP_ISSUE(ba2, bb2, sq2, s12, bt2r, 2, ta[2]); ta[3] = window_end(2); }
-    if constexpr (CPD > 3) { CAP_ISSUE(ba3, bb3, sq3, s13, bt3r, 3, ta[3]); ta[4] = window_end(3); }
-    // rank of the first candidate position at or behind tstart
-    uint32_t ubase = 0;
-    {
-        const uint32_t w0 = (uint32_t)lane_val((int)s10.x, 0);
-        ubase = rk0 + (uint32_t)__popc(w0 & ((1u << (tstart & 31)) - 1u));
-        if ((int64_t)(tstart >> 5) > X.nwords - 1) ubase = rk0;
-    }
-    int head = 0, n = 0;   // the list: entries head .. head + n - 1 (mod CLQ)
+    if constexpr (CPD > 2) { CAP_ISSUE(ba2, bb2, sq2, bt2r, 2, ta[2]); ta[3] = window_end(2); }
+    if constexpr (CPD > 3) { CAP_ISSUE(ba3, bb3, sq3, bt3r, 3, ta[3]); ta[4] = window_end(3); }
+    // ---- the read's marked positions, taken from the bitmap 16 k positions at a time (a read's span in one or two turns)
+    //      into a list the windows then consume in order: list[i] = position - lbase, entries i_list .. n_list - 1 not yet
+    //      used, all the marked positions of [.., covB) are in it or done with; u_list = the rank of list[0] among the
+    //      contig's marked positions (the column's number: the block's first rank + what lies in front of tstart in it)
+    int32_t covB = tstart, lbase = tstart & ~31;
+    uint32_t u_list = rk0;
+    int n_list = 0, i_list = 0;
+    bool first_fill = true;
+    auto refill = [&]() {
+        u_list += (uint32_t)n_list; n_list = 0; i_list = 0;
+        lbase = covB & ~31;
+        for (int pass = 0; pass < 4 && covB <= tend; pass++) {          // (offsets stay below 2^16)
+            const int32_t s0 = covB & ~31;
+            const int64_t w0 = ((int64_t)s0 >> 5) + 8 * lane;
+            uint32_t w[8];
+            {
+                uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+                if (w0 + 8 <= X.nwords + 2) {                               // (nwords + 2 words are allocated)
+                    __builtin_memcpy(&a, X.bits + w0, 16);
+                    __builtin_memcpy(&b, X.bits + w0 + 4, 16);
+                } else {
+                    uint32_t t[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) t[i] = (w0 + i < X.nwords) ? X.bits[w0 + i] : 0u;
+                    a = make_uint4(t[0], t[1], t[2], t[3]); b = make_uint4(t[4], t[5], t[6], t[7]);
+                }
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+            }
+            if (first_fill) {       // what the block's rank does not count yet: the bits of tstart's word in front of it
+                u_list += (uint32_t)__popc((uint32_t)lane_val((int)w[0], 0) & ((1u << (tstart & 31)) - 1u));
+                first_fill = false;
+            }
+            // positions in front of covB (they lie in the first word of lane 0) and behind tend (the read's last turn) are not
+            // the read's
+            const int32_t p_lane = s0 + CPL * lane;
+            if (lane == 0) w[0] &= 0xffffffffu << (covB - s0);
+            const int32_t keep = tend + 1 - p_lane;                        // this lane's leading positions that are the read's
+            if (__ballot(keep < CPL)) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int32_t ki = keep - 32 * i;
+                    if (ki < 32) w[i] &= ki <= 0 ? 0u : ((1u << ki) - 1u);
+                }
+            }
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) cnt += __popc(w[i]);
+            const int incl = wave_incl_add(cnt, lane);
+            // the lanes whose positions still fit the list, from lane 0 on
+            const unsigned long long fitb = __ballot(n_list + incl <= CLQ);
+            const int L = fitb == ~0ULL ? 64 : (int)__builtin_ctzll(~fitb);
+            if (lane < L) {
+                int at = n_list + incl - cnt;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    uint32_t b = w[i];
+                    const int32_t off = p_lane + 32 * i - lbase;
+                    while (b) { const int k = __ffs((int)b) - 1; b &= b - 1; list[at++] = (uint16_t)(off + k); }
+                }
+            }
+            if (L > 0) n_list += lane_val(incl, L - 1);
+            covB = s0 + CPL * L;
+            if (L < 64) break;                                              // the list is full up to here
+        }
+        if (covB > tend) covB = tend + 1;
+        __builtin_amdgcn_wave_barrier();
+    };
     int jcur = 0;          // segment cursor of the candidate walk
 
-    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint2& s1, uint32_t& btv, const int k) {
+    auto window = [&](uint4& ba, uint4& bb, uint4& sq, uint32_t& btv, const int k) {
         const int32_t tA = ta[0], tB = ta[1];
         const int32_t cq = c0 + k * CWQ;
         // ---- this window's bytes and tables -> LDS; its registers take window k + 2
@@ -1452,11 +1505,7 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
                 }
             }
         }
-        // the window's bitmap words move to registers of their own: the ones they arrived in are reloaded next
-        uint32_t mylo, myhi;
-        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mylo), "=&v"(myhi) : "v"(s1.x), "v"(s1.y));
-        const unsigned long long mybits = ((unsigned long long)myhi << 32) | mylo;
-        CAP_ISSUE(ba, bb, sq, s1, btv, k + CPD, ta[CPD]);
+        CAP_ISSUE(ba, bb, sq, btv, k + CPD, ta[CPD]);
         const int32_t ta_next = window_end(k + CPD);
         __builtin_amdgcn_wave_barrier();
         const int64_t btb = tA >> 8;
@@ -1507,59 +1556,22 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
                 }
             }
         };
-        {
-        // ---- candidate bits of [tA, tB): lane l takes the CPL positions from tA + CPL * l
-        for (int32_t pg = tA; pg < tB; pg += 64 * CPL) {
-            const int32_t p0 = pg + CPL * lane;
-            unsigned long long pair = mybits;
-            if (pg != tA) {                                // a window across more than 2112 positions (long deletions)
-                uint2 t = make_uint2(0, 0);
-                __builtin_memcpy(&t, X.bits + min((int64_t)(p0 >> 5), X.nwords - 1), 8);
-                CAP_LANDED2(t);
-                pair = ((unsigned long long)t.y << 32) | t.x;
+        // ---- the marked positions of [tA, tB): the next entries of the list, a lane each (a window holds about twenty);
+        //      the list is filled again where the window reaches beyond what it covers
+        while (true) {
+            const int32_t hiP = min(tB, covB);
+            int32_t e = 0x7fffffff;
+            if (i_list + lane < n_list) e = lbase + (int32_t)list[i_list + lane];
+            const bool act = e < hiP;
+            const int bn = (int)__popcll(__ballot(act));                     // (the list is in order: the first bn lanes)
+            if (bn) {
+                batch(act, (uint32_t)e, u_list + (uint32_t)(i_list + lane), lane_val(e, bn - 1));
+                i_list += bn;
             }
-            const int nvalid = min(tB - p0, CPL);          // <= 0 behind the window (also where the address was clamped)
-            unsigned long long bits = 0;
-            if (nvalid > 0) bits = (pair >> (p0 & 31)) & ((1ULL << nvalid) - 1ULL);
-            const int cnt = __popcll(bits);
-            const int incl = wave_incl_add(cnt, lane);
-            const int total = lane_val(incl, 63);
-            int done = 0, basecnt = 0;
-            while (true) {
-                // ---- compaction: the lanes whose bits still fit go into the list
-                const bool fit = lane >= done && n + incl - basecnt <= CLQ;
-                const int nfit = __popcll(__ballot(fit));
-                if (fit) {
-                    int slot = head + n + (incl - cnt - basecnt);
-                    unsigned long long b = bits;
-                    uint32_t uu = ubase + (uint32_t)(incl - cnt);
-                    while (b) {
-                        const int i = __ffsll((long long)b) - 1;
-                        b &= b - 1;
-                        list[slot & (CLQ - 1)] = make_uint2((uint32_t)(p0 + i), uu);
-                        slot++; uu++;
-                    }
-                }
-                if (nfit) {
-                    const int inc = lane_val(incl, done + nfit - 1);
-                    n += inc - basecnt; basecnt = inc; done += nfit;
-                }
-                __builtin_amdgcn_wave_barrier();
-                // ---- one candidate per lane; the list is emptied before the window's bytes go away
-                const bool last_piece = done >= 64 && !(pg + 64 * CPL < tB);
-                while (n >= 64 || ((done < 64 || last_piece) && n > 0)) {
-                    const int bn = min(n, 64);
-                    const bool act = lane < bn;
-                    uint32_t rpos = 0, u = 0;
-                    if (act) { const uint2 e = list[(head + lane) & (CLQ - 1)]; rpos = e.x; u = e.y; }
-                    batch(act, rpos, u, lane_val((int)rpos, bn - 1));
-                    head = (head + bn) & (CLQ - 1); n -= bn;
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (done >= 64) break;
-            }
-            ubase += (uint32_t)total;
-        }
+            if (bn == 64) continue;
+            if (tB <= covB || covB > tend) break;
+            __builtin_amdgcn_wave_barrier();
+            refill();
         }
 #pragma unroll
         for (int i = 0; i < CPD; i++) ta[i] = ta[i + 1];
@@ -1569,10 +1581,10 @@ __device__ __forceinline__ void capture_wave(const CaptureArgs& A) {
     // CPD windows per trip, each with its own registers; the last ones of a trip may lie behind the
     // read (empty range): it still issues its loads, so the number in flight never depends on the path
     for (int k = 0; k < nwin; k += CPD) {
-        window(ba0, bb0, sq0, s10, bt0r, k);
-        window(ba1, bb1, sq1, s11, bt1r, k + 1);
-        if constexpr (CPD > 2) window(ba2, bb2, sq2, s12, bt2r, k + 2);
-        if constexpr (CPD > 3) window(ba3, bb3, sq3, s13, bt3r, k + 3);
+        window(ba0, bb0, sq0, bt0r, k);
+        window(ba1, bb1, sq1, bt1r, k + 1);
+        if constexpr (CPD > 2) window(ba2, bb2, sq2, bt2r, k + 2);
+        if constexpr (CPD > 3) window(ba3, bb3, sq3, bt3r, k + 3);
     }
     {
         if (A.bqsum) {

@@ -105,3 +105,18 @@ def test_call_parameter_sweep_phase_oracle_parity(worker, tmp_path, min_hap, ext
     p.update(extra)
     recs, log = _compare(worker, b, chunks, p, phase_sets=phase_sets)
     assert log[1] > 0
+
+
+def test_call_reads_with_thousands_of_marked_positions(worker):
+    """One error in 300 bases at 60x: a tenth of the reference positions carry some read's substitution, a read crosses two
+    thousand of them -- the capture keeps 512 marked positions of its read at a time and fills the list again inside a
+    window -- and reads span more than the 16 k positions one pass over the bitmap takes."""
+    from himut_amd import synth, util as hutil
+    s = synth.generate(synth.SynthConfig(seed=131, contig_len=150_000, depth=60.0, sub_rate=3e-3, som_rate=2e-4,
+                                         read_len_mean=19000, read_len_sd=2500, read_len_min=9000, read_len_max=26000, name="chrM"))
+    b = s.batch
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((b.name, 0, b.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=8000, qlen_upper_limit=30000, md_threshold=200, min_sequence_identity=0.9, max_mismatch_count=50)
+    recs, log = _compare(worker, b, chunks, p)
+    assert log[1] > 1000
