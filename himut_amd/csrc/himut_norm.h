@@ -912,9 +912,9 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
 }
 
 // ---------------------------------------------------------------------------------------
-// A position k_norm_col does not classify itself -- its column holds a base of another allele than the reference's, or
+// A position k_norm_quad does not classify itself -- its column holds a base of another allele than the reference's, or
 // hom-ref is not the smallest of its genotype sums by itself: everything the column walk knows about it.  One position in
-// thirty; k_norm_dirty takes them a lane each, where inside k_norm_col the general classification would run for a lane or
+// thirty; k_norm_dirty takes them a lane each, where inside k_norm_quad the general classification would run for a lane or
 // two of a wave, every other wave, and set the kernel's registers.
 struct NormDirty {
     int64_t rpos;
@@ -958,7 +958,7 @@ __global__ void __launch_bounds__(256) k_norm_dirty(NormArgs A, const NormDirty*
         }
         double R0 = d.R[0], R1 = d.R[1], R2 = d.R[2];
         uint32_t nref = d.nref, tri_sum = d.tri_sum, h0 = d.h0, h1 = d.h1;
-        const bool bq0 = false;                                       // (a zero quality ended the column in k_norm_col)
+        const bool bq0 = false;                                       // (a zero quality ended the column in k_norm_quad)
         NORM_CLASSIFY()
     }
     __syncthreads();
