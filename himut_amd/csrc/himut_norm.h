@@ -724,7 +724,12 @@ __global__ void __launch_bounds__(256, HIMUT_NT_WAVES) k_norm_tile(NormArgs A, D
     // (Speed only: any mapping gives the same counts.)
     // A workgroup goes through several such tiles (its counters go to memory once): XCD class r = blockIdx.x & 7 owns the
     // tiles [r * per, (r + 1) * per) of the chunk and its NT_Q workgroups take NT_Q neighbouring ones per step.
-    const int64_t per = tiles_per_class;
+    // (per: by THIS chunk's length -- with the longest chunk's figure a short chunk would sit on the first XCDs only)
+    int64_t per = tiles_per_class;
+    if (!redo) {
+        const int64_t span = (int64_t)A.C.end[blockIdx.y] - (int64_t)A.C.start[blockIdx.y];
+        per = min(per, ((span + 255) / 256 + 7) / 8);
+    }
     const int64_t wg = redo ? (int64_t)blockIdx.x + (int64_t)blockIdx.y * gridDim.x : (int64_t)(blockIdx.x >> 3);
     const int64_t wgs = redo ? (int64_t)gridDim.x * gridDim.y : (int64_t)(gridDim.x >> 3);
     for (int64_t t = wg; t < (redo ? nlist : per); t += wgs) {

@@ -342,7 +342,9 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
     const uint32_t o_q = 4u * (uint32_t)lane;                   // this lane's offset into a spanning piece's 256 qualities
     constexpr int NB = HIMUT_NQ_NB;
     static_assert(NB == 4, "the switches below are written for four places");
-    const int64_t per = tiles_per_class;
+    // workgroup tiles per XCD class, by THIS chunk's length (chunks differ under --phase: with the longest chunk's figure the
+    // short ones would sit on the first few XCDs only)
+    const int64_t per = min(tiles_per_class, (((int64_t)(ce_ - cs_) + NQ_WG_COLS - 1) / NQ_WG_COLS + 7) / 8);
     for (int64_t t = blockIdx.x >> 3; t < per; t += (int64_t)(gridDim.x >> 3)) {         // the tile mapping of k_norm_tile
         const int64_t tile = ((int64_t)(blockIdx.x & 7) * per + t) * NQ_WAVES + wv;       // this wave's 256 positions
         const int64_t base64 = (int64_t)cs_ + tile * NQ_COLS;
