@@ -102,7 +102,7 @@ struct himut_ctx {
     DevBuf d_cstart, d_cend, d_maskoff, d_tileoff, d_sstart, d_sidx, d_spmax, d_rlo, d_rhi, d_pairoff, d_hint, d_crec, d_mtile;
     std::vector<int32_t> up_cs, up_ce;   // the chunk list the device tables were built for
     bool tables_valid = false, chunks_in_order = false;
-    int64_t up_positions = 0, up_tiles = 0, up_pairs = 0;
+    int64_t up_positions = 0, up_tiles = 0, up_pairs = 0, up_maxpairs = 0;
     int64_t nhint = 0;
     std::vector<int64_t> maskoff, tileoff;
     DevBuf d_pon, d_com, d_posbits;
@@ -246,7 +246,7 @@ Derived make_derived(himut_ctx* c) {
 
 // Uploads the chunk tables for the given chunk list and the current reads.
 struct ChunkTables {
-    int64_t n = 0, positions = 0, n_tiles = 0, npairs = 0;
+    int64_t n = 0, positions = 0, n_tiles = 0, npairs = 0, maxpairs = 0;   // maxpairs: the most reads under one chunk
 };
 
 ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const std::vector<int32_t>& ce) {
@@ -255,7 +255,7 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
     const int64_t n = (int64_t)cs.size();
     T.n = n;
     if (c->tables_valid && cs == c->up_cs && ce == c->up_ce) {   // same chunks, same reads: the tables are on the device
-        T.positions = c->up_positions; T.n_tiles = c->up_tiles; T.npairs = c->up_pairs;
+        T.positions = c->up_positions; T.n_tiles = c->up_tiles; T.npairs = c->up_pairs; T.maxpairs = c->up_maxpairs;
         return T;
     }
     c->maskoff.assign(n + 1, 0);
@@ -284,6 +284,7 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
         rhi[k] = std::lower_bound(c->h_tstart.begin(), c->h_tstart.end(), ce[k]) - c->h_tstart.begin();
         if (rhi[k] < rlo[k]) rhi[k] = rlo[k];
         pairoff[k + 1] = pairoff[k] + (rhi[k] - rlo[k]);
+        T.maxpairs = std::max<int64_t>(T.maxpairs, rhi[k] - rlo[k]);
     }
     T.npairs = pairoff[n];
     // look-up hint: for each 16-kb block of positions, the number of sorted starts <= block start
@@ -332,7 +333,7 @@ ChunkTables upload_chunks(himut_ctx* c, const std::vector<int32_t>& cs, const st
     upload(c->d_rlo, rlo, st); upload(c->d_rhi, rhi, st); upload(c->d_pairoff, pairoff, st);
     HCHECK(hipStreamSynchronize(st));  // the host vectors above go out of scope
     c->up_cs = cs; c->up_ce = ce; c->tables_valid = true;
-    c->up_positions = T.positions; c->up_tiles = T.n_tiles; c->up_pairs = T.npairs;
+    c->up_positions = T.positions; c->up_tiles = T.n_tiles; c->up_pairs = T.npairs; c->up_maxpairs = T.maxpairs;
     return T;
 }
 
@@ -567,7 +568,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow, bool defer) {
         stage_event(c, EV_PARSE, 2, st);
     }
     if (phase && T.npairs > 0)
-        hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
+        hipLaunchKernelGGL(k_read_hap, dim3((unsigned)blocks_for(T.maxpairs, 16), (unsigned)T.n), dim3(256), 0, st, R, D, C, H, &sc->err);
     stage_event(c, EV_HAP, 2, st);
 
     // ---- columns: per 256-position block the column positions and the read window -> one scan -> the block table
@@ -1337,7 +1338,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
         hipLaunchKernelGGL(k_callable, dim3(blocks_for(c->n, 4)), dim3(256), 0, st, R, D, c->params, c->d_live.as<uint8_t>(),
                            c->d_callable.as<uint32_t>(), c->d_ccs.as<uint8_t>());
         if (phase && T.npairs > 0) {
-            hipLaunchKernelGGL(k_read_hap, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, R, D, C, H, T.npairs, &sc->err);
+            hipLaunchKernelGGL(k_read_hap, dim3((unsigned)blocks_for(T.maxpairs, 16), (unsigned)T.n), dim3(256), 0, st, R, D, C, H, &sc->err);
             hipLaunchKernelGGL(k_pair_ccs, dim3(blocks_for(T.npairs, 256)), dim3(256), 0, st, C, H, R, c->d_live.as<uint8_t>(),
                                T.npairs, c->d_ccs.as<uint8_t>());
         }

@@ -6,7 +6,7 @@
 //                      identity (cslib.py:7-64, bamlib.py:47-63); sets the bitmap of column positions (the
 //                      substitutions of the reads that pass the filters known so far); checks the cs bases against
 //                      SEQ; on its way every wave stores its share of the EMPTY column store
-//   k_read_hap         (--phase) one thread per (chunk, read): haplib.py:46-83
+//   k_read_hap         (--phase) sixteen lanes per (chunk, read), a lane per hetSNP: haplib.py:46-83
 //   k_window_index     per 256-position block: the range of reads that can cover it (once per pushed batch)
 //   k_block_sums / k_block_table3
 //                      per 256-position block the number of column positions and of column-store slots, their
@@ -754,33 +754,49 @@ __global__ void __launch_bounds__(256) k_check_longcs(Reads R, Derived D, int* e
 
 // ---------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------
-// k_read_hap: thread per (chunk, read-in-window) pair; haplib.get_ccs_hap (haplib.py:61-83).
-__global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, Phase H, int64_t npairs, int* err) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= npairs) return;
-    const int64_t c = upper_bound(C.pairoff, (int64_t)0, C.n + 1, k) - 1;
-    const int64_t r = C.rlo[c] + (k - C.pairoff[c]);
+// k_read_hap: sixteen lanes per (chunk, read-in-window) pair; haplib.get_ccs_hap (haplib.py:61-83).
+__global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, Phase H, int* err) {
+    // chunk = blockIdx.y; sixteen lanes per (chunk, read) pair, a lane per heterozygous SNP of the chunk's phase set under the
+    // read: each finds its segment by a search of its own and fetches its base, instead of one thread walking up to forty
+    // of them in turn
+    const int64_t c = blockIdx.y;
+    const int64_t kin = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;       // the pair's place in the chunk's window
+    const int gl = threadIdx.x & 15;
+    const int64_t p0 = C.pairoff[c];
+    if (kin >= C.pairoff[c + 1] - p0) return;
+    const int64_t k = p0 + kin;
+    const int64_t r = C.rlo[c] + kin;
     uint8_t hap = HAP_NONE;
     const int32_t s = C.start[c], e = C.end[c];
-    if (!(D.rflag[r] & RF_SECONDARY) && R.tstart[r] < e && R.tend[r] > s) {
+    const int32_t ts = R.tstart[r], te = R.tend[r];
+    if (!(D.rflag[r] & RF_SECONDARY) && ts < e && te > s) {
         const int32_t* hpos = H.hpos;
         const int64_t a = H.off[c], b = H.off[c + 1];
-        const int64_t idx = upper_bound(hpos, a, b, R.tstart[r]);  // bisect_right, haplib.py:68-69
-        const int64_t jdx = upper_bound(hpos, a, b, R.tend[r]);
+        // bisect_right of the read's start and end among the set's positions (haplib.py:68-69): counted, sixteen at a time
+        int n_le_s = 0, n_le_e = 0;
+        for (int64_t g = a + gl; g < b; g += 16) { const int32_t hp = hpos[g]; n_le_s += hp <= ts ? 1 : 0; n_le_e += hp <= te ? 1 : 0; }
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) { n_le_s += __shfl_xor(n_le_s, d, 16); n_le_e += __shfl_xor(n_le_e, d, 16); }
+        const int64_t idx = a + n_le_s, jdx = a + n_le_e;
         if (jdx - idx >= 2) {
-            bool all0 = true, all1 = true;
+            bool all0 = true, all1 = true, uncovered = false;
             const Seg* segs = D.segs + seg_base(R, r);
             const int ns = D.nseg[r];
-            int j = 0;
-            for (int64_t g = idx; g < jdx; g++) {
+            const int64_t qo = R.qoff[r];
+            for (int64_t g = idx + gl; g < jdx; g += 16) {
                 const int32_t rpos = hpos[g] - 1;
-                while (j < ns && rpos >= segs[j].t0 + segs[j].len) j++;
+                // the first segment that ends behind rpos (segments are in order and do not overlap)
+                int lo = 0, hi = ns;
+                while (lo < hi) { const int m = (lo + hi) >> 1; if (rpos >= segs[m].t0 + segs[m].len) lo = m + 1; else hi = m; }
                 int qb = 0;  // 0: not in tpos2qbase -> KeyError
-                if (j < ns && rpos >= segs[j].t0) {
-                    if (segs[j].flags & SEG_DEL) qb = '-';
-                    else qb = nib2char(nib_at(R.seq, R.qoff[r] + segs[j].q0 + (rpos - segs[j].t0)));
+                if (lo < ns) {
+                    const Seg sg = segs[lo];
+                    if (rpos >= sg.t0) {
+                        if (sg.flags & SEG_DEL) qb = '-';
+                        else qb = nib2char(nib_at(R.seq, qo + sg.q0 + (rpos - sg.t0)));
+                    }
                 }
-                if (qb == 0) { set_err(err, HIMUT_ERR_COVER); all0 = all1 = false; break; }
+                if (qb == 0) { uncovered = true; continue; }
                 int bit = '-';
                 if (H.href[g] && qb == H.href[g]) bit = '0';        // haplib.py:52-57
                 else if (H.halt[g] && qb == H.halt[g]) bit = '1';
@@ -789,10 +805,20 @@ __global__ void __launch_bounds__(256) k_read_hap(Reads R, Derived D, Chunks C, 
                 if (bit != h0) all0 = false;
                 if (bit != h1) all1 = false;
             }
-            hap = all0 ? HAP_0 : (all1 ? HAP_1 : HAP_NONE);
+            // the pair's sixteen lanes agree (they sit in one row of the wave)
+            int v0 = all0 ? 1 : 0, v1 = all1 ? 1 : 0, vu = uncovered ? 1 : 0;      // (every lane takes part in every exchange)
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1) {
+                v0 &= __shfl_xor(v0, d, 16);
+                v1 &= __shfl_xor(v1, d, 16);
+                vu |= __shfl_xor(vu, d, 16);
+            }
+            all0 = v0 != 0; all1 = v1 != 0; uncovered = vu != 0;
+            if (uncovered) { if (gl == 0) set_err(err, HIMUT_ERR_COVER); }
+            else hap = all0 ? HAP_0 : (all1 ? HAP_1 : HAP_NONE);
         }
     }
-    H.hap[k] = hap;
+    if (gl == 0) H.hap[k] = hap;
 }
 
 // ---------------------------------------------------------------------------------------

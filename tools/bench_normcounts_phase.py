@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--contig-len", type=int, default=64_444_167)
+    ap.add_argument("--call", action="store_true", help="time himut_run (the call path) on the same contig and chunks instead")
     ap.add_argument("--no-phase", action="store_true", help="the same chunks (the phase blocks) without --phase: what the chunking costs by itself")
     a = ap.parse_args()
     import numpy as np
@@ -44,6 +45,17 @@ def main():
     ctx.push_reads(b)
     if not a.no_phase:
         ctx.set_phase(*caller.pack_phase_sets(chunks, dict(hb[b.name]), dict(hp[b.name]), dict(hs[b.name])))
+    if a.call:
+        ctx.set_stage_timing(2)
+        rows = []
+        for k in range(a.steps + 2):
+            ctx.run()
+            if k >= 2:
+                rows.append(ctx.stats())
+        keys = [k for k in rows[0] if k.startswith("ms_")]
+        print(json.dumps({"chunks": len(chunks), "phase": not a.no_phase, "records": int(rows[-1]["n_records"]),
+                          **{k: float(np.mean([r[k] for r in rows])) for k in keys}}))
+        return
     refseq = bytes(s.ref)
     chars, cls = normcounts.tri_classes(refseq)
     ctx.set_reference(refseq, cls, len(chars))
