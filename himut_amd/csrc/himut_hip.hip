@@ -487,6 +487,7 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow, bool defer) {
     c->d_tilecnt.reserve((size_t)mtiles * 4 + 64);
     c->d_tileoff2.reserve((size_t)mtiles * 4 + 64);
     const bool clear_all = clear_mask || tcnt_was != c->d_tilecnt.p;
+    if (phase && T.n > 65535) return fail(c, HIMUT_ERR_ARG, "--phase: more than 65,535 chunks in one contig (k_read_hap takes a chunk per grid row)");
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
     // bitmap of column positions: probed at every position a read covers, so it spans reads as well as chunks; the
     // read windows and the column offsets are kept per 256 positions of the same span
@@ -1278,6 +1279,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     memset(&c->stats, 0, sizeof(c->stats));
     c->params.unique_qnames = c->unique_qnames ? 1 : 0;
 
+    if (c->cstart.size() > 65535) return fail(c, HIMUT_ERR_ARG, "more than 65,535 chunks in one contig (the sweep's grids take a chunk per row)");
     ChunkTables T = upload_chunks(c, c->cstart, c->cend);
     alloc_derived(c);
     Reads R = make_reads(c);
