@@ -1301,14 +1301,17 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     const bool sweep_quad = !sweep_tile;
     // the sweep's grid (workgroups of NQ_WAVES waves, a wave per 256 positions; NQ_Q workgroups per XCD class and chunk),
     // and the list of the positions k_norm_quad leaves to k_norm_dirty (a column with another allele: one in thirty): a part
-    // per workgroup, room for one of its positions in six
+    // per workgroup, room for one of its positions in four
     int32_t maxspan = 1;
     for (size_t k = 0; k < c->cstart.size(); k++) maxspan = std::max(maxspan, c->cend[k] - c->cstart[k]);
     const int64_t q_per = ((int64_t)blocks_for(maxspan, NQ_WG_COLS) + 7) / 8;             // workgroup tiles of a chunk per XCD class
-    const unsigned q_gx = 8u * (unsigned)std::min<int64_t>(NQ_Q, q_per);
+    // (NQ_Q workgroups per class and chunk keep a wave on a dozen tiles of a long contig; a contig of a few chunks gets
+    //  more of them, so that the grid still fills the chip: about 4096 workgroups where the tiles allow)
+    const int64_t q_want = std::max<int64_t>(NQ_Q, (4096 + 8 * std::max<int64_t>(T.n, 1) - 1) / (8 * std::max<int64_t>(T.n, 1)));
+    const unsigned q_gx = 8u * (unsigned)std::min<int64_t>(q_want, q_per);
     const int64_t q_regions = (int64_t)q_gx * (int64_t)std::max<int64_t>(T.n, 1);
     const int64_t q_tiles_per_wg = (q_per + (q_gx / 8) - 1) / (q_gx / 8);
-    int64_t dirty_cap = std::max<int64_t>(q_tiles_per_wg * NQ_WG_COLS / 6, 128);
+    int64_t dirty_cap = q_tiles_per_wg * NQ_WAVES * NQ_SLOTS + 64;     // (what the waves' pools can hold: a quarter of the positions)
     dirty_cap = std::min<int64_t>(std::max(dirty_cap, c->norm_dirty_room), q_tiles_per_wg * NQ_WG_COLS);
     if (c->dbg_norm_dirty_cap > 0 && attempt == 0) dirty_cap = c->dbg_norm_dirty_cap;   // (tests: the first pass overflows)
     // tiles left to k_norm_tile (more pieces than the plan holds, more columns with another allele than a wave's pool): room for
@@ -1408,7 +1411,7 @@ int do_normcounts(himut_ctx* c, const uint8_t* alt_order, int non_human, bool fo
     HCHECK(hipMemcpyAsync(c->h_tri.data(), c->d_tri.p, (2 * ntri + 16) * 8, hipMemcpyDeviceToHost, st));
     HCHECK(hipMemcpyAsync(&hs, sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
     HCHECK(hipStreamSynchronize(st));
-    // The list of positions left to k_norm_dirty was too short in some part (a region where more than one position in six
+    // The list of positions left to k_norm_dirty was too short in some part (a region where more than one position in four
     // holds another allele: deep piles, a sample far from the reference): the same sweep once more with the room the
     // counters say it needs -- the context keeps it for its later passes, as himut_run keeps its capacities.  The list of
     // tiles was too short (or the room still is, which the counters rule out): the whole contig with k_norm_tile.

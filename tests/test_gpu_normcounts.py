@@ -107,7 +107,7 @@ def test_normcounts_golden_tile_sweep(worker, case):
 @pytest.mark.parametrize("case", ["norm_dense", "norm_sets", "norm_phase"])
 def test_normcounts_left_over_positions_do_not_fit(worker, case):
     """k_norm_quad hands the positions it does not classify itself (a column with another allele) to k_norm_dirty through
-    a list with a part per workgroup, sized for one position in six; when a part is too short the sweep is repeated once
+    a list with a part per workgroup, sized for one position in four; when a part is too short the sweep is repeated once
     with the room its counters ask for, and the context keeps that room.  A list with one entry per part: the same golden
     vectors, one repeat."""
     reran, _ = _golden_with(worker, case, dirty_cap=1)
