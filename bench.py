@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--contig-len", type=int, default=CHR20_LEN)
     ap.add_argument("--depth", type=float, default=30.0)
+    ap.add_argument("--error-rate", type=float, default=None,
+                    help="NOT the headline workload: substitution, insertion and deletion rate each of the synthetic reads "
+                         "(generator defaults 2e-4 / 1e-4 / 1e-4), for the sensitivity table of DESIGN.md")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=24.0)
     ap.add_argument("--legs", default="queued,normcounts,edges,e2e",
@@ -449,6 +452,8 @@ def main():
     t_gen = time.perf_counter()
     names = ["chr{}".format(20 + k) for k in range(world)]   # one chr20-sized contig per rank
     cfg = synth.SynthConfig(seed=2 + rank, contig_len=a.contig_len, depth=a.depth, name=names[rank])
+    if a.error_rate is not None:
+        cfg.sub_rate = cfg.ins_rate = cfg.del_rate = a.error_rate
     legs = [x for x in a.legs.split(",") if x] if world == 1 else []
     sample = synth.generate(cfg, want_ref="normcounts" in legs)
     batch = batch_keep = sample.batch
@@ -591,7 +596,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "chr20-sized contig ({} bp) {:.0f}x synthetic CCS per GPU, common-SNP + PoN "
                                    "filtering, reference chunking ({} chunks)".format(a.contig_len, a.depth,
-                                                                                        len(chunks)),
+                                                                                        len(chunks)) +
+                                   ("" if a.error_rate is None else "; NOT the default reads: error rates {:g} each".format(a.error_rate)),
                        "reads_per_gpu": st["n_reads"], "read_bases_per_gpu": st["read_bases"],
                        "parallelism": "contig-per-gpu x{} + RCCL gather".format(world)},
             "candidate_sites_per_sec": cand_sites / (elapsed / a.steps),

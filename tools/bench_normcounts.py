@@ -19,13 +19,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)       # (the leg always makes two untimed passes first)
     ap.add_argument("--contig-len", type=int, default=64_444_167)
     ap.add_argument("--depth", type=float, default=30.0)
+    ap.add_argument("--error-rate", type=float, default=None, help="substitution, insertion and deletion rate each (generator defaults: 2e-4, 1e-4, 1e-4)")
+    ap.add_argument("--bq93-prob", type=float, default=None, help="fraction of the bases with quality 93 (the generator's default if not given)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=16.0)
     a = ap.parse_args()
     from himut_amd import bamlib, caller, synth, util as hutil
     import bench as B
 
-    sample = synth.generate(synth.SynthConfig(seed=2, contig_len=a.contig_len, depth=a.depth, name="chr20"), want_ref=True)
+    extra = {} if a.bq93_prob is None else {"bq93_prob": a.bq93_prob}
+    if a.error_rate is not None:
+        extra.update(sub_rate=a.error_rate, ins_rate=a.error_rate, del_rate=a.error_rate)
+    sample = synth.generate(synth.SynthConfig(seed=2, contig_len=a.contig_len, depth=a.depth, name="chr20", **extra), want_ref=True)
     batch = sample.batch
     chunks = [(c[1], c[2]) for c in hutil.chunkloci((batch.name, 0, batch.length))]
     ql, qu, md = bamlib.get_thresholds({batch.name: batch}, [batch.name], {batch.name: batch.length})
