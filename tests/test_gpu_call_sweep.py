@@ -120,3 +120,18 @@ def test_call_reads_with_thousands_of_marked_positions(worker):
     p.update(qlen_lower_limit=8000, qlen_upper_limit=30000, md_threshold=200, min_sequence_identity=0.9, max_mismatch_count=50)
     recs, log = _compare(worker, b, chunks, p)
     assert log[1] > 1000
+
+
+def test_call_indel_heavy_reads(worker):
+    """An insertion or a deletion every 250 bases: dozens of segments a read (the capture's segment window in LDS is walked
+    and reloaded), long mismatch lists in the window filter -- against the oracle."""
+    from himut_amd import synth, util as hutil
+    s = synth.generate(synth.SynthConfig(seed=133, contig_len=150_000, depth=40.0, sub_rate=1e-3, ins_rate=2e-3, del_rate=2e-3,
+                                         som_rate=2e-4, name="chrJ"))
+    b = s.batch
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((b.name, 0, b.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=8000, qlen_upper_limit=30000, md_threshold=200, min_sequence_identity=0.9, max_mismatch_count=6,
+             mismatch_window_size=30)
+    recs, log = _compare(worker, b, chunks, p)
+    assert log[1] > 100

@@ -143,6 +143,26 @@ def test_normcounts_noisy_contig_goes_tile_by_tile_to_the_tile_kernel(worker):
     assert st["reran"] == 0 and st["column_slots"] > 150_000 // 256 // 2
 
 
+def test_normcounts_indel_heavy_reads(worker):
+    """An insertion or a deletion every 250 bases (and a substitution every 1000): a read's piece over a tile is cut in two or
+    three, nearly every word of the bit array lies near a mismatch entry, reads have more segments than the plan's first
+    look takes in -- against the oracle."""
+    from oracle import oracle as O
+    from himut_amd import normcounts, synth, util as hutil
+    s = synth.generate(synth.SynthConfig(seed=47, contig_len=120_000, depth=40.0, sub_rate=1e-3, ins_rate=2e-3, del_rate=2e-3,
+                                         name="chrI"), want_ref=True)
+    refseq = bytes(s.ref)
+    chunks = [(c[1], c[2]) for c in hutil.chunkloci((s.batch.name, 0, s.batch.length))]
+    p = dict(util.CALL_DEFAULTS)
+    p.update(qlen_lower_limit=9000, qlen_upper_limit=22500, md_threshold=80, min_sequence_identity=0.9, max_mismatch_count=3)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+    o_ccs, o_ref, o_log = O.normcounts(s.batch, chunks, p, refseq, p["germline_snv_prior"], alt_order=order)
+    _configure(worker, p)
+    ccs, rf, log = normcounts.norm_contig(worker, s.batch, chunks, refseq, alt_order=order)
+    assert log == o_log and ccs == o_ccs and rf == o_ref
+    assert log[13] > 0
+
+
 def test_normcounts_soft_clips_and_failing_reads(worker):
     """Long soft clips (the sweep's loads start behind them), a fifth of the reads failing the quality filter, a fifth the
     mapping-quality filter (piled, not counted), against the oracle."""
