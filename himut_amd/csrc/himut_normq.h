@@ -383,17 +383,15 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
         }
         // ---- per-column state
         double R0[4], R1[4], R2[4];
-        uint32_t nref[4], tri[4];
+        uint32_t nref[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { R0[j] = 0.0; R1[j] = 0.0; R2[j] = 0.0; nref[j] = 0; tri[j] = 0; }
-        uint32_t tri4b = 0;                    // callable bases of the running batch, a byte per column
+        for (int j = 0; j < 4; j++) { R0[j] = 0.0; R1[j] = 0.0; R2[j] = 0.0; nref[j] = 0; }
+        // callable bases per column, a byte each: a tile has at most NQ_ITEMS = 128 pieces, so a byte holds the count (and the
+        // counts of the reads of either haplotype, --phase, likewise)
+        static_assert(NQ_ITEMS <= 255, "byte counters per column");
+        uint32_t tri4b = 0;
         uint32_t slotmap = 0xffffffffu;        // pool slot per column (255: none)
-        uint32_t h0g[4], h1g[4];               // (phase) the reads of either haplotype with a base in the column
-        uint32_t h0b = 0, h1b = 0;
-        if (phase) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { h0g[j] = 0; h1g[j] = 0; }
-        }
+        uint32_t h0b = 0, h1b = 0;             // (phase) the reads of either haplotype with a base in the column
         if (lane == 0) pool.n = 0;
         __builtin_amdgcn_wave_barrier();
 
@@ -567,15 +565,6 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
                     }
                 }
             }
-            // ---- the batch's byte counters into the columns' words
-#pragma unroll
-            for (int j = 0; j < 4; j++) tri[j] += (tri4b >> (8 * j)) & 255u;
-            tri4b = 0;
-            if (phase) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) { h0g[j] += (h0b >> (8 * j)) & 255u; h1g[j] += (h1b >> (8 * j)) & 255u; }
-                h0b = 0; h1b = 0;
-            }
         }
         // ---- the pool ran out somewhere in the wave: the 256 positions go to k_norm_tile as they are
         if (__ballot((fl >> NQF_OVER) & 1u)) {
@@ -601,10 +590,10 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
             constexpr bool rot = !NQ_CLS_UNROLL;
             const int jj = rot ? 0 : j;
             const uint32_t code = (uint32_t)(codes >> (rot ? 0 : 16 * j)) & 0xffffu;
-            const uint32_t tri_sum = tri[jj];
+            const uint32_t tri_sum = (tri4b >> (rot ? 0 : 8 * j)) & 255u;
             const bool cls = ((fl >> (NQF_CLS + (rot ? 0 : j))) & 1u) && tri_sum != 0;
             uint32_t h0 = 0, h1 = 0;
-            if (phase) { h0 = h0g[jj]; h1 = h1g[jj]; }
+            if (phase) { h0 = (h0b >> (rot ? 0 : 8 * j)) & 255u; h1 = (h1b >> (rot ? 0 : 8 * j)) & 255u; }
             const bool hapfail = phase && cls && !((int32_t)h0 >= min_hap && (int32_t)h1 >= min_hap);
             const bool q0 = cls && !hapfail && ((fl >> (NQF_ZERO + (rot ? 0 : j))) & 1u);
             bad |= q0 ? (1 << HIMUT_ERR_BQ0) : 0;
@@ -679,8 +668,8 @@ k_norm_quad(NormArgs A, const uint32_t* __restrict__ callable, int64_t nbases, c
             if (rot) {                                       // the next column into place
                 R0[0] = R0[1]; R0[1] = R0[2]; R0[2] = R0[3]; R1[0] = R1[1]; R1[1] = R1[2]; R1[2] = R1[3];
                 R2[0] = R2[1]; R2[1] = R2[2]; R2[2] = R2[3];
-                nref[0] = nref[1]; nref[1] = nref[2]; nref[2] = nref[3]; tri[0] = tri[1]; tri[1] = tri[2]; tri[2] = tri[3];
-                if (phase) { h0g[0] = h0g[1]; h0g[1] = h0g[2]; h0g[2] = h0g[3]; h1g[0] = h1g[1]; h1g[1] = h1g[2]; h1g[2] = h1g[3]; }
+                nref[0] = nref[1]; nref[1] = nref[2]; nref[2] = nref[3]; tri4b >>= 8;
+                if (phase) { h0b >>= 8; h1b >>= 8; }
                 fl = (fl >> 1) & 0x77007u;                   // (the one-bit fields move down; the alleles are not looked at here)
                 slotmap >>= 8; codes >>= 16;
             }
