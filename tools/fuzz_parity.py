@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Randomised parity of the HIP paths with the oracle (test infrastructure: the oracle is the checker).  Every round draws a
+synthetic contig (length, depth, error rates, read lengths, soft clips, noisy / low-quality / low-mapq reads, qualities up
+to 255 in some), thresholds, a chunking (the reference's 200 kb tiles or random regions) and --phase or not, runs himut call's
+worker and the normcounts sweep on the GPU and the oracle on the CPU, and compares records, counters and counts bit for bit.
+Prints one line per round and stops at the first difference with the seed that reproduces it.
+
+    python tools/fuzz_parity.py --rounds 40 --seed 1 [--minutes 8]
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--minutes", type=float, default=8.0)
+    a = ap.parse_args()
+    import numpy as np
+    from himut_amd import caller, normcounts, synth, util as hutil, vcflib
+    from himut_amd.readbatch import ReadBatch
+    from oracle import oracle as O
+    from tests import util
+    w = caller.Worker(0)
+    order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
+    t_end = time.time() + a.minutes * 60
+    for rnd in range(a.rounds):
+        if time.time() > t_end:
+            break
+        seed = a.seed * 1000 + rnd
+        rs = np.random.RandomState(seed)
+        lg = lambda lo, hi: float(np.exp(rs.uniform(np.log(lo), np.log(hi))))
+        phase = bool(rs.rand() < 0.3)
+        rl = float(rs.choice([6000, 10000, 15000, 20000]))
+        cfg = synth.SynthConfig(seed=seed, contig_len=int(rs.randint(30_000, 260_000)), depth=float(rs.choice([6, 15, 30, 45, 80])),
+                                sub_rate=lg(1e-5, 3e-3), ins_rate=lg(1e-5, 2e-3), del_rate=lg(1e-5, 2e-3), som_rate=lg(1e-5, 5e-4),
+                                snp_rate=lg(2e-4, 3e-3), read_len_mean=rl, read_len_sd=rl / 6, read_len_min=int(rl / 3), read_len_max=int(rl * 1.7),
+                                frac_noisy=float(rs.choice([0, 0.05, 0.3])), frac_lowbq=float(rs.choice([0, 0.1])),
+                                frac_lowmapq=float(rs.choice([0, 0.1])), frac_softclip=float(rs.choice([0, 0.3])), softclip_max=3000,
+                                hetalt_frac=float(rs.choice([0, 0.05])), name="chrF")
+        s = synth.generate(cfg, want_ref=True)
+        b = s.batch
+        if rs.rand() < 0.3:                                    # qualities of 94 .. 255 in some reads
+            bq = b.bq.copy()
+            idx = rs.randint(0, len(bq), 5000)
+            bq[idx] = rs.randint(94, 256, 5000)
+            b = ReadBatch(name=b.name, length=b.length, tstart=b.tstart, tend=b.tend, qstart=b.qstart, qlen=b.qlen, mapq=b.mapq,
+                          flag=b.flag, qid=b.qid, qoff=b.qoff, cs_off=b.cs_off, seq=b.seq, bq=bq, cs=b.cs, tp=b.tp)
+        p = dict(util.CALL_DEFAULTS)
+        p.update(qlen_lower_limit=int(rl / 2.5), qlen_upper_limit=int(rl * 1.6), md_threshold=int(rs.choice([20, 60, 400])),
+                 min_bq=int(rs.choice([0, 20, 60, 93, 93, 93, 150])), min_qv=int(rs.choice([0, 20, 30])),
+                 min_sequence_identity=float(rs.choice([0.0, 0.9, 0.99])), min_trim=float(rs.choice([0.0, 0.01, 0.1])),
+                 max_mismatch_count=int(rs.choice([0, 0, 1, 4])), mismatch_window_size=int(rs.choice([0, 10, 20, 60])),
+                 min_gq=int(rs.choice([0, 20, 60])), min_ref_count=int(rs.choice([0, 3, 10])), min_alt_count=int(rs.choice([1, 2])),
+                 min_hap_count=int(rs.choice([0, 3])))
+        phase_sets = None
+        if phase:
+            with tempfile.TemporaryDirectory() as d:
+                pv = os.path.join(d, "p.vcf")
+                synth.write_phased_vcf(pv, s, block=int(rs.choice([8, 40])))
+                hb, hp, hs, c2c = vcflib.load_phased_hetsnps(pv, [b.name], {b.name: b.length})
+            if b.name not in c2c or not c2c[b.name]:
+                phase = False
+            else:
+                phase_sets = (dict(hb[b.name]), dict(hp[b.name]), dict(hs[b.name]))
+                chunks = [(c[1], c[2]) for c in c2c[b.name]]
+        if not phase:
+            if rs.rand() < 0.5:
+                chunks = [(c[1], c[2]) for c in hutil.chunkloci((b.name, 0, b.length))]
+            else:                                              # random regions in order (they may touch or overlap)
+                cuts = np.sort(rs.randint(0, b.length, 2 * int(rs.randint(1, 6))))
+                chunks = [(int(cuts[i]), int(max(cuts[i + 1], cuts[i] + 1))) for i in range(0, len(cuts), 2)]
+        sites = [(int(x) + 1, chr(r), chr(al)) for x, r, al in zip(s.snp_pos, s.snp_ref, s.snp_alt)]
+        pon = O.site_keys(sites[::3])
+        com = O.site_keys(sites[1::3])
+        what = "seed {} len {} depth {:.0f} sub {:.1e} ins {:.1e} del {:.1e} readlen {:.0f} chunks {} phase {} min_bq {} win {}/{}".format(
+            seed, b.length, cfg.depth, cfg.sub_rate, cfg.ins_rate, cfg.del_rate, rl, len(chunks), phase, p["min_bq"],
+            p["max_mismatch_count"], p["mismatch_window_size"])
+        t0 = time.time()
+        # ---- the call path
+        orecs = oerr = None
+        try:
+            orecs, olog = O.call(b, chunks, p, p["germline_snv_prior"], pon, com, phase_sets)
+        except Exception as e:                                  # noqa: BLE001 -- the reference raises: so must the library
+            oerr = type(e).__name__
+        herr = None
+        try:
+            w.configure(p["min_qv"], p["min_mapq"], p["qlen_lower_limit"], p["qlen_upper_limit"], p["min_sequence_identity"],
+                        p["min_gq"], p["min_bq"], p["min_trim"], p["max_mismatch_count"], p["mismatch_window_size"],
+                        p["md_threshold"], p["min_ref_count"], p["min_alt_count"], p["min_hap_count"], p["germline_snv_prior"], phase)
+            hrecs, hlog = w.call_contig(b, chunks, pon, com, phase_sets)
+        except Exception as e:                                  # noqa: BLE001
+            herr = type(e).__name__
+        if (oerr is None) != (herr is None):
+            print("DIFFERENT (call: oracle raised {}, library raised {}): {}".format(oerr, herr, what)); return 1
+        if oerr is None:
+            ok = hlog == olog and len(hrecs) == len(orecs) and all(np.array_equal(hrecs[k], orecs[k]) for k in (
+                "tpos", "chunk", "phase_set", "gq", "ref", "alt", "gt0", "gt1", "status", "gt_state", "counts", "bqsum"))
+            if not ok:
+                print("DIFFERENT (call): " + what); return 1
+        # ---- the normcounts sweep
+        refseq = bytes(s.ref)
+        oerr = herr = None
+        try:
+            o_ccs, o_ref, o_log = O.normcounts(b, chunks, p, refseq, p["germline_snv_prior"], pon, com, alt_order=order, phase=phase_sets)
+        except Exception as e:                                  # noqa: BLE001
+            oerr = type(e).__name__
+        try:
+            ccs, rf, log = normcounts.norm_contig(w, b, chunks, refseq, pon, com, False, order, phase_sets=phase_sets)
+        except Exception as e:                                  # noqa: BLE001
+            herr = type(e).__name__
+        if (oerr is None) != (herr is None):
+            print("DIFFERENT (normcounts: oracle raised {}, library raised {}): {}".format(oerr, herr, what)); return 1
+        if oerr is None and not (log == o_log and ccs == o_ccs and rf == o_ref):
+            print("DIFFERENT (normcounts): " + what); return 1
+        print("ok  {:5.1f} s  records {}  callable {}  {}".format(time.time() - t0, -1 if orecs is None else len(orecs),
+                                                                  -1 if oerr else o_log[13], what), flush=True)
+    print("fuzz ok")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
