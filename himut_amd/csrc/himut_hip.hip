@@ -42,6 +42,8 @@ struct HipFail {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    uint64_t gen = 0;      // counts the allocations: a block that was freed and allocated again may come back at the SAME address,
+                           // with other contents -- who keeps track of what a buffer holds compares this, not the pointer
     ~DevBuf() { if (p) (void)hipFree(p); }
     void reserve(size_t bytes) {
         if (bytes <= cap && p) return;
@@ -50,7 +52,7 @@ struct DevBuf {
         if (p) { HCHECK(hipDeviceSynchronize()); HCHECK(hipFree(p)); p = nullptr; cap = 0; }
         size_t want = std::max<size_t>(bytes, 256);
         HCHECK(hipMalloc(&p, want));
-        cap = want;
+        cap = want; gen++;
     }
     // grows to at least `bytes` keeping the first `used` bytes (the ingest's arrays grow while they are being filled)
     void grow_keep(size_t bytes, size_t used) {
@@ -61,7 +63,7 @@ struct DevBuf {
         HCHECK(hipMalloc(&q, want));
         if (p && used) HCHECK(hipMemcpy(q, p, std::min(used, cap), hipMemcpyDeviceToDevice));
         if (p) HCHECK(hipFree(p));
-        p = q; cap = want;
+        p = q; cap = want; gen++;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -478,15 +480,15 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow, bool defer) {
     const size_t mask_bytes = (size_t)n4 * 16;
     const int64_t anyw = ((int64_t)T.positions + 31) / 32;        // the mask sweeps take 32 cells per thread
     const unsigned mtiles = blocks_for(anyw, 256);
-    const void* mask_was = c->d_mask.p;
+    const uint64_t mask_was = c->d_mask.gen;
     c->d_mask.reserve(mask_bytes + 64);
     // the emit sweep zeroes what the propose kernel set: a buffer that went through a whole run is clean
-    const bool clear_mask = !c->mask_clean || mask_was != c->d_mask.p;
+    const bool clear_mask = !c->mask_clean || mask_was != c->d_mask.gen;
     c->mask_clean = false;
-    const void* tcnt_was = c->d_tilecnt.p;
+    const uint64_t tcnt_was = c->d_tilecnt.gen;
     c->d_tilecnt.reserve((size_t)mtiles * 4 + 64);
     c->d_tileoff2.reserve((size_t)mtiles * 4 + 64);
-    const bool clear_all = clear_mask || tcnt_was != c->d_tilecnt.p;
+    const bool clear_all = clear_mask || tcnt_was != c->d_tilecnt.gen;
     if (phase && T.n > 65535) return fail(c, HIMUT_ERR_ARG, "--phase: more than 65,535 chunks in one contig (k_read_hap takes a chunk per grid row)");
     if (phase) c->d_hap.reserve((size_t)T.npairs + 64);
     // bitmap of column positions: probed at every position a read covers, so it spans reads as well as chunks; the
@@ -504,9 +506,9 @@ int do_run_once(himut_ctx* c, bool allow_spec, bool* overflow, bool defer) {
         // buffer in the middle of a run would free it under the kernels already queued on it)
         c->d_winlo.reserve((size_t)nblk * 4 + 64);
         c->d_winhi.reserve((size_t)nblk * 4 + 64);
-        const void* bits_was = c->d_posbits_c.p;
+        const uint64_t bits_was = c->d_posbits_c.gen;
         c->d_posbits_c.reserve((size_t)(nwords + 2) * 4 + 256);
-        if (bits_was != c->d_posbits_c.p) c->lead_clean_bytes = 0;
+        if (bits_was != c->d_posbits_c.gen) c->lead_clean_bytes = 0;
         c->d_posrank.reserve((size_t)idx_wgs * sizeof(uint4) + 256);      // per-workgroup totals of the column index
         c->d_blkslots.reserve((size_t)nblk * 4 + 256); c->d_blkoff.reserve((size_t)nblk * 4 + 256);
         c->d_blktab.reserve((size_t)nblk * sizeof(BlockTab) + 256);

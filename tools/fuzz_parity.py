@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--minutes", type=float, default=8.0)
+    ap.add_argument("--start", type=int, default=0, help="skip the rounds in front of this one (the seeds stay what they are)")
+    ap.add_argument("--verbose", action="store_true", help="say where a round differs")
+    ap.add_argument("--only", type=int, default=None, help="run the one round with this seed and say where it differs")
     a = ap.parse_args()
     import numpy as np
     from himut_amd import caller, normcounts, synth, util as hutil, vcflib
@@ -31,10 +34,10 @@ def main():
     w = caller.Worker(0)
     order = {"A": ["T", "G", "C"], "T": ["C", "A", "G"], "G": ["A", "C", "T"], "C": ["G", "T", "A"]}
     t_end = time.time() + a.minutes * 60
-    for rnd in range(a.rounds):
+    for rnd in range(a.start, a.rounds) if a.only is None else [0]:
         if time.time() > t_end:
             break
-        seed = a.seed * 1000 + rnd
+        seed = a.seed * 1000 + rnd if a.only is None else a.only
         rs = np.random.RandomState(seed)
         lg = lambda lo, hi: float(np.exp(rs.uniform(np.log(lo), np.log(hi))))
         phase = bool(rs.rand() < 0.3)
@@ -104,7 +107,21 @@ def main():
             ok = hlog == olog and len(hrecs) == len(orecs) and all(np.array_equal(hrecs[k], orecs[k]) for k in (
                 "tpos", "chunk", "phase_set", "gq", "ref", "alt", "gt0", "gt1", "status", "gt_state", "counts", "bqsum"))
             if not ok:
-                print("DIFFERENT (call): " + what); return 1
+                print("DIFFERENT (call): " + what)
+                if a.only is not None or a.verbose:
+                    print("chunks", chunks)
+                    print("log oracle ", olog); print("log library", hlog, " records", len(orecs), len(hrecs))
+                    ko = set((int(r["tpos"]), int(r["chunk"]), int(r["ref"]), int(r["alt"])) for r in orecs)
+                    kh = set((int(r["tpos"]), int(r["chunk"]), int(r["ref"]), int(r["alt"])) for r in hrecs)
+                    print("library only:", sorted(kh - ko)[:40]); print("oracle only:", sorted(ko - kh)[:40])
+                    print("reads", len(b.tstart), "last read starts", b.tstart[-5:], "ends", b.tend[-5:])
+                    n = min(len(orecs), len(hrecs))
+                    for k in ("tpos", "chunk", "phase_set", "gq", "ref", "alt", "gt0", "gt1", "status", "gt_state", "counts", "bqsum"):
+                        d = np.nonzero(np.any(np.atleast_2d((hrecs[k][:n] != orecs[k][:n]).reshape(n, -1)), axis=1) if n else np.zeros(0))[0]
+                        if len(d):
+                            i = int(d[0])
+                            print("field", k, "first difference at record", i, "of", len(d), ": oracle", orecs[i], "| library", hrecs[i]); break
+                return 1
         # ---- the normcounts sweep
         refseq = bytes(s.ref)
         oerr = herr = None
@@ -120,8 +137,10 @@ def main():
             print("DIFFERENT (normcounts: oracle raised {}, library raised {}): {}".format(oerr, herr, what)); return 1
         if oerr is None and not (log == o_log and ccs == o_ccs and rf == o_ref):
             print("DIFFERENT (normcounts): " + what); return 1
-        print("ok  {:5.1f} s  records {}  callable {}  {}".format(time.time() - t0, -1 if orecs is None else len(orecs),
-                                                                  -1 if oerr else o_log[13], what), flush=True)
+        print("ok  {:5.1f} s  records {}  callable {}  {}{}".format(time.time() - t0, -1 if orecs is None else len(orecs),
+                                                                    -1 if oerr else o_log[13], what,
+                                                                    "" if orecs is not None and not oerr else "  [raised: call {} normcounts {}]".format(
+                                                                        "yes" if orecs is None else "no", oerr)), flush=True)
     print("fuzz ok")
     return 0
 
