@@ -47,7 +47,11 @@ def main():
                                 snp_rate=lg(2e-4, 3e-3), read_len_mean=rl, read_len_sd=rl / 6, read_len_min=int(rl / 3), read_len_max=int(rl * 1.7),
                                 frac_noisy=float(rs.choice([0, 0.05, 0.3])), frac_lowbq=float(rs.choice([0, 0.1])),
                                 frac_lowmapq=float(rs.choice([0, 0.1])), frac_softclip=float(rs.choice([0, 0.3])), softclip_max=3000,
-                                hetalt_frac=float(rs.choice([0, 0.05])), name="chrF")
+                                hetalt_frac=float(rs.choice([0, 0.05])), cs_long=bool(rs.rand() < 0.15),
+                                pile_frac=float(rs.choice([0, 0, 0.05])), pile_mult=float(rs.choice([3, 6])), name="chrF")
+        if rs.rand() < 0.1:
+            cfg.depth = 150.0
+            cfg.contig_len = min(cfg.contig_len, 90_000)
         s = synth.generate(cfg, want_ref=True)
         b = s.batch
         if rs.rand() < 0.3:                                    # qualities of 94 .. 255 in some reads
@@ -137,6 +141,23 @@ def main():
             print("DIFFERENT (normcounts: oracle raised {}, library raised {}): {}".format(oerr, herr, what)); return 1
         if oerr is None and not (log == o_log and ccs == o_ccs and rf == o_ref):
             print("DIFFERENT (normcounts): " + what); return 1
+        # ---- the edge counts of himut phase, through the same context
+        if rs.rand() < 0.5:
+            hets = sorted(set((int(pp) + 1, chr(r), chr(al)) for pp, r, al, g in zip(s.snp_pos, s.snp_ref, s.snp_alt, s.snp_gt) if g in (1, 2)))
+            if len(hets) >= 2:
+                ebq, emq = int(rs.choice([0, 20, 93])), int(rs.choice([0, 20, 60]))
+                o_lst, o_e2c = O.edges(b, hets, ebq, emq)
+                hpos = np.array([h[0] for h in hets], np.int32)
+                href = np.array([ord(h[1]) for h in hets], np.uint8)
+                band = O.edge_band(b, hpos)
+                w.ctx.push_reads(b)
+                cnt = w.ctx.run_edges(hpos, href, ebq, emq, band).reshape(-1, 4)
+                h_e2c = {}
+                for e in np.flatnonzero(cnt.sum(1)):
+                    i, d = int(e) // band, int(e) % band
+                    h_e2c[(i, i + 1 + d)] = [float(x) for x in cnt[e]]
+                if sorted(h_e2c) != o_lst or h_e2c != o_e2c:
+                    print("DIFFERENT (edges): " + what); return 1
         print("ok  {:5.1f} s  records {}  callable {}  {}{}".format(time.time() - t0, -1 if orecs is None else len(orecs),
                                                                     -1 if oerr else o_log[13], what,
                                                                     "" if orecs is not None and not oerr else "  [raised: call {} normcounts {}]".format(
