@@ -60,6 +60,17 @@ def main():
             bq[idx] = rs.randint(94, 256, 5000)
             b = ReadBatch(name=b.name, length=b.length, tstart=b.tstart, tend=b.tend, qstart=b.qstart, qlen=b.qlen, mapq=b.mapq,
                           flag=b.flag, qid=b.qid, qoff=b.qoff, cs_off=b.cs_off, seq=b.seq, bq=bq, cs=b.cs, tp=b.tp)
+        zq = rs.rand() < 0.12                                    # a few zero qualities (ValueError in a candidate column)
+        nb = rs.rand() < 0.08 and not cfg.cs_long                # a few bases outside ATGC (KeyError where aligned and fetched)
+        if zq or nb:
+            bq, seq = b.bq.copy(), b.seq.copy()
+            if zq:
+                bq[rs.randint(0, len(bq), int(rs.choice([1, 20, 400])))] = 0
+            if nb:
+                k = rs.randint(0, len(seq), int(rs.choice([1, 5])))
+                seq[k] = (seq[k] & 0x0f) | 0xf0
+            b = ReadBatch(name=b.name, length=b.length, tstart=b.tstart, tend=b.tend, qstart=b.qstart, qlen=b.qlen, mapq=b.mapq,
+                          flag=b.flag, qid=b.qid, qoff=b.qoff, cs_off=b.cs_off, seq=seq, bq=bq, cs=b.cs, tp=b.tp)
         p = dict(util.CALL_DEFAULTS)
         p.update(qlen_lower_limit=int(rl / 2.5), qlen_upper_limit=int(rl * 1.6), md_threshold=int(rs.choice([20, 60, 400])),
                  min_bq=int(rs.choice([0, 20, 60, 93, 93, 93, 150])), min_qv=int(rs.choice([0, 20, 30])),
@@ -96,7 +107,7 @@ def main():
         try:
             orecs, olog = O.call(b, chunks, p, p["germline_snv_prior"], pon, com, phase_sets)
         except Exception as e:                                  # noqa: BLE001 -- the reference raises: so must the library
-            oerr = type(e).__name__
+            oerr = type(e).__name__ + ": " + str(e)[:120]
         herr = None
         try:
             w.configure(p["min_qv"], p["min_mapq"], p["qlen_lower_limit"], p["qlen_upper_limit"], p["min_sequence_identity"],
@@ -104,9 +115,15 @@ def main():
                         p["md_threshold"], p["min_ref_count"], p["min_alt_count"], p["min_hap_count"], p["germline_snv_prior"], phase)
             hrecs, hlog = w.call_contig(b, chunks, pon, com, phase_sets)
         except Exception as e:                                  # noqa: BLE001
-            herr = type(e).__name__
+            herr = type(e).__name__ + ": " + str(e)[:120]
+        if nb and oerr is None and herr is not None and ("error 3" in herr or "error 4" in herr):
+            # the N landed on a substitution: cs still names the old base, which the reference would pile (it takes a
+            # substitution's base from cs) and the library refuses (it takes every base from SEQ and checks the two agree:
+            # DESIGN section 5) -- an input no aligner writes
+            print("skip (N on a substitution: cs and SEQ disagree)  " + what, flush=True)
+            continue
         if (oerr is None) != (herr is None):
-            print("DIFFERENT (call: oracle raised {}, library raised {}): {}".format(oerr, herr, what)); return 1
+            print("DIFFERENT (call: oracle raised {}, library raised {}): {} [zero qualities {} N bases {} chunks {}]".format(oerr, herr, what, zq, nb, chunks)); return 1
         if oerr is None:
             ok = hlog == olog and len(hrecs) == len(orecs) and all(np.array_equal(hrecs[k], orecs[k]) for k in (
                 "tpos", "chunk", "phase_set", "gq", "ref", "alt", "gt0", "gt1", "status", "gt_state", "counts", "bqsum"))
