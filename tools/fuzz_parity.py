@@ -158,6 +158,21 @@ def main():
             print("DIFFERENT (normcounts: oracle raised {}, library raised {}): {}".format(oerr, herr, what)); return 1
         if oerr is None and not (log == o_log and ccs == o_ccs and rf == o_ref):
             print("DIFFERENT (normcounts): " + what); return 1
+        # ---- the BAM ingest: the batch written to a file, parsed on the device and by the host, compared byte for byte
+        if rs.rand() < 0.15 and b.length < 160_000:
+            from himut_amd import bamio
+            with tempfile.TemporaryDirectory() as d:
+                path = os.path.join(d, "f.bam")
+                bamio.write_bam(path, [b], sample="S")
+                host = bamio.BamFile(path, threads=2).batches[b.name]
+                st = bamio.BamStream(path, threads=3)
+                res = st.ingest_contig(w.ctx, b.name, window_bytes=int(rs.choice([96, 300, 1024])) << 10)
+                got = w.ctx.download_reads(res, b.name, st.tname2tsize[b.name])
+                st.close()
+            for k in ("tstart", "tend", "qstart", "qlen", "mapq", "flag", "qid", "qoff", "cs_off", "seq", "bq", "cs", "tp"):
+                x, y = getattr(got, k), getattr(host, k)
+                if x.shape != y.shape or not np.array_equal(x, y):
+                    print("DIFFERENT (ingest, field {}): {}".format(k, what)); return 1
         # ---- the edge counts of himut phase, through the same context
         if rs.rand() < 0.5:
             hets = sorted(set((int(pp) + 1, chr(r), chr(al)) for pp, r, al, g in zip(s.snp_pos, s.snp_ref, s.snp_alt, s.snp_gt) if g in (1, 2)))
