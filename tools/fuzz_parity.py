@@ -144,14 +144,25 @@ def main():
                             print("field", k, "first difference at record", i, "of", len(d), ": oracle", orecs[i], "| library", hrecs[i]); break
                 return 1
         # ---- the normcounts sweep
-        refseq = bytes(s.ref)
+        refseq = bytearray(bytes(s.ref))
+        if rs.rand() < 0.3:                                     # soft-masked stretches and runs of N in the FASTA (case matters: normcounts.py:320)
+            for _ in range(int(rs.randint(1, 6))):
+                a0 = int(rs.randint(0, len(refseq))); n0 = int(rs.choice([1, 3, 50, 3000]))
+                if rs.rand() < 0.5:
+                    refseq[a0:a0 + n0] = bytes(refseq[a0:a0 + n0]).lower()
+                else:
+                    refseq[a0:a0 + n0] = b"N" * len(refseq[a0:a0 + n0])
+        refseq = bytes(refseq)
+        nhs = bool(rs.rand() < 0.2)
+        perm = lambda x: [x[i] for i in rs.permutation(3)]
+        order_r = {r_: perm([c_ for c_ in "ATGC" if c_ != r_]) for r_ in "ATGC"} if rs.rand() < 0.5 else order
         oerr = herr = None
         try:
-            o_ccs, o_ref, o_log = O.normcounts(b, chunks, p, refseq, p["germline_snv_prior"], pon, com, alt_order=order, phase=phase_sets)
+            o_ccs, o_ref, o_log = O.normcounts(b, chunks, p, refseq, p["germline_snv_prior"], pon, com, alt_order=order_r, non_human_sample=nhs, phase=phase_sets)
         except Exception as e:                                  # noqa: BLE001
             oerr = type(e).__name__
         try:
-            ccs, rf, log = normcounts.norm_contig(w, b, chunks, refseq, pon, com, False, order, phase_sets=phase_sets)
+            ccs, rf, log = normcounts.norm_contig(w, b, chunks, refseq, pon, com, nhs, order_r, phase_sets=phase_sets)
         except Exception as e:                                  # noqa: BLE001
             herr = type(e).__name__
         if (oerr is None) != (herr is None):
