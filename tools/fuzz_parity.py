@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--minutes", type=float, default=8.0)
+    ap.add_argument("--scale", type=float, default=1.0, help="multiplies the contig lengths drawn (30 .. 260 kb at 1)")
     ap.add_argument("--start", type=int, default=0, help="skip the rounds in front of this one (the seeds stay what they are)")
     ap.add_argument("--verbose", action="store_true", help="say where a round differs")
     ap.add_argument("--only", type=int, default=None, help="run the one round with this seed and say where it differs")
@@ -42,7 +43,7 @@ def main():
         lg = lambda lo, hi: float(np.exp(rs.uniform(np.log(lo), np.log(hi))))
         phase = bool(rs.rand() < 0.3)
         rl = float(rs.choice([6000, 10000, 15000, 20000]))
-        cfg = synth.SynthConfig(seed=seed, contig_len=int(rs.randint(30_000, 260_000)), depth=float(rs.choice([6, 15, 30, 45, 80])),
+        cfg = synth.SynthConfig(seed=seed, contig_len=int(rs.randint(30_000, 260_000) * a.scale), depth=float(rs.choice([6, 15, 30, 45, 80])),
                                 sub_rate=lg(1e-5, 3e-3), ins_rate=lg(1e-5, 2e-3), del_rate=lg(1e-5, 2e-3), som_rate=lg(1e-5, 5e-4),
                                 snp_rate=lg(2e-4, 3e-3), read_len_mean=rl, read_len_sd=rl / 6, read_len_min=int(rl / 3), read_len_max=int(rl * 1.7),
                                 frac_noisy=float(rs.choice([0, 0.05, 0.3])), frac_lowbq=float(rs.choice([0, 0.1])),
@@ -170,7 +171,7 @@ def main():
         if oerr is None and not (log == o_log and ccs == o_ccs and rf == o_ref):
             print("DIFFERENT (normcounts): " + what); return 1
         # ---- the BAM ingest: the batch written to a file, parsed on the device and by the host, compared byte for byte
-        if rs.rand() < 0.15 and b.length < 160_000:
+        if rs.rand() < 0.15 and b.length < 160_000 * max(1.0, a.scale / 4):
             from himut_amd import bamio
             with tempfile.TemporaryDirectory() as d:
                 path = os.path.join(d, "f.bam")
