@@ -1,7 +1,7 @@
 // The position sweep of normcounts.get_callable_tricounts (src/himut/normcounts.py:113-140,315-402) in two kernels.
 //
-//   k_norm_plan   a wave per 256 positions of a chunk, a LANE per read of the window index under them: which gapless pieces
-//                 of which reads lie over the 256 positions, written as a list of ITEMS in read order (where a piece's
+//   k_norm_plan   a wave per four consecutive tiles of 256 positions of a chunk, a LANE per read of the window index under them:
+//                 which gapless pieces of which reads lie over each tile, written as a list of ITEMS in read order (where a piece's
 //                 bases sit in the arrays, its first position and length, whether it is a deletion, whether an insertion
 //                 precedes it, the read's haplotype).  Everything here is a chain of dependent look-ups -- window index,
 //                 read header, segment starts, segment -- and every chain is short and independent of every other, so the
@@ -12,9 +12,9 @@
 //                 four qualities (a 256-byte row per wave), a dword that holds the four packed bases, sixteen bits of the
 //                 callable bit array.  The reference allele's three ordered fp64 sums of the lane's four columns are four
 //                 independent chains (nq_pair: scheduled by hand); a cell of another allele -- one in a thousand -- sends
-//                 the lanes that hold one down a side path that adds to a small POOL of accumulators in LDS (thirty-two of
+//                 the lanes that hold one down a side path that adds to a small POOL of accumulators in LDS (sixty-four of
 //                 a wave's 256 columns may own one: nine doubles and four counts each).  An item that covers a part of the
-//                 positions takes the same update under a per-lane mask of cells.  At the end of a column: nothing but the
+//                 positions rides in the same batches of four under a per-lane mask of cells.  At the end of a column: nothing but the
 //                 reference allele in it makes the ten genotype sums four numbers and the kernel classifies the position
 //                 itself; the others go to k_norm_dirty's list (himut_norm.h).  A wave whose pool runs out, or whose
 //                 positions have more items than the plan holds, leaves them to k_norm_tile through a list of tiles.
@@ -26,13 +26,13 @@
 namespace himut {
 
 #ifndef HIMUT_NQ_NB
-#define HIMUT_NQ_NB 4            // spanning items whose loads are issued together
+#define HIMUT_NQ_NB 4            // pieces whose loads are issued together
 #endif
 #ifndef HIMUT_NQ_OCC
 #define HIMUT_NQ_OCC 4           // waves per SIMD asked of the register allocator
 #endif
 #ifndef HIMUT_NQ_Q
-#define HIMUT_NQ_Q 2             // workgroups per XCD class and chunk (neighbouring tiles: the mapping of k_norm_tile)
+#define HIMUT_NQ_Q 2             // workgroups per XCD class and chunk at least (a contig of few chunks gets more: do_normcounts)
 #endif
 constexpr int NQ_WAVES = 4;
 constexpr int NQ_COLS = 256;                       // positions per wave
